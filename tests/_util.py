@@ -1,0 +1,40 @@
+"""Shared helpers for the test-suite (golden fixture loading, tolerances)."""
+import ast
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Stated tolerances (SURVEY.md section 8c / BASELINE.md): the reference itself, fp32 vs fp64,
+# differs by 1e-7..1.2e-6 relative to max|y| on these shapes.
+FWD_RTOL = 1e-5      # max|y - y_ref64| <= FWD_RTOL * max|y_ref64|
+GRAD_RTOL = 1e-4     # max|g - g_ref64| <= GRAD_RTOL * max|g_ref64|
+
+
+def golden_files(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN, prefix + "_*.npz")))
+
+
+def load(path):
+    d = dict(np.load(path, allow_pickle=False))
+    shape = tuple(int(v) for v in d["S_shape"])
+    S = np.zeros(shape, dtype=np.float64)
+    S[d["S_e"], d["S_r"], d["S_c"]] = d["S_v"]
+    d["S"] = S
+    if "cfg" in d:
+        d["cfg"] = ast.literal_eval(str(d["cfg"]))
+    return d
+
+
+def relerr(a, ref):
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    denom = np.max(np.abs(ref))
+    return float(np.max(np.abs(a - ref)) / (denom if denom > 0 else 1.0))
+
+
+def case_id(path):
+    return os.path.splitext(os.path.basename(path))[0]

@@ -1,0 +1,146 @@
+"""Generate tests/golden/*.npz by running the REAL reference (alegnn @ /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+Every array is produced by the reference's own code (gml.LSIGF, gml.GraphFilter,
+archit.SelectionGNN and torch autograd through them) in float64, which is how the
+reference's examples run (examples/sourceLocGNN.py:40).  The import shims are the ones
+in SURVEY.md Appendix B.  The fixtures pin oracle/lsigf_oracle.py (tests/test_oracle_golden.py)
+and are the ground truth for the HIP parity tests (tests/test_gpu_parity.py).
+"""
+import os
+import pickle
+import sys
+import types
+
+for m in ("hdf5storage", "gensim"):            # dataTools.py:33, :4335 -- unused loaders
+    sys.modules[m] = types.ModuleType(m)
+import numpy as np
+import scipy.sparse  # noqa: F401  (import scipy before aliasing np.int)
+
+np.int = int
+np.float = float
+sys.path.insert(0, "/root/reference")
+import torch  # noqa: E402
+
+import alegnn.utils.graphML as gml  # noqa: E402
+import alegnn.utils.graphTools as gt  # noqa: E402
+import alegnn.modules.architectures as archit  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_default_dtype(torch.float64)
+
+
+def coo(S):
+    """dense [E,N,N] -> (rows, cols, vals, e) arrays to keep fixtures small."""
+    e, r, c = np.nonzero(S)
+    return dict(S_e=e.astype(np.int32), S_r=r.astype(np.int32), S_c=c.astype(np.int32), S_v=S[e, r, c],
+                S_shape=np.array(S.shape, dtype=np.int64))
+
+
+def lsigf_case(name, S, B, G, F, K, bias=True, seed=0):
+    rng = np.random.RandomState(seed)
+    E, N, _ = S.shape
+    h = rng.uniform(-1, 1, (F, E, K, G)) / np.sqrt(G * K)
+    x = rng.randn(B, G, N)
+    b = rng.uniform(-1, 1, (F, 1)) if bias else None
+    dy = rng.randn(B, F, N)
+    ht = torch.tensor(h, requires_grad=True)
+    xt = torch.tensor(x, requires_grad=True)
+    bt = torch.tensor(b, requires_grad=True) if bias else None
+    y = gml.LSIGF(ht, torch.tensor(S), xt, bt)                  # the reference itself
+    y.backward(torch.tensor(dy))
+    out = dict(h=h, x=x, dy=dy, y=y.detach().numpy(), dx=xt.grad.numpy(), dh=ht.grad.numpy(), **coo(S))
+    if bias:
+        out.update(b=b, db=bt.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, f"lsigf_{name}.npz"), **out)
+    print(f"lsigf_{name}: N={N} E={E} B={B} G={G} F={F} K={K} nnz={int((S != 0).sum())} max|y|={np.abs(out['y']).max():.3g}")
+
+
+def graph_filter_case(name, S, B, G, F, K, Nin, seed=0):
+    """GraphFilter.forward with Nin < N (zero-pad / slice path, graphML.py:2131-2143)."""
+    rng = np.random.RandomState(seed)
+    E, N, _ = S.shape
+    torch.manual_seed(seed)
+    layer = gml.GraphFilter(G, F, K, E, True)
+    layer.addGSO(torch.tensor(S))
+    x = rng.randn(B, G, Nin)
+    dy = rng.randn(B, F, Nin)
+    xt = torch.tensor(x, requires_grad=True)
+    y = layer(xt)
+    y.backward(torch.tensor(dy))
+    np.savez_compressed(os.path.join(HERE, f"gfilter_{name}.npz"), x=x, dy=dy, y=y.detach().numpy(),
+                        dx=xt.grad.numpy(), weight=layer.weight.detach().numpy(), bias=layer.bias.detach().numpy(),
+                        dweight=layer.weight.grad.numpy(), dbias=layer.bias.grad.numpy(), **coo(S))
+    print(f"gfilter_{name}: N={N} Nin={Nin} y{tuple(y.shape)}")
+
+
+def selection_gnn_case(name, S2d, dimNodeSignals, nFilterTaps, nSelectedNodes, pool, poolingSize, dimLayersMLP, B, seed=0):
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    N = S2d.shape[0]
+    net = archit.SelectionGNN(dimNodeSignals, nFilterTaps, True, torch.nn.ReLU, nSelectedNodes,
+                              getattr(gml, pool), poolingSize, dimLayersMLP, S2d)   # order=None (architectures.py:210 bug)
+    x = rng.randn(B, dimNodeSignals[0], N)
+    xt = torch.tensor(x, requires_grad=True)
+    y, ygnn = net.splitForward(xt)
+    w = rng.randn(*y.shape)
+    (y * torch.tensor(w)).sum().backward()
+    out = dict(x=x, w=w, y=y.detach().numpy(), ygnn=ygnn.detach().numpy(), dx=xt.grad.numpy(),
+               **coo(S2d[None]))
+    for k, v in net.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    cfg = dict(dimNodeSignals=dimNodeSignals, nFilterTaps=nFilterTaps, nSelectedNodes=nSelectedNodes, pool=pool,
+               poolingSize=poolingSize, dimLayersMLP=dimLayersMLP)
+    out["cfg"] = np.array(repr(cfg))
+    np.savez_compressed(os.path.join(HERE, f"selgnn_{name}.npz"), **out)
+    print(f"selgnn_{name}: N={N} y{tuple(y.shape)} ygnn{tuple(ygnn.shape)} keys={[k for k in out if k.startswith('sd:')]}")
+
+
+def main():
+    # ---- graphs --------------------------------------------------------------------------
+    # directed ring with distinct weights + one chord: maximally asymmetric (catches S vs S^T)
+    N = 6
+    ring = np.zeros((1, N, N))
+    for i in range(N):
+        ring[0, i, (i + 1) % N] = 0.3 + 0.1 * i
+    ring[0, 4, 1] = -0.7
+    rng = np.random.RandomState(1)
+    asym = (rng.rand(2, 17, 17) < 0.2) * rng.randn(2, 17, 17)            # E = 2, asymmetric, signed
+    asym37 = (rng.rand(1, 37, 37) < 0.15) * rng.randn(1, 37, 37) * 0.5   # has empty rows / columns
+    asym37[0, 5, :] = 0.0
+    asym37[0, :, 9] = 0.0
+    with open("/root/reference/datasets/facebookEgo/facebookEgo234.pkl", "rb") as f:
+        A = pickle.load(f)["adjacencyMatrix"]
+    fb = (A / np.max(np.abs(np.linalg.eigvalsh(A))))[None]               # S = A / lambda_max (sourceLocGNN.py:752)
+    np.random.seed(0)
+    G = gt.Graph("SBM", 100, {"nCommunities": 5, "probIntra": 0.8, "probInter": 0.2})   # sourceLocGNN.py:128-130
+    G.computeGFT()
+    sbm = (G.S / np.max(np.real(G.E)))                                   # sourceLocGNN.py:752
+
+    # ---- LSIGF -----------------------------------------------------------------------------
+    lsigf_case("ring_dir", ring, B=2, G=2, F=3, K=3)
+    lsigf_case("asym_E2", asym, B=3, G=3, F=5, K=4)
+    lsigf_case("asym37_K1", asym37, B=2, G=4, F=6, K=1)
+    lsigf_case("asym37_nobias", asym37, B=2, G=8, F=32, K=5, bias=False)
+    lsigf_case("asym37_G32", asym37, B=5, G=32, F=32, K=5)
+    lsigf_case("fbego_G32", fb, B=4, G=32, F=32, K=5)
+    lsigf_case("fbego_G1_F64", fb, B=5, G=1, F=64, K=5)
+    lsigf_case("fbego_G64_F32", fb, B=3, G=64, F=32, K=5)
+    lsigf_case("sbm100_G32", sbm[None], B=8, G=32, F=32, K=5)
+    # ---- GraphFilter zero-pad path -----------------------------------------------------------
+    graph_filter_case("sbm100_Nin10", sbm[None], B=6, G=32, F=32, K=5, Nin=10)
+    graph_filter_case("asym_E2_Nin11", asym, B=3, G=4, F=8, K=3, Nin=11)
+    # ---- SelectionGNN ------------------------------------------------------------------------
+    # config 1 (examples/sourceLocGNN.py:243-260): F=[1,32,32], K=[5,5], MaxPoolLocal N=[100,10,10], alpha=[6,8], MLP [5]
+    selection_gnn_case("cfg1_sbm100", sbm, [1, 32, 32], [5, 5], [10, 10], "MaxPoolLocal", [6, 8], [5], B=6)
+    # config 3 shapes (examples/movieGNN.py:259-276): F=[1,64,32], K=[5,5], NoPool, MLP [1]; graph = fbego (MovieLens needs network)
+    selection_gnn_case("cfg3_fbego", fb[0], [1, 64, 32], [5, 5], [234, 234], "NoPool", [1, 1], [1], B=5)
+
+
+if __name__ == "__main__":
+    main()
