@@ -1,0 +1,23 @@
+"""alegnn_amd -- MI355X (gfx950) implementation of the GraphFilter / LSIGF hot path of alelab-upenn/graph-neural-networks.
+
+Layout mirrors the reference package so that call sites read the same:
+    alegnn.utils.graphML.GraphFilter            ->  alegnn_amd.utils.graphML.GraphFilter
+    alegnn.utils.graphML.LSIGF                  ->  alegnn_amd.utils.graphML.LSIGF
+    alegnn.modules.architectures.SelectionGNN   ->  alegnn_amd.modules.architectures.SelectionGNN
+`install(reference_gml)` rebinds the reference's own symbols.
+"""
+from .functional import LSIGF
+from .gso import SparseGSO
+
+__all__ = ["LSIGF", "SparseGSO", "install"]
+__version__ = "0.1.0"
+
+
+def install(reference_graphML_module):
+    """Monkey-patch the reference: ``import alegnn.utils.graphML as gml; alegnn_amd.install(gml)`` makes every
+    architecture that instantiates ``gml.GraphFilter`` / calls ``gml.LSIGF`` (architectures.py:277, 665, 990, 4501, 4824;
+    graphML.py:592, 1403, 1461) run on the HIP path."""
+    from .utils import graphML as amd_gml
+    reference_graphML_module.GraphFilter = amd_gml.GraphFilter
+    reference_graphML_module.LSIGF = amd_gml.LSIGF
+    return reference_graphML_module

@@ -1,0 +1,109 @@
+"""Autograd boundary of the HIP path: ``LSIGF`` with the reference's signature (alegnn/utils/graphML.py:83).
+
+    y = LSIGF(h, S, x, b)      h [F,E,K,G], S [E,N,N] (dense tensor, or SparseGSO / scipy sparse), x [B,G,N], b [F,1]|[F,N]|None
+
+Forward and backward are two C-ABI calls (gf_lsigf_forward / gf_lsigf_backward, include/gfhip.h) on the current
+torch HIP stream.  torch is used for device memory, streams and autograd bookkeeping only -- the arithmetic is in
+libgfhip.so.  S gets no gradient (it is not a Parameter in the reference either, graphML.py:2099).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .gso import SparseGSO
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_f32_cuda(name, t):
+    if t.device.type != "cuda":
+        raise RuntimeError(f"alegnn_amd.LSIGF: `{name}` is on '{t.device}'. This implementation runs on MI355X (HIP) only "
+                           "and has no CPU fallback; move the module and data to 'cuda'.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"alegnn_amd.LSIGF: `{name}` has dtype {t.dtype}; the gfx950 kernels compute in float32 "
+                        "(cast the module / data with .float()).")
+
+
+class _LSIGFFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h, bias, gso: SparseGSO):
+        L = _lib.lib()
+        B, G, Nin = x.shape
+        F_, E, K, G2 = h.shape
+        N = gso.N
+        T = 1 + E * (K - 1)
+        x = x.contiguous()
+        h = h.contiguous()
+        bias_c = None if bias is None else bias.contiguous()
+        with torch.cuda.device(x.device):
+            plans = gso.plans(x.device)
+            Z = torch.empty((T, B, N, G), dtype=torch.float32, device=x.device)
+            y = torch.empty((B, F_, Nin), dtype=torch.float32, device=x.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(L.gf_lsigf_forward(plans, E, x.data_ptr(), h.data_ptr(), _ptr(bias_c), Z.data_ptr(), y.data_ptr(),
+                                          B, G, F_, K, Nin, stream), "gf_lsigf_forward")
+        ctx.gso = gso
+        ctx.dims = (B, G, F_, E, K, Nin, N, T)
+        ctx.has_bias = bias is not None
+        need_taps = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])  # dh / db read Z
+        ctx.save_for_backward(h, Z if need_taps else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        h, Z = ctx.saved_tensors
+        B, G, F_, E, K, Nin, N, T = ctx.dims
+        need_dx, need_dh, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dy = dy.contiguous()
+        dev = dy.device
+        with torch.cuda.device(dev):
+            plans = ctx.gso.plans(dev)
+            P = torch.empty((T if need_dx else 1, B, N, F_), dtype=torch.float32, device=dev)
+            dx = torch.empty((B, G, Nin), dtype=torch.float32, device=dev) if need_dx else None
+            dh = torch.empty_like(h) if need_dh else None
+            db = torch.empty((F_, 1), dtype=torch.float32, device=dev) if need_db else None
+            ws = None
+            ws_bytes = 0
+            if need_dh or need_db:
+                ws_bytes = L.gf_grad_taps_workspace_bytes(B, N, G, F_, E, K)
+                ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(L.gf_lsigf_backward(plans, E, dy.data_ptr(), _ptr(Z), h.data_ptr(), P.data_ptr(), _ptr(dx), _ptr(dh),
+                                           _ptr(db), _ptr(ws), ws_bytes, B, G, F_, K, Nin, stream), "gf_lsigf_backward")
+        return dx, dh, db, None
+
+
+def LSIGF(h, S, x, b=None):
+    """Linear shift-invariant graph filter, reference signature and semantics (graphML.py:83-176):
+
+        y[b,f,n] = sum_{e,k,g} h[f,e,k,g] * (x_g S_e^k)[b,n] + b[f]
+
+    ``S`` may be the reference's dense ``[E,N,N]`` tensor or anything ``SparseGSO.from_any`` accepts.
+    ``x`` may have fewer nodes than S (Nin < N): it is zero-padded and the output keeps the first Nin nodes,
+    which is what GraphFilter.forward does around its LSIGF call (graphML.py:2131-2143).
+    """
+    gso = SparseGSO.from_any(S)
+    assert h.dim() == 4 and x.dim() == 3
+    F_, E, K, G = h.shape
+    assert gso.E == E                                  # graphML.py:135
+    assert x.shape[1] == G                             # graphML.py:139
+    assert x.shape[2] <= gso.N                         # graphML.py:140 (== N); < N only via GraphFilter padding
+    _require_f32_cuda("x", x)
+    _require_f32_cuda("h", h)
+    fused_bias = None
+    late_bias = None
+    if b is not None:
+        _require_f32_cuda("b", b)
+        assert b.dim() == 2 and b.shape[0] == F_
+        if b.shape[1] == 1:
+            fused_bias = b
+        else:                                          # per-node bias [F,N] (graphML.py:110-112): broadcast add, plumbing
+            late_bias = b
+    y = _LSIGFFunction.apply(x, h, fused_bias, gso)
+    if late_bias is not None:
+        y = y + late_bias[:, : y.shape[2]]
+    return y

@@ -1,0 +1,120 @@
+"""GSO ingest: turn whatever the caller hands to ``addGSO`` into host CSR + lazily-built device plans.
+
+The reference keeps the graph shift operator as a dense ``[E, N, N]`` tensor
+(alegnn/utils/graphML.py:2116-2123, alegnn/modules/architectures.py:192-197, 253-256) -- 40 GB at N = 1e5.
+``SparseGSO`` accepts that dense tensor (reference-compatible) and, as a superset, scipy / torch sparse
+matrices; the device side is the opaque plan of ``gf_plan_create`` (include/gfhip.h).
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+
+
+def _csr_from_dense(a: np.ndarray) -> sp.csr_matrix:
+    m = sp.csr_matrix(a)
+    m.eliminate_zeros()
+    return m
+
+
+class SparseGSO:
+    """E sparse N x N shift operators S_e (host CSR, float64 or float32) + per-device plans."""
+
+    def __init__(self, mats):
+        mats = [sp.csr_matrix(m, copy=True) for m in mats]
+        assert len(mats) >= 1
+        n = mats[0].shape[0]
+        for m in mats:
+            assert m.shape == (n, n), "every edge feature needs an N x N operator"   # graphML.py:2119-2122
+            if m.dtype not in (np.float32, np.float64):
+                raise TypeError(f"GSO dtype {m.dtype} is not supported (float32 / float64)")
+            m.sum_duplicates()
+            m.sort_indices()
+        self.mats = mats
+        self.E = len(mats)
+        self.N = n
+        self.nnz = [int(m.nnz) for m in mats]
+        self._plans = {}          # device index -> (ctypes array of plan pointers, [raw pointers])
+        self._finalizer = weakref.finalize(self, SparseGSO._destroy_all, self._plans)
+
+    # ---- construction --------------------------------------------------------------------------------
+    @classmethod
+    def from_any(cls, S) -> "SparseGSO":
+        if isinstance(S, SparseGSO):
+            return S
+        if isinstance(S, torch.Tensor):
+            if S.layout != torch.strided:                       # torch sparse COO / CSR, 2-D
+                Sc = S.detach().cpu().to_sparse_coo().coalesce()
+                assert Sc.dim() == 2, "sparse torch GSO must be 2-D (one edge feature)"
+                idx = Sc.indices().numpy()
+                return cls([sp.csr_matrix((Sc.values().numpy(), (idx[0], idx[1])), shape=tuple(Sc.shape))])
+            S = S.detach().cpu().numpy()
+        if sp.issparse(S):
+            return cls([S])
+        if isinstance(S, (list, tuple)):
+            return cls([m if sp.issparse(m) else _csr_from_dense(np.asarray(m)) for m in S])
+        S = np.asarray(S)
+        assert S.ndim == 2 or S.ndim == 3                       # architectures.py:192
+        if S.ndim == 2:
+            S = S[None]
+        assert S.shape[1] == S.shape[2]                         # architectures.py:197 / graphML.py:2122
+        if S.dtype not in (np.float32, np.float64):
+            S = S.astype(np.float64)
+        return cls([_csr_from_dense(S[e]) for e in range(S.shape[0])])
+
+    # ---- reference-compatible views -----------------------------------------------------------------------
+    @property
+    def shape(self):
+        return (self.E, self.N, self.N)
+
+    def to_dense(self, dtype=torch.float32) -> torch.Tensor:
+        """Dense [E,N,N] tensor (small N only) -- what the reference stores as ``GraphFilter.S``."""
+        return torch.stack([torch.from_numpy(m.toarray()).to(dtype) for m in self.mats])
+
+    def __repr__(self):
+        return f"SparseGSO(E={self.E}, N={self.N}, nnz={self.nnz})"
+
+    # ---- device plans ------------------------------------------------------------------------------------
+    def plans(self, device: torch.device):
+        """ctypes ``gf_plan*[E]`` for ``device`` (built on first use; one host->device upload per device)."""
+        if device.type != "cuda":
+            raise RuntimeError(f"alegnn_amd runs on MI355X only (HIP device required), got device '{device}'")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        hit = self._plans.get(idx)
+        if hit is not None:
+            return hit[0]
+        L = _lib.lib()
+        raw = []
+        with torch.cuda.device(idx):
+            for m in self.mats:
+                rowptr = np.ascontiguousarray(m.indptr, dtype=np.int32)
+                col = np.ascontiguousarray(m.indices, dtype=np.int32)
+                val = np.ascontiguousarray(m.data)
+                out = ctypes.c_void_p()
+                rc = L.gf_plan_create(self.N, m.nnz, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data,
+                                      1 if val.dtype == np.float64 else 0, 0, ctypes.byref(out))
+                if rc != 0:
+                    for p in raw:
+                        L.gf_plan_destroy(p)
+                    _lib.check(rc, "gf_plan_create")
+                raw.append(out.value)
+        arr = (ctypes.c_void_p * self.E)(*raw)
+        self._plans[idx] = (arr, raw)
+        return arr
+
+    @staticmethod
+    def _destroy_all(plans):
+        try:
+            L = _lib.lib()
+        except Exception:
+            return
+        for _, raw in plans.values():
+            for p in raw:
+                L.gf_plan_destroy(p)
+        plans.clear()

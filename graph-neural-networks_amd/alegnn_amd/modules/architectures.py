@@ -1,0 +1,153 @@
+"""SelectionGNN with the reference's constructor (alegnn/modules/architectures.py:49-479), built on the HIP GraphFilter.
+
+Same signature, same sub-module names (``GFL`` = [GraphFilter, sigma, rho] x L, ``MLP``), hence the same state_dict
+keys (``GFL.0.weight`` ... ``MLP.0.bias``): checkpoints written by the reference's Model.save (model.py:106-117)
+load here and vice versa.
+
+Differences, all supersets or fixes:
+  * ``GSO`` may also be a scipy sparse matrix, a list of them (one per edge feature) or a ``SparseGSO`` -- required
+    for N >= 1e4 where the reference's dense E x N x N array stops fitting.
+  * ``order='Degree' | 'EDS' | 'SpectralProxies'`` works (the reference evaluates ``Utils.graphTools.perm...`` with an
+    undefined name ``Utils`` and raises NameError, architectures.py:210).
+  * ``coarsening=True`` (Graclus, graphTools.py:1337-1614) is not rebuilt: NotImplementedError.
+  * ``.to(device)`` moves parameters and buffers only; device plans are built lazily per device, and the identity
+    node ordering skips the ``x[:, :, order]`` gather (architectures.py:437 copies x every call).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+from ..gso import SparseGSO
+from ..utils import graphML as gml
+from ..utils import graphTools
+
+
+class SelectionGNN(nn.Module):
+    def __init__(self,
+                 # Graph filtering
+                 dimNodeSignals, nFilterTaps, bias,
+                 # Nonlinearity
+                 nonlinearity,
+                 # Pooling
+                 nSelectedNodes, poolingFunction, poolingSize,
+                 # MLP in the end
+                 dimLayersMLP,
+                 # Structure
+                 GSO,
+                 # Ordering
+                 order=None,
+                 # Coarsening
+                 coarsening=False):
+        super().__init__()
+        assert len(dimNodeSignals) == len(nFilterTaps) + 1         # architectures.py:184
+        assert len(nSelectedNodes) == len(nFilterTaps)              # :187
+        assert len(poolingSize) == len(nFilterTaps)                 # :189
+        if coarsening:
+            raise NotImplementedError("SelectionGNN(coarsening=True): Graclus coarsening (reference graphTools.py:1337-1614) "
+                                      "is host-side setup outside the rebuilt hot path; use selection pooling.")
+        self.L = len(nFilterTaps)
+        self.F = dimNodeSignals
+        self.K = nFilterTaps
+        self.bias = bias
+        self.sigma = nonlinearity
+        self.rho = poolingFunction
+        self.dimLayersMLP = dimLayersMLP
+        self.coarsening = False
+        self.alpha = poolingSize
+        self._order_name = order
+        self._install_gso(GSO)
+        self.N = [self._gso.N] + nSelectedNodes                     # :256
+
+        gfl = []
+        for l in range(self.L):
+            gfl.append(gml.GraphFilter(self.F[l], self.F[l + 1], self.K[l], self.E, self.bias))   # :277-278
+            gfl[3 * l].addGSO(self._gso)
+            gfl.append(self.sigma())                                                              # :287
+            gfl.append(self.rho(self.N[l], self.N[l + 1], self.alpha[l]))                        # :292
+            gfl[3 * l + 2].addGSO(self._gso)
+        self.GFL = nn.Sequential(*gfl)
+
+        fc = []
+        if len(self.dimLayersMLP) > 0:                              # :299-317
+            fc.append(nn.Linear(self.N[-1] * self.F[-1], dimLayersMLP[0], bias=self.bias))
+            for l in range(len(dimLayersMLP) - 1):
+                fc.append(self.sigma())
+                fc.append(nn.Linear(dimLayersMLP[l], dimLayersMLP[l + 1], bias=self.bias))
+        self.MLP = nn.Sequential(*fc)
+
+    # ---- GSO handling -----------------------------------------------------------------------------------------
+    def _install_gso(self, GSO):
+        """Normalise GSO to E x N x N, apply the node ordering, keep ``self.S`` (reference attribute) and the SparseGSO."""
+        sparse_in = sp.issparse(GSO) or isinstance(GSO, (SparseGSO, list, tuple))
+        if sparse_in:
+            if self._order_name is not None:
+                raise NotImplementedError("node reordering needs the dense GSO (it is O(N^3) host work); pass order=None "
+                                          "with a sparse GSO, or reorder the graph beforehand")
+            self._gso = SparseGSO.from_any(GSO)
+            self.E = self._gso.E
+            self.S = self._gso
+            self.order = list(range(self._gso.N))
+            self._identity_order = True
+            return
+        if isinstance(GSO, torch.Tensor):
+            GSO = GSO.detach().cpu().numpy()
+        GSO = np.asarray(GSO)
+        assert len(GSO.shape) == 2 or len(GSO.shape) == 3           # :192
+        if len(GSO.shape) == 2:
+            assert GSO.shape[0] == GSO.shape[1]
+            GSO = GSO.reshape([1, GSO.shape[0], GSO.shape[1]])
+        else:
+            assert GSO.shape[1] == GSO.shape[2]
+        self.E = GSO.shape[0]                                       # :202
+        perm = graphTools.permIdentity if self._order_name is None else getattr(graphTools, 'perm' + self._order_name)
+        S, self.order = perm(GSO)                                   # :253
+        self.S = torch.tensor(S)                                    # :254-255 (keeps numpy's dtype, as the reference does)
+        self._gso = SparseGSO.from_any(S)
+        self._identity_order = list(self.order) == list(range(len(self.order)))
+        self._order_index = None
+
+    def changeGSO(self, GSO, nSelectedNodes=[], poolingSize=[]):
+        """Swap the graph under the same filter taps -- architectures.py:322-420 (selection pooling branch)."""
+        self._install_gso(GSO)
+        if len(poolingSize) > 0:
+            assert len(poolingSize) == self.L
+            self.alpha = poolingSize
+        if len(nSelectedNodes) > 0:
+            assert len(nSelectedNodes) == self.L
+            self.N = [self._gso.N] + nSelectedNodes
+            device = next(self.parameters()).device
+            for l in range(self.L):
+                self.GFL[3 * l + 2] = self.rho(self.N[l], self.N[l + 1], self.alpha[l])
+                self.GFL[3 * l + 2].addGSO(self._gso)
+                self.GFL[3 * l + 2].to(device)
+        else:
+            for l in range(self.L):
+                self.GFL[3 * l + 2].addGSO(self._gso)
+        for l in range(self.L):
+            self.GFL[3 * l].addGSO(self._gso)
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    def splitForward(self, x):
+        if not self._identity_order:
+            if self._order_index is None or self._order_index.device != x.device:
+                self._order_index = torch.as_tensor(self.order, dtype=torch.int64, device=x.device)
+            x = x[:, :, self._order_index]                          # :437
+        assert len(x.shape) == 3                                    # :440-443
+        batchSize = x.shape[0]
+        assert x.shape[1] == self.F[0]
+        assert x.shape[2] == self.N[0]
+        y = self.GFL(x)                                             # :445
+        yFlat = y.reshape(batchSize, self.F[-1] * self.N[-1])       # :447
+        return self.MLP(yFlat), y
+
+    def forward(self, x):
+        output, _ = self.splitForward(x)
+        return output
+
+    def to(self, *args, **kwargs):
+        # The reference moves S and re-adds it to every layer (architectures.py:463-479); here the GSO lives on the host
+        # as CSR and device plans are created on first use per device, so only parameters / buffers move.
+        return super().to(*args, **kwargs)

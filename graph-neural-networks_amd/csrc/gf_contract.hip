@@ -1,0 +1,219 @@
+// gf_contract.hip -- filter-bank contraction of the tap stack.
+// Replaces reference graphML.py:170-175:
+//     y = matmul(z.permute(0,4,1,2,3).reshape(B,N,E*K*G), h.reshape(F,E*K*G).T).permute(0,2,1) + b
+// i.e. a materialising permute of z, a [B*N, E*K*G] x [E*K*G, F] GEMM, another permute and a broadcast add.
+// Here the tap stack is already row-major [T][B*N, Cin] (node-major), so the GEMM reads it in place and the
+// epilogue writes the REFERENCE layout out[B, Cout, Nout] directly (bias fused, only the kept nodes n < Nout).
+//
+// Shape: tall-skinny, HBM-bound (AI = 2*T*Cin*Cout / ((T*Cin + Cout)*4) ~ 13 flop/B at K=5, G=F=32).
+// Algorithmic bytes = 4*(T*B*Nout*Cin + B*Nout*Cout + T*Cin*Cout);  flops = 2*B*Nout*T*Cin*Cout.
+//
+// MFMA kernel (fp32-exact v_mfma_f32_32x32x2_f32; operands fp32 so the 1e-5 tolerance holds):
+//   D[o][row] += sum_c Hm[c][o] * Ztile[row][c]   -- the output tile is computed TRANSPOSED (A = Hm^T, B = Z^T) so
+//   that in the 32x32 C/D layout lane&31 indexes the node: every store instruction writes 2 x 128 contiguous
+//   bytes of out[b, o, n0:n0+32].  One wavefront owns a 32-node tile of one batch entry and all Cout outputs.
+//   * Hm (the filter bank, gathered from the reference parameter layout h[F,E,K,G]; tap 0 summed over e) lives in
+//     LDS, shared by the 4 waves of the workgroup; workgroups are persistent (grid-stride over tiles) so it is
+//     loaded once per workgroup.
+//   * the Z tile of the current tap is staged per wave through LDS: coalesced 16-byte global loads (8 lanes = one
+//     128-byte row), ds_write_b128 into rows padded to Cin+4 floats, ds_read_b128 of the lane's own row as the B
+//     operand (padding makes (Cin+4)/4 odd -> the 16-lane read groups hit 16 distinct 16-byte slots).
+//     The reduction index c is permuted within each group of 8 so one float4 feeds four consecutive MFMAs:
+//     lane half h, step s  <->  c = 8u + 4h + s.  The next tap's global loads are in flight during the MFMAs.
+#include "gf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+struct BankView {  // how to read Hm[c = t*Cin + ci][o] out of h[F,E,K,G]
+    const float* h;
+    int E, K, G, F, mode;  // mode 0: (ci, o) = (g, f);  mode 1: (ci, o) = (f, g)
+    __device__ __forceinline__ float at(int t, int ci, int o) const {
+        const int f = mode ? ci : o, g = mode ? o : ci;
+        if (t == 0) {
+            float v = 0.f;
+            for (int e = 0; e < E; ++e) v += h[((int64_t)(f * E + e) * K) * G + g];
+            return v;
+        }
+        const int e = (t - 1) / (K - 1), k = (t - 1) % (K - 1) + 1;
+        return h[((int64_t)(f * E + e) * K + k) * G + g];
+    }
+};
+
+template <int NT, int CIN8>
+__global__ __launch_bounds__(kThreads) void contract_mfma_kernel(const float* __restrict__ Z, BankView bank,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int B, int N, int Nout, int Cout, int T, int tilesPerB,
+                                                                 int64_t totalTiles) {
+    constexpr int Cin = CIN8 * 8;
+    constexpr int Cop = NT * 32;
+    constexpr int ZS = Cin + 4;  // padded LDS row stride (floats)
+    constexpr int LPR = Cin / 4;  // lanes (float4) per row
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_w = smem;                  // [T*Cin][Cop]
+    float* s_z = smem + T * Cin * Cop;  // [kWaves][32][ZS]
+
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < T * Cin * Cop; idx += kThreads) {
+        const int o = idx % Cop, c = idx / Cop;
+        s_w[idx] = (o < Cout) ? bank.at(c / Cin, c % Cin, o) : 0.f;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    float* zt = s_z + wave * 32 * ZS;
+    const int64_t tapStride = (int64_t)B * N * Cin;
+
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < totalTiles; tile += (int64_t)gridDim.x * kWaves) {
+        const int b = (int)(tile / tilesPerB);
+        const int n0 = (int)(tile - (int64_t)b * tilesPerB) * 32;
+        const float* zb = Z + ((int64_t)b * N + n0) * Cin;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                acc[nt][r] = (bias != nullptr && o < Cout) ? bias[o] : 0.f;
+            }
+
+        float4 stage[CIN8];
+        auto issue_loads = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < CIN8; ++i) {
+                const int idx = lane + 64 * i;
+                const int row = idx / LPR, c4 = idx % LPR;
+                stage[i] = (n0 + row < Nout) ? *reinterpret_cast<const float4*>(zb + t * tapStride + (int64_t)row * Cin + c4 * 4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        issue_loads(0);
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = 0; i < CIN8; ++i) {
+                const int idx = lane + 64 * i;
+                const int row = idx / LPR, c4 = idx % LPR;
+                *reinterpret_cast<float4*>(zt + row * ZS + c4 * 4) = stage[i];
+            }
+            if (t + 1 < T) issue_loads(t + 1);  // in flight while this tap is multiplied
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float* wt = s_w + (int64_t)t * Cin * Cop;
+#pragma unroll
+            for (int u = 0; u < CIN8; ++u) {
+                const float4 bv = *reinterpret_cast<const float4*>(zt + l31 * ZS + u * 8 + half * 4);
+                const float bs[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float* wr = wt + (u * 8 + half * 4 + s) * Cop + l31;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[nt * 32], bs[s], acc[nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // all lanes' reads of zt issued before the next tap overwrites it
+        }
+
+        if (n0 + l31 < Nout) {
+            float* ob = out + (int64_t)b * Cout * Nout + n0 + l31;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o < Cout) ob[(int64_t)o * Nout] = acc[nt][r];
+                }
+        }
+    }
+}
+
+// any (Cin, Cout): one thread per output element.  Used for G = 1 first layers and shapes the MFMA kernel
+// does not tile (Cin not in {8,16,32,64,128}, Cout > 128, filter bank larger than LDS).
+__global__ __launch_bounds__(kThreads) void contract_generic_kernel(const float* __restrict__ Z, BankView bank,
+                                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                                    int B, int N, int Nout, int Cin, int Cout, int T) {
+    const int64_t total = (int64_t)B * Cout * Nout;
+    const int64_t tapStride = (int64_t)B * N * Cin;
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+        const int n = (int)(idx % Nout);
+        const int o = (int)((idx / Nout) % Cout);
+        const int64_t b = idx / ((int64_t)Nout * Cout);
+        const float* zr = Z + (b * N + n) * Cin;
+        float acc = bias ? bias[o] : 0.f;
+        for (int t = 0; t < T; ++t)
+            for (int ci = 0; ci < Cin; ++ci) acc = fmaf(zr[t * tapStride + ci], bank.at(t, ci, o), acc);
+        out[idx] = acc;
+    }
+}
+
+template <int NT, int CIN8>
+int launch_mfma(const float* Z, const BankView& bank, const float* bias, float* out, int B, int N, int Nout, int Cout, int T,
+                hipStream_t st) {
+    constexpr int Cin = CIN8 * 8;
+    const size_t lds = ((size_t)T * Cin * NT * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
+    const int tilesPerB = (Nout + 31) / 32;
+    const int64_t totalTiles = (int64_t)B * tilesPerB;
+    const int wgPerCU = lds <= 40 * 1024 ? 4 : (lds <= 80 * 1024 ? 2 : 1);
+    int64_t nblk = (totalTiles + kWaves - 1) / kWaves;
+    if (nblk > 256 * wgPerCU) nblk = 256 * wgPerCU;  // persistent: the bank is staged once per workgroup
+    auto kern = contract_mfma_kernel<NT, CIN8>;
+    if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, st, Z, bank, bias, out, B, N, Nout, Cout, T,
+                       tilesPerB, totalTiles);
+    GF_LAUNCH_CHECK("contract_mfma_kernel");
+    return GF_OK;
+}
+
+template <int NT>
+int dispatch_cin(int cin8, const float* Z, const BankView& bank, const float* bias, float* out, int B, int N, int Nout,
+                 int Cout, int T, hipStream_t st) {
+    switch (cin8) {
+        case 1: return launch_mfma<NT, 1>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
+        case 2: return launch_mfma<NT, 2>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
+        case 4: return launch_mfma<NT, 4>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
+        case 8: return launch_mfma<NT, 8>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
+        default: return launch_mfma<NT, 16>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
+    }
+}
+
+}  // namespace
+
+int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G, int F,
+                       int E, int K, int transpose_bank, hipStream_t st) {
+    const int T = gf_num_taps(E, K);
+    const int Cin = transpose_bank ? F : G, Cout = transpose_bank ? G : F;
+    BankView bank{h, E, K, G, F, transpose_bank ? 1 : 0};
+    static const int env_generic = getenv("GFHIP_CONTRACT_GENERIC") ? atoi(getenv("GFHIP_CONTRACT_GENERIC")) : 0;
+
+    const int cin8 = Cin / 8;
+    const bool cin_ok = (Cin % 8 == 0) && (cin8 == 1 || cin8 == 2 || cin8 == 4 || cin8 == 8 || cin8 == 16);
+    const int nt = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4);
+    const size_t lds = ((size_t)T * Cin * nt * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
+    if (!env_generic && cin_ok && Cout <= 128 && lds <= 160 * 1024) {
+        switch (nt) {
+            case 1: return dispatch_cin<1>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st);
+            case 2: return dispatch_cin<2>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st);
+            default: return dispatch_cin<4>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st);
+        }
+    }
+    const int64_t total = (int64_t)B * Cout * Nout;
+    const int64_t want = (total + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(contract_generic_kernel, dim3((unsigned)(want < 65536 * 8 ? want : 65536 * 8)), dim3(kThreads), 0, st,
+                       Z, bank, bias, out, B, N, Nout, Cin, Cout, T);
+    GF_LAUNCH_CHECK("contract_generic_kernel");
+    return GF_OK;
+}
+
+extern "C" int gf_contract(const float* Z, const float* h, const float* bias, float* out, int32_t B, int32_t N, int32_t Nout,
+                           int32_t G, int32_t F, int32_t E, int32_t K, int32_t transpose_bank, void* stream) {
+    GF_REQUIRE_ARG(Z && h && out, "gf_contract: NULL tensor");
+    GF_REQUIRE_SHAPE(B > 0 && N > 0 && Nout > 0 && Nout <= N && G > 0 && F > 0 && E > 0 && K > 0,
+                     "gf_contract: bad shape B=%d N=%d Nout=%d G=%d F=%d E=%d K=%d", B, N, Nout, G, F, E, K);
+    GF_REQUIRE_ARG(!(transpose_bank && bias), "gf_contract: bias is only defined for the forward bank");
+    return gf_contract_launch(Z, h, bias, out, B, N, Nout, G, F, E, K, transpose_bank, gf_stream(stream));
+}

@@ -1,0 +1,219 @@
+// gf_gradw.hip -- gradient of the filter taps and the bias (autograd of reference graphML.py:170-175 wrt h, b):
+//     dh[f,e,k,g] = sum_{b,n} Z[t(e,k), b, n, g] * dY[b, n, f]         dbias[f] = sum_{b,n} dY[b, n, f]
+// A tall-skinny reduction GEMM  dHm[T*G, F] = Z^T[T*G, R] * P0[R, F]  over R = B*N rows.  HBM-bound: reads Z and P0
+// once (4*R*(T*G + F) bytes), 2*R*T*G*F flops.
+//
+// Stage 1 (MFMA, v_mfma_f32_32x32x2_f32): each wavefront owns a contiguous strip of rows and keeps up to 8
+//   32x32 output tiles (c-tile x f-tile) in accumulators; both operands are read straight from HBM, fully
+//   coalesced, with no LDS: A[i = g][k = row] is 32 consecutive floats of one Z row per half-wave, B[k = row][j = f]
+//   32 consecutive floats of one P0 row.  Each wave writes its partial tiles to the workspace.
+// Stage 2/3: fixed-order tree over the per-wave partials (no atomics -> bitwise deterministic), then scatter into the
+//   reference parameter layout dh[F,E,K,G] (tap 0 is shared by all e, so its gradient is written for every e).
+#include "gf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kMaxWaves = 2048;  // stage-1 partial producers
+constexpr int kSlices = 32;      // stage-2 fan-in
+
+struct Geo {
+    int T, numGI, numCT, numFT, ctp, cpasses, passes, rowsPerWave, numWaves, strips;
+    int64_t R;
+    size_t off_partial_b, off_mid, off_mid_b, bytes;  // float offsets into the workspace (off_* in floats)
+    int64_t tileOutputs, biasOutputs;
+};
+
+Geo make_geo(int B, int N, int G, int F, int E, int K) {
+    Geo g{};
+    g.T = gf_num_taps(E, K);
+    g.R = (int64_t)B * N;
+    g.numGI = (G + 31) / 32;
+    g.numCT = g.T * g.numGI;
+    g.numFT = (F + 31) / 32;
+    g.cpasses = (g.numCT + 7) / 8;
+    g.ctp = (g.numCT + g.cpasses - 1) / g.cpasses;
+    g.passes = g.cpasses * g.numFT;
+    int64_t rpw = (g.R + kMaxWaves - 1) / kMaxWaves;
+    if (rpw < 64) rpw = 64;
+    rpw = (rpw + 7) & ~(int64_t)7;  // whole 8-row steps
+    g.rowsPerWave = (int)rpw;
+    g.numWaves = (int)((g.R + rpw - 1) / rpw);
+    g.strips = (g.numWaves + kWaves - 1) / kWaves;
+    const int wavesPadded = g.strips * kWaves;
+    g.tileOutputs = (int64_t)g.passes * g.ctp * 1024;
+    g.biasOutputs = (int64_t)g.numFT * 32;
+    size_t off = (size_t)wavesPadded * g.tileOutputs;  // partial tiles
+    g.off_partial_b = off;
+    off += (size_t)wavesPadded * g.biasOutputs;
+    g.off_mid = off;
+    off += (size_t)kSlices * g.tileOutputs;
+    g.off_mid_b = off;
+    off += (size_t)kSlices * g.biasOutputs;
+    g.bytes = off * sizeof(float);
+    return g;
+}
+
+template <int CTP>
+__global__ __launch_bounds__(kThreads) void grad_taps_kernel(const float* __restrict__ Z, const float* __restrict__ P0,
+                                                             float* __restrict__ partial, float* __restrict__ partial_b,
+                                                             int64_t R, int G, int F, int numGI, int numCT, int numFT,
+                                                             int passes, int rowsPerWave) {
+    const int pass = blockIdx.y;
+    const int ft = pass % numFT, cpass = pass / numFT;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wg = blockIdx.x * kWaves + wave;
+    const int64_t r_begin = (int64_t)wg * rowsPerWave;
+    const int64_t r_end = min(R, r_begin + rowsPerWave);
+    const int64_t tapStride = R * G;
+
+    const int f = ft * 32 + l31;
+    const bool fvalid = f < F;
+    const float* zp[CTP];
+    bool gvalid[CTP];
+#pragma unroll
+    for (int j = 0; j < CTP; ++j) {
+        const int ct = cpass * CTP + j;
+        const int t = ct / numGI, gi = ct - t * numGI;
+        const int g = gi * 32 + l31;
+        gvalid[j] = (ct < numCT) && (g < G);
+        zp[j] = Z + (gvalid[j] ? (int64_t)t * tapStride + g : 0);
+    }
+    f32x16 acc[CTP];
+#pragma unroll
+    for (int j = 0; j < CTP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum = 0.f;
+
+    // lane half h takes rows r0 + h, +2, +4, +6 of each 8-row step (k index of the 32x32x2 MFMA = row parity);
+    // the 4 x (1 + CTP) loads of a step are issued before its 4 x CTP MFMAs.
+    for (int64_t r0 = r_begin; r0 < r_begin + rowsPerWave; r0 += 8) {
+        float p[4], a[4][CTP];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t r = r0 + 2 * s + half;
+            const bool rv = r < r_end;
+            p[s] = (rv && fvalid) ? P0[r * F + f] : 0.f;
+#pragma unroll
+            for (int j = 0; j < CTP; ++j) a[s][j] = (rv && gvalid[j]) ? zp[j][r * G] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bsum += p[s];
+#pragma unroll
+            for (int j = 0; j < CTP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][j], p[s], acc[j], 0, 0, 0);
+        }
+    }
+
+    float* pt = partial + ((int64_t)wg * passes + pass) * CTP * 1024;
+#pragma unroll
+    for (int j = 0; j < CTP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            pt[j * 1024 + i * 32 + l31] = acc[j][r];
+        }
+    if (cpass == 0) {
+        const float other = __shfl_xor(bsum, 32, 64);
+        if (half == 0) partial_b[((int64_t)wg * numFT + ft) * 32 + l31] = bsum + other;  // even rows + odd rows
+    }
+}
+
+// out[s][o] = sum over rows w in slice s (ascending) of in[w][o];  slices partition [0, rows) evenly.
+__global__ __launch_bounds__(kThreads) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int rows, int64_t width, int slices) {
+    const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int s = blockIdx.y;
+    if (o >= width) return;
+    const int per = (rows + slices - 1) / slices;
+    const int w0 = s * per, w1 = min(rows, w0 + per);
+    float acc = 0.f;
+    for (int w = w0; w < w1; ++w) acc += in[(int64_t)w * width + o];
+    out[(int64_t)s * width + o] = acc;
+}
+
+__global__ __launch_bounds__(kThreads) void finalize_taps_kernel(const float* __restrict__ mid, const float* __restrict__ mid_b,
+                                                                 float* __restrict__ dh, float* __restrict__ dbias,
+                                                                 int64_t tileOutputs, int biasOutputs, int slices, int G, int F,
+                                                                 int E, int K, int numGI, int numCT, int numFT, int ctp) {
+    const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (o < tileOutputs) {
+        float acc = 0.f;
+        for (int s = 0; s < slices; ++s) acc += mid[(int64_t)s * tileOutputs + o];
+        const int jj = (int)(o & 31), i = (int)((o >> 5) & 31);
+        const int64_t tileIdx = o >> 10;  // pass * ctp + j
+        const int j = (int)(tileIdx % ctp), pass = (int)(tileIdx / ctp);
+        const int ft = pass % numFT, cpass = pass / numFT;
+        const int ct = cpass * ctp + j;
+        const int t = ct / numGI, gi = ct - t * numGI;
+        const int g = gi * 32 + i, f = ft * 32 + jj;
+        if (dh != nullptr && ct < numCT && g < G && f < F) {
+            if (t == 0) {
+                for (int e = 0; e < E; ++e) dh[((int64_t)(f * E + e) * K) * G + g] = acc;
+            } else {
+                const int e = (t - 1) / (K - 1), k = (t - 1) % (K - 1) + 1;
+                dh[((int64_t)(f * E + e) * K + k) * G + g] = acc;
+            }
+        }
+    } else if (o < tileOutputs + biasOutputs && dbias != nullptr) {
+        const int fb = (int)(o - tileOutputs);
+        float acc = 0.f;
+        for (int s = 0; s < slices; ++s) acc += mid_b[(int64_t)s * biasOutputs + fb];
+        if (fb < F) dbias[fb] = acc;
+    }
+}
+
+template <int CTP>
+void launch_stage1(const Geo& g, const float* Z, const float* P0, float* ws, int G, int F, hipStream_t st) {
+    hipLaunchKernelGGL((grad_taps_kernel<CTP>), dim3(g.strips, g.passes), dim3(kThreads), 0, st, Z, P0, ws,
+                       ws + g.off_partial_b, g.R, G, F, g.numGI, g.numCT, g.numFT, g.passes, g.rowsPerWave);
+}
+
+}  // namespace
+
+extern "C" size_t gf_grad_taps_workspace_bytes(int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K) {
+    if (B <= 0 || N <= 0 || G <= 0 || F <= 0 || E <= 0 || K <= 0) return 0;
+    return make_geo(B, N, G, F, E, K).bytes;
+}
+
+extern "C" int gf_grad_taps(const float* Z, const float* P0, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
+                            int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K, void* stream) {
+    GF_REQUIRE_ARG(Z && P0 && workspace, "gf_grad_taps: NULL tensor");
+    GF_REQUIRE_ARG(dh || dbias, "gf_grad_taps: nothing to compute (dh and dbias both NULL)");
+    GF_REQUIRE_SHAPE(B > 0 && N > 0 && G > 0 && F > 0 && E > 0 && K > 0, "gf_grad_taps: bad shape B=%d N=%d G=%d F=%d E=%d K=%d",
+                     B, N, G, F, E, K);
+    const Geo g = make_geo(B, N, G, F, E, K);
+    GF_REQUIRE_ARG(workspace_bytes >= g.bytes, "gf_grad_taps: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
+    GF_REQUIRE_SHAPE(g.passes <= 65535, "gf_grad_taps: %d passes exceed the grid limit", g.passes);
+    hipStream_t st = gf_stream(stream);
+    float* ws = (float*)workspace;
+    switch (g.ctp) {
+        case 1: launch_stage1<1>(g, Z, P0, ws, G, F, st); break;
+        case 2: launch_stage1<2>(g, Z, P0, ws, G, F, st); break;
+        case 3: launch_stage1<3>(g, Z, P0, ws, G, F, st); break;
+        case 4: launch_stage1<4>(g, Z, P0, ws, G, F, st); break;
+        case 5: launch_stage1<5>(g, Z, P0, ws, G, F, st); break;
+        case 6: launch_stage1<6>(g, Z, P0, ws, G, F, st); break;
+        case 7: launch_stage1<7>(g, Z, P0, ws, G, F, st); break;
+        default: launch_stage1<8>(g, Z, P0, ws, G, F, st); break;
+    }
+    GF_LAUNCH_CHECK("grad_taps_kernel");
+    const int wavesPadded = g.strips * kWaves;
+    const int slices = wavesPadded < kSlices ? wavesPadded : kSlices;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((g.tileOutputs + kThreads - 1) / kThreads), slices), dim3(kThreads), 0,
+                       st, ws, ws + g.off_mid, wavesPadded, g.tileOutputs, slices);
+    GF_LAUNCH_CHECK("reduce_rows_kernel(taps)");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((g.biasOutputs + kThreads - 1) / kThreads), slices), dim3(kThreads), 0,
+                       st, ws + g.off_partial_b, ws + g.off_mid_b, wavesPadded, g.biasOutputs, slices);
+    GF_LAUNCH_CHECK("reduce_rows_kernel(bias)");
+    const int64_t tot = g.tileOutputs + g.biasOutputs;
+    hipLaunchKernelGGL(finalize_taps_kernel, dim3((unsigned)((tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                       ws + g.off_mid, ws + g.off_mid_b, dh, dbias, g.tileOutputs, (int)g.biasOutputs, slices, G, F, E, K,
+                       g.numGI, g.numCT, g.numFT, g.ctp);
+    GF_LAUNCH_CHECK("finalize_taps_kernel");
+    return GF_OK;
+}

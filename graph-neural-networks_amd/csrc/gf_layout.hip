@@ -1,0 +1,70 @@
+// gf_layout.hip -- boundary layout kernels between the reference layout x[B,G,N] (node index contiguous,
+// reference graphML.py:108-109) and the node-major layout X[B,N,G] the gather kernels want (one contiguous
+// feature row per (b, n): a full 128-byte line at G = 32).
+//
+// bgn_to_bng also implements GraphFilter.forward's zero-padding to N nodes (reference graphML.py:2131-2135):
+// rows n >= Nin of X are written as zeros.  bng_to_bgn keeps nodes n < Nout (graphML.py:2142-2143).
+//
+// HBM-bound: algorithmic bytes = 4*B*G*(Nin + N).  32x32 tiles through LDS, both sides coalesced.
+#include "gf_common.h"
+
+namespace {
+
+constexpr int TILE = 32;
+constexpr int TROWS = 8;  // 32 x 8 threads
+
+// in:  [B, R, C] (C contiguous, only columns c < Cin exist, leading dim Cin)
+// out: [B, Cout_rows, R] viewed as out[b][c][r] for c < Cout (leading dim R); c >= Cin reads as zero.
+// With (R, C) = (G, N) this is x[B,G,Nin] -> X[B,N,G];  with (R, C) = (N, G) and swapped roles it is the inverse.
+__global__ __launch_bounds__(TILE* TROWS) void transpose_pad_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                      int R, int Cin, int Cout, int64_t in_bstride,
+                                                                      int64_t out_bstride) {
+    __shared__ float tile[TILE][TILE + 1];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.x * TILE;
+    const int r0 = blockIdx.y * TILE;
+    const float* ib = in + (int64_t)b * in_bstride;
+    float* ob = out + (int64_t)b * out_bstride;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int i = 0; i < TILE; i += TROWS) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < Cin) v = ib[(int64_t)r * Cin + c];
+        tile[ty + i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TILE; i += TROWS) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (c < Cout && r < R) ob[(int64_t)c * R + r] = tile[tx][ty + i];
+    }
+}
+
+}  // namespace
+
+extern "C" int gf_layout_bgn_to_bng(const float* x, float* X, int32_t B, int32_t G, int32_t Nin, int32_t N, void* stream) {
+    GF_REQUIRE_ARG(x && X, "gf_layout_bgn_to_bng: NULL tensor");
+    GF_REQUIRE_SHAPE(B > 0 && G > 0 && Nin > 0 && N >= Nin, "gf_layout_bgn_to_bng: bad shape B=%d G=%d Nin=%d N=%d", B, G,
+                     Nin, N);
+    GF_REQUIRE_SHAPE(B <= 65535, "gf_layout_bgn_to_bng: batch %d > 65535", B);
+    dim3 grid((N + TILE - 1) / TILE, (G + TILE - 1) / TILE, B), block(TILE, TROWS);
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, gf_stream(stream), x, X, G, Nin, N, (int64_t)G * Nin,
+                       (int64_t)N * G);
+    GF_LAUNCH_CHECK("transpose_pad_kernel(bgn->bng)");
+    return GF_OK;
+}
+
+extern "C" int gf_layout_bng_to_bgn(const float* X, float* x, int32_t B, int32_t G, int32_t N, int32_t Nout, void* stream) {
+    GF_REQUIRE_ARG(x && X, "gf_layout_bng_to_bgn: NULL tensor");
+    GF_REQUIRE_SHAPE(B > 0 && G > 0 && Nout > 0 && N >= Nout, "gf_layout_bng_to_bgn: bad shape B=%d G=%d N=%d Nout=%d", B,
+                     G, N, Nout);
+    GF_REQUIRE_SHAPE(B <= 65535, "gf_layout_bng_to_bgn: batch %d > 65535", B);
+    // in = X viewed [B, R = N(only first Nout rows used), C = G]; out[b][g][n] has leading dim Nout, so run the
+    // kernel with R = Nout rows of the input (input batch stride still N*G).
+    dim3 grid((G + TILE - 1) / TILE, (Nout + TILE - 1) / TILE, B), block(TILE, TROWS);
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, gf_stream(stream), X, x, Nout, G, G, (int64_t)N * G,
+                       (int64_t)G * Nout);
+    GF_LAUNCH_CHECK("transpose_pad_kernel(bng->bgn)");
+    return GF_OK;
+}

@@ -1,0 +1,117 @@
+/* gfhip.h -- C ABI of libgfhip.so: the MI355X (gfx950) implementation of the LSIGF / GraphFilter hot path
+ * of alelab-upenn/graph-neural-networks ("alegnn").
+ *
+ * The reference has no FFI / plugin registry: callers bind the Python symbols
+ *     alegnn/utils/graphML.py:83     LSIGF(h, S, x, b)
+ *     alegnn/utils/graphML.py:2036   class GraphFilter  (addGSO :2116, forward :2125)
+ *     alegnn/utils/graphML.py:389    EVGF / :2511 class EdgeVariantGF
+ * by name.  This header is what a Python (ctypes) / C / C++ host binds instead; each entry point says which
+ * reference lines it replaces.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - plain C types only; every tensor argument is a DEVICE pointer to fp32 data unless it says HOST.
+ *   - the library never allocates or frees tensor storage; the caller passes outputs and workspaces.
+ *     The only library-owned object is the opaque plan (device CSR of S and S^T + row schedule).
+ *   - every launch goes to the hipStream_t passed as `stream` (void*; NULL = default stream);
+ *     no internal synchronisation, no host callbacks.
+ *   - return value: 0 = GF_OK, negative = error (see enum); gf_last_error() gives a thread-local message.
+ *     Shape violations that the reference reports with `assert` (graphML.py:135-140, 2118-2122) come back
+ *     as GF_ERR_SHAPE so the Python layer can re-raise AssertionError.
+ *   - results are bitwise run-to-run deterministic (no floating-point atomics).
+ *
+ * Layouts
+ *   reference layout   x [B, G, N]  (node index contiguous)          graphML.py:108-109
+ *   node-major layout  X [B, N, G]  (feature index contiguous)       internal; one 128-byte line per (b, n) at G = 32
+ *   tap stack          Z [T, B, N, G], T = 1 + E*(K-1):  tap 0 = X_0 (shared by all e, graphML.py:154),
+ *                      tap 1 + e*(K-1) + (k-1) = x S_e^k  for k = 1..K-1      (replaces the cat at graphML.py:161)
+ *   filter taps        h [F, E, K, G]   reference parameter layout    graphML.py:2101  (read in place, never repacked)
+ */
+#ifndef GFHIP_H
+#define GFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFHIP_VERSION 100 /* major*10000 + minor*100 + patch */
+
+enum {
+    GF_OK = 0,
+    GF_ERR_SHAPE = -1,       /* the reference would have raised AssertionError            */
+    GF_ERR_ARG = -2,         /* null pointer / bad enum / unsupported value               */
+    GF_ERR_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString) */
+    GF_ERR_UNSUPPORTED = -4, /* valid request this build cannot serve                      */
+    GF_ERR_NOMEM = -5
+};
+
+/* which operator a hop applies on the node axis */
+enum {
+    GF_OP_FWD = 0, /* X_out = S^T X_in  == reference row-vector product x @ S (graphML.py:159)          */
+    GF_OP_BWD = 1  /* X_out = S   X_in  == its adjoint, used by the backward pass (autograd of :159)    */
+};
+
+typedef struct gf_plan gf_plan; /* opaque */
+
+int gf_version(void);
+const char* gf_last_error(void);
+
+/* ---- GSO ingest: replaces holding the dense [E,N,N] tensor of GraphFilter.addGSO (graphML.py:2116-2123) ------
+ * Builds the device plan for ONE edge feature S_e from HOST CSR arrays of S_e (row i lists S_e[i, :]).
+ * Duplicate (i,j) entries are summed in order; explicit zeros are kept.  vals may be fp32 or fp64 (vals_is_f64).
+ * flags: bit 0 = disable the degree-sorted row schedule (debug). */
+int gf_plan_create(int32_t n_nodes, int64_t nnz, const int32_t* rowptr_host, const int32_t* colidx_host,
+                   const void* vals_host, int32_t vals_is_f64, uint32_t flags, gf_plan** out_plan);
+int gf_plan_destroy(gf_plan* plan);
+/* n_nodes, nnz, and the device bytes held by the plan */
+int gf_plan_info(const gf_plan* plan, int32_t* n_nodes, int64_t* nnz, int64_t* device_bytes);
+
+/* ---- boundary layout kernels (replace nothing in the reference: they are the price of node-major gathers) ---- */
+/* x [B,G,Nin] -> X [B,N,G]; rows n >= Nin are zero-filled == GraphFilter.forward zero-padding (graphML.py:2131-2135) */
+int gf_layout_bgn_to_bng(const float* x, float* X, int32_t B, int32_t G, int32_t Nin, int32_t N, void* stream);
+/* X [B,N,G] -> x [B,G,Nout], keeping nodes n < Nout == the index_select at graphML.py:2142-2143 */
+int gf_layout_bng_to_bgn(const float* X, float* x, int32_t B, int32_t G, int32_t N, int32_t Nout, void* stream);
+
+/* ---- one hop: X_out[b] = op(S) X_in[b] for b < B, rows of width W floats (replaces torch.matmul, graphML.py:159) */
+int gf_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* X_out, int32_t B, int32_t W, void* stream);
+
+/* ---- K-hop tap stack for E plans: fills taps 1..T-1 of Z from tap 0 (replaces the loop graphML.py:158-161) ---- */
+int gf_khop(const gf_plan* const* plans, int32_t E, int32_t op, float* Z, int32_t B, int32_t W, int32_t K,
+            void* stream);
+
+/* ---- filter-bank contraction (replaces permute+matmul+permute+bias, graphML.py:170-175)
+ * transpose_bank = 0 (forward):   out[b, f, n] = bias[f] + sum_{t,g} Z[t,b,n,g] * h[f, e(t), k(t), g]      Cin = G, Cout = F
+ * transpose_bank = 1 (backward):  out[b, g, n] =           sum_{t,f} Z[t,b,n,f] * h[f, e(t), k(t), g]      Cin = F, Cout = G
+ * Z [T,B,N,Cin] node-major tap stack; out [B,Cout,Nout] in the REFERENCE layout, nodes n < Nout only; bias nullable [F]. */
+int gf_contract(const float* Z, const float* h, const float* bias, float* out, int32_t B, int32_t N, int32_t Nout,
+                int32_t G, int32_t F, int32_t E, int32_t K, int32_t transpose_bank, void* stream);
+
+/* ---- filter-tap gradient (autograd of graphML.py:170-175 wrt h and b):
+ * dh[f,e,k,g] = sum_{b,n} Z[t(e,k),b,n,g] * P0[b,n,f]   (for k = 0 the same value is written for every e)
+ * dbias[f]    = sum_{b,n} P0[b,n,f]                      (dbias nullable)
+ * P0 [B,N,F] is dy in node-major layout.  workspace: gf_grad_taps_workspace_bytes() bytes of device scratch. */
+size_t gf_grad_taps_workspace_bytes(int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K);
+int gf_grad_taps(const float* Z, const float* P0, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
+                 int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K, void* stream);
+
+/* ---- whole-layer entry points: what GraphFilter.forward / its autograd call (graphML.py:2125-2144) -------------
+ * forward:  x [B,G,Nin], h [F,E,K,G], bias [F]|NULL  ->  y [B,F,Nin];  Z [T,B,N,G] is written (save it for backward).
+ * backward: dy [B,F,Nin], Z (saved), h -> dx [B,G,Nin] (NULL = skip), dh [F,E,K,G] (NULL = skip), dbias [F] (NULL = skip);
+ *           P [T,B,N,F] scratch, workspace as for gf_grad_taps.  */
+int gf_lsigf_forward(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias,
+                     float* Z, float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
+int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const float* dy, const float* Z, const float* h,
+                      float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
+                      int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
+
+/* ---- measurement hook: run ONE hop `iters` times on `stream` bracketed by HIP events on that stream and return
+ * the average milliseconds per launch (bench.py's roofline leg; hipEvents see the launch stream, torch events may not). */
+int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* X_out, int32_t B, int32_t W,
+                     int32_t iters, void* stream, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFHIP_H */

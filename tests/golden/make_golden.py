@@ -122,6 +122,22 @@ def main():
     G.computeGFT()
     sbm = (G.S / np.max(np.real(G.E)))                                   # sourceLocGNN.py:752
 
+    # ---- graphTools pieces SelectionGNN depends on (orderings, MaxPoolLocal neighbourhoods) -------------------
+    gt_out = dict(S=sbm)
+    for (K, N, nb) in [(6, 10, 100), (8, 10, 10), (1, 100, 100), (0, 5, 100), (2, 37, 20)]:
+        src = sbm[None] if N <= 100 and nb != 20 else asym37
+        nbh = gt.computeNeighborhood(src, K, N, nb, 'matrix')
+        gt_out[f"nbh_{K}_{N}_{nb}"] = np.sort(nbh, axis=1)      # neighbourhoods are sets: compare sorted
+    gt_out["asym37"] = asym37
+    for name in ("Degree", "EDS", "SpectralProxies"):
+        Sp, order = getattr(gt, "perm" + name)(sbm)
+        gt_out["order_" + name] = np.array(order)
+        gt_out["S_" + name] = Sp
+    Sp, order = gt.permDegree(asym)
+    gt_out["order_Degree_E2"], gt_out["S_Degree_E2"], gt_out["asym_E2"] = np.array(order), Sp, asym
+    np.savez_compressed(os.path.join(HERE, "graphtools_sbm100.npz"), **gt_out)
+    print("graphtools_sbm100:", sorted(gt_out))
+
     # ---- LSIGF -----------------------------------------------------------------------------
     lsigf_case("ring_dir", ring, B=2, G=2, F=3, K=3)
     lsigf_case("asym_E2", asym, B=3, G=3, F=5, K=4)

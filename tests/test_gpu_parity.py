@@ -1,0 +1,343 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+  (1) the golden vectors produced by the real reference (tests/golden/*.npz, float64 ground truth),
+  (2) the CPU oracle on seeded random inputs at sizes it finishes in seconds,
+  (3) size-independent properties at the benchmark's full size (linearity, batch independence, determinism).
+
+Stated tolerances:  forward  max|y - y_ref64| <= 1e-5 * max|y_ref64|
+                                           gradients            <= 1e-4 * max|g_ref64|
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from _util import FWD_RTOL, GOLDEN, GRAD_RTOL, case_id, golden_files, load, relerr
+from oracle import lsigf_oracle as orc
+
+from alegnn_amd import LSIGF, SparseGSO, _lib, graphgen
+from alegnn_amd.modules.architectures import SelectionGNN
+from alegnn_amd.utils import graphML as gml
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def cu(a, grad=False):
+    t = torch.tensor(np.asarray(a), dtype=torch.float32, device=DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# unit level: every exported kernel entry point against numpy
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,G,Nin,N", [(3, 32, 100, 100), (2, 1, 37, 37), (5, 7, 10, 45), (1, 64, 33, 70), (4, 3, 1, 1)])
+def test_layout_kernels(B, G, Nin, N):
+    L = _lib.lib()
+    rng = np.random.RandomState(0)
+    x = rng.randn(B, G, Nin).astype(np.float32)
+    xt = cu(x)
+    X = torch.full((B, N, G), float("nan"), device=DEV)
+    _lib.check(L.gf_layout_bgn_to_bng(xt.data_ptr(), X.data_ptr(), B, G, Nin, N, stream()))
+    want = np.zeros((B, N, G), np.float32)
+    want[:, :Nin] = x.transpose(0, 2, 1)
+    assert np.array_equal(X.cpu().numpy(), want)                      # pure data movement: bit-exact
+    back = torch.full((B, G, Nin), float("nan"), device=DEV)
+    _lib.check(L.gf_layout_bng_to_bgn(X.data_ptr(), back.data_ptr(), B, G, N, Nin, stream()))
+    assert np.array_equal(back.cpu().numpy(), x)
+
+
+def _rand_graph(n, density, seed, empty_rows=True):
+    rng = np.random.RandomState(seed)
+    A = sp.random(n, n, density=density, random_state=rng, data_rvs=rng.randn, format="lil")
+    if empty_rows and n > 4:
+        A[3, :] = 0
+        A[:, 2] = 0
+    return sp.csr_matrix(A)
+
+
+@pytest.mark.parametrize("W", [1, 3, 4, 8, 16, 32, 64, 128, 256, 20])
+@pytest.mark.parametrize("B", [1, 5, 17, 40])
+def test_spmm_hop_against_scipy(W, B):
+    """One hop, both orientations, every kernel variant (vector widths, generic width, BT = 1/2/4 heuristics)."""
+    L = _lib.lib()
+    n = 203
+    A = _rand_graph(n, 0.05, seed=W + B)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    rng = np.random.RandomState(1)
+    X = rng.randn(B, n, W).astype(np.float32)
+    Xt = cu(X)
+    for op, M in ((0, A.T.tocsr()), (1, A)):
+        out = torch.full((B, n, W), float("nan"), device=DEV)
+        _lib.check(L.gf_spmm_hop(plans[0], op, Xt.data_ptr(), out.data_ptr(), B, W, stream()))
+        want = np.stack([M.astype(np.float64) @ X[b].astype(np.float64) for b in range(B)])
+        assert relerr(out.cpu().numpy(), want) < 2e-6, (op, W, B)
+
+
+def test_spmm_hop_skewed_degrees_and_long_rows():
+    """Rows far longer than the 2048-entry LDS chunk, a power-law tail, and empty rows."""
+    L = _lib.lib()
+    n = 6000
+    rng = np.random.RandomState(7)
+    rows = [np.full(5000, 0), np.full(2500, 17)]                      # two hub rows
+    cols = [rng.choice(n, 5000, replace=False), rng.choice(n, 2500, replace=False)]
+    deg = np.minimum((rng.pareto(1.5, n) * 3).astype(int), 300)
+    for i in range(100, n):
+        if deg[i]:
+            rows.append(np.full(deg[i], i))
+            cols.append(rng.choice(n, deg[i], replace=False))
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    A = sp.csr_matrix((rng.randn(r.size), (r, c)), shape=(n, n))
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    B, W = 3, 32
+    X = rng.randn(B, n, W).astype(np.float32)
+    Xt = cu(X)
+    for op, M in ((0, A.T.tocsr()), (1, A)):
+        out = torch.empty((B, n, W), device=DEV)
+        _lib.check(L.gf_spmm_hop(plans[0], op, Xt.data_ptr(), out.data_ptr(), B, W, stream()))
+        want = np.stack([M @ X[b].astype(np.float64) for b in range(B)])
+        assert relerr(out.cpu().numpy(), want) < 5e-6
+
+
+def _bank(h, transpose):
+    """Hm[t, ci, o] as the contraction sees it (tap 0 summed over e)."""
+    F, E, K, G = h.shape
+    T = 1 + E * (K - 1)
+    Hm = np.zeros((T, G, F))
+    Hm[0] = h[:, :, 0, :].sum(axis=1).T
+    for e in range(E):
+        for k in range(1, K):
+            Hm[1 + e * (K - 1) + k - 1] = h[:, e, k, :].T
+    return Hm.transpose(0, 2, 1) if transpose else Hm          # [T, Cin, Cout]
+
+
+CONTRACT_SHAPES = [  # B, N, Nout, G, F, E, K
+    (2, 70, 70, 32, 32, 1, 5), (3, 45, 10, 32, 32, 1, 5), (2, 33, 33, 64, 32, 1, 5), (2, 40, 40, 32, 64, 1, 3),
+    (2, 50, 50, 8, 5, 1, 4), (2, 37, 37, 16, 100, 2, 3), (3, 41, 41, 1, 64, 1, 5), (2, 29, 29, 3, 5, 2, 4),
+    (1, 64, 64, 32, 32, 1, 1), (2, 31, 31, 128, 32, 1, 2), (2, 31, 31, 24, 7, 1, 3),
+]
+
+
+@pytest.mark.parametrize("shape", CONTRACT_SHAPES, ids=lambda s: "B%d_N%d_Nout%d_G%d_F%d_E%d_K%d" % s)
+@pytest.mark.parametrize("transpose", [0, 1])
+def test_contract_against_einsum(shape, transpose):
+    L = _lib.lib()
+    B, N, Nout, G, F, E, K = shape
+    T = 1 + E * (K - 1)
+    Cin, Cout = (F, G) if transpose else (G, F)
+    rng = np.random.RandomState(3)
+    Z = rng.randn(T, B, N, Cin).astype(np.float32)
+    h = (rng.randn(F, E, K, G) / np.sqrt(G * K)).astype(np.float32)
+    bias = None if transpose else rng.randn(F).astype(np.float32)
+    out = torch.full((B, Cout, Nout), float("nan"), device=DEV)
+    Zt, ht = cu(Z), cu(h)
+    bt = cu(bias) if bias is not None else None
+    _lib.check(L.gf_contract(Zt.data_ptr(), ht.data_ptr(), bt.data_ptr() if bt is not None else None, out.data_ptr(),
+                             B, N, Nout, G, F, E, K, transpose, stream()))
+    Hm = _bank(h.astype(np.float64), transpose)
+    want = np.einsum("tbnc,tco->bon", Z[:, :, :Nout].astype(np.float64), Hm)
+    if bias is not None:
+        want = want + bias.astype(np.float64)[None, :, None]
+    assert relerr(out.cpu().numpy(), want) < 3e-6
+
+
+@pytest.mark.parametrize("shape", [(4, 100, 32, 32, 1, 5), (3, 77, 64, 32, 1, 5), (2, 60, 32, 64, 1, 3), (5, 33, 1, 64, 1, 5),
+                                   (2, 41, 7, 5, 2, 3), (3, 500, 32, 32, 2, 5), (2, 50, 96, 40, 1, 4)],
+                         ids=lambda s: "B%d_N%d_G%d_F%d_E%d_K%d" % s)
+def test_grad_taps_against_einsum(shape):
+    L = _lib.lib()
+    B, N, G, F, E, K = shape
+    T = 1 + E * (K - 1)
+    rng = np.random.RandomState(5)
+    Z = rng.randn(T, B, N, G).astype(np.float32)
+    P0 = rng.randn(B, N, F).astype(np.float32)
+    dh = torch.full((F, E, K, G), float("nan"), device=DEV)
+    db = torch.full((F,), float("nan"), device=DEV)
+    nbytes = L.gf_grad_taps_workspace_bytes(B, N, G, F, E, K)
+    ws = torch.empty(nbytes // 4 + 1, device=DEV)
+    Zt, Pt = cu(Z), cu(P0)
+    _lib.check(L.gf_grad_taps(Zt.data_ptr(), Pt.data_ptr(), dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes,
+                              B, N, G, F, E, K, stream()))
+    dHm = np.einsum("tbng,bnf->tgf", Z.astype(np.float64), P0.astype(np.float64))
+    want = np.zeros((F, E, K, G))
+    for e in range(E):
+        want[:, e, 0, :] = dHm[0].T
+        for k in range(1, K):
+            want[:, e, k, :] = dHm[1 + e * (K - 1) + k - 1].T
+    assert relerr(dh.cpu().numpy(), want) < 5e-6
+    assert relerr(db.cpu().numpy(), P0.astype(np.float64).sum(axis=(0, 1))) < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LSIGF / GraphFilter / SelectionGNN against the reference's own outputs (golden vectors)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files("lsigf"), ids=case_id)
+def test_lsigf_matches_reference_golden(path):
+    d = load(path)
+    h, x = cu(d["h"], True), cu(d["x"], True)
+    b = cu(d["b"], True) if "b" in d else None
+    y = LSIGF(h, torch.tensor(d["S"]), x, b)              # dense E x N x N GSO, exactly the reference's call
+    y.backward(cu(d["dy"]))
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    assert relerr(h.grad.cpu().numpy(), d["dh"]) < GRAD_RTOL
+    if b is not None:
+        assert relerr(b.grad.cpu().numpy(), d["db"]) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("path", golden_files("gfilter"), ids=case_id)
+def test_graph_filter_zero_padding_matches_reference(path):
+    d = load(path)
+    F, E, K, G = d["weight"].shape
+    layer = gml.GraphFilter(G, F, K, E, True)
+    layer.load_state_dict({"weight": torch.tensor(d["weight"]), "bias": torch.tensor(d["bias"])})
+    layer.addGSO(torch.tensor(d["S"]))
+    layer.to(DEV)
+    x = cu(d["x"], True)
+    y = layer(x)
+    assert tuple(y.shape) == d["y"].shape                  # Nin < N: output keeps Nin nodes (graphML.py:2142-2143)
+    y.backward(cu(d["dy"]))
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    assert relerr(layer.weight.grad.cpu().numpy(), d["dweight"]) < GRAD_RTOL
+    assert relerr(layer.bias.grad.cpu().numpy(), d["dbias"]) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("name", ["cfg1_sbm100", "cfg3_fbego"])
+def test_selection_gnn_matches_reference(name):
+    """BASELINE configs[0] (sourceLocGNN SBM N=100, K=5, F=[1,32,32]) and the config-3 architecture, with the
+    reference's weights: forward, input gradient and every parameter gradient."""
+    d = load(os.path.join(GOLDEN, f"selgnn_{name}.npz"))
+    cfg = d["cfg"]
+    net = SelectionGNN(cfg["dimNodeSignals"], cfg["nFilterTaps"], True, torch.nn.ReLU, cfg["nSelectedNodes"],
+                       getattr(gml, cfg["pool"]), cfg["poolingSize"], cfg["dimLayersMLP"], d["S"][0])
+    net.load_state_dict({k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")})
+    net = net.float().to(DEV)
+    x = cu(d["x"], True)
+    y, ygnn = net.splitForward(x)
+    (y * cu(d["w"])).sum().backward()
+    assert relerr(ygnn.detach().cpu().numpy(), d["ygnn"]) < FWD_RTOL
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < 5 * FWD_RTOL       # + fp32 nn.Linear on top
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    for k, p in net.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# seeded random inputs vs the CPU oracle (sparse restatement), sizes the oracle finishes in seconds
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(N=3000, B=20, G=32, F=32, K=5, directed=True, model="sbm"),
+    dict(N=5000, B=8, G=64, F=32, K=5, directed=False, model="er"),
+    dict(N=1682, B=5, G=1, F=64, K=5, directed=False, model="sbm"),      # config-3 first layer shape
+    dict(N=2000, B=33, G=32, F=32, K=3, directed=True, model="er", E=2),
+], ids=lambda c: "_".join(f"{k}{v}" for k, v in c.items()))
+def test_lsigf_random_sparse_vs_oracle(cfg):
+    E = cfg.get("E", 1)
+    gen = graphgen.sbm if cfg["model"] == "sbm" else graphgen.er
+    mats = [gen(cfg["N"], seed=11 + e, directed=cfg["directed"]) for e in range(E)]
+    rng = np.random.RandomState(2)
+    B, G, F, K, N = cfg["B"], cfg["G"], cfg["F"], cfg["K"], cfg["N"]
+    h = rng.uniform(-1, 1, (F, E, K, G)) / np.sqrt(G * K)
+    x = rng.randn(B, G, N)
+    b = rng.uniform(-1, 1, (F, 1))
+    dy = rng.randn(B, F, N)
+    ht, xt, bt = cu(h, True), cu(x, True), cu(b, True)
+    y = LSIGF(ht, SparseGSO(mats), xt, bt)
+    y.backward(cu(dy))
+    h32, x32, b32 = h.astype(np.float32), x.astype(np.float32), b.astype(np.float32)      # same rounded inputs
+    want = orc.lsigf_sparse(h32, mats, x32, b32)
+    dx, dh, db = orc.lsigf_sparse_grads(h32, mats, x32, b32, dy.astype(np.float32))
+    assert relerr(y.detach().cpu().numpy(), want) < FWD_RTOL
+    assert relerr(xt.grad.cpu().numpy(), dx) < GRAD_RTOL
+    assert relerr(ht.grad.cpu().numpy(), dh) < GRAD_RTOL
+    assert relerr(bt.grad.cpu().numpy(), db) < GRAD_RTOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full benchmark size (configs[1]: SBM N=10k, nnz~100k, B=256, K=5, 32->32): properties + oracle on a batch slice
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cfg2():
+    N, B, G, F, K = 10000, 256, 32, 32, 5
+    A = graphgen.sbm(N, seed=0)
+    torch.manual_seed(0)
+    layer = gml.GraphFilter(G, F, K, 1, True)
+    layer.addGSO(A)
+    layer.to(DEV)
+    x = torch.randn(B, G, N, device=DEV)
+    return dict(A=A, layer=layer, x=x, dims=(N, B, G, F, K))
+
+
+def test_full_size_batch_slice_vs_oracle(cfg2):
+    layer, x, A = cfg2["layer"], cfg2["x"], cfg2["A"]
+    xg = x.clone().requires_grad_(True)
+    y = layer(xg)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    sl = [0, 101, 255]                                       # batch entries are independent: check three of them
+    w, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+    want = orc.lsigf_sparse(w, A, x[sl].cpu().numpy(), b)
+    assert relerr(y[sl].detach().cpu().numpy(), want) < FWD_RTOL
+    dx, _, _ = orc.lsigf_sparse_grads(w, A, x[sl].cpu().numpy(), b, dy[sl].cpu().numpy())
+    assert relerr(xg.grad[sl].cpu().numpy(), dx) < GRAD_RTOL
+    # tap / bias gradients: oracle on a 16-entry slice of the batch, HIP path re-run on the same slice
+    sl16 = list(range(0, 256, 16))
+    layer.zero_grad()
+    y16 = layer(x[sl16])
+    y16.backward(dy[sl16])
+    _, dh, db = orc.lsigf_sparse_grads(w, A, x[sl16].cpu().numpy(), b, dy[sl16].cpu().numpy())
+    assert relerr(layer.weight.grad.cpu().numpy(), dh) < GRAD_RTOL
+    assert relerr(layer.bias.grad.cpu().numpy(), db) < GRAD_RTOL
+    layer.zero_grad()
+
+
+def test_full_size_properties(cfg2):
+    layer, x = cfg2["layer"], cfg2["x"]
+    with torch.no_grad():
+        y1 = layer(x)
+        y2 = layer(x)
+        assert torch.equal(y1, y2)                           # bitwise run-to-run determinism (no float atomics)
+        bias = layer.bias.detach().reshape(1, -1, 1)
+        ya = layer(2.0 * x)                                  # scaling by a power of two is exact in fp32
+        assert torch.equal(ya - bias, 2.0 * (y1 - bias)) or relerr((ya - bias).cpu().numpy(), (2.0 * (y1 - bias)).cpu().numpy()) < 1e-6
+        perm = torch.randperm(x.shape[0], device=DEV)
+        assert torch.equal(layer(x[perm]), y1[perm])         # batch entries never mix
+        x2 = torch.randn_like(x)
+        lin = layer(x + x2) - bias
+        assert relerr(lin.cpu().numpy(), ((y1 - bias) + (layer(x2) - bias)).cpu().numpy()) < 1e-5   # additivity
+
+
+def test_gradients_are_deterministic(cfg2):
+    layer, x = cfg2["layer"], cfg2["x"][:64]
+    grads = []
+    for _ in range(2):
+        layer.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        layer(xg).square().sum().backward()
+        grads.append((xg.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone()))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    layer.zero_grad()
+
+
+def test_error_conventions_on_device():
+    layer = gml.GraphFilter(4, 8, 3).to(DEV)
+    layer.addGSO(torch.eye(6).reshape(1, 6, 6))
+    with pytest.raises(AssertionError):
+        layer(torch.zeros(2, 5, 6, device=DEV))              # wrong feature count (graphML.py:139)
+    with pytest.raises(AssertionError):
+        layer(torch.zeros(2, 4, 7, device=DEV))              # more nodes than the GSO (graphML.py:140)
+    with pytest.raises(TypeError):
+        layer(torch.zeros(2, 4, 6, device=DEV, dtype=torch.float64))
+    y = layer(torch.zeros(2, 4, 6, device=DEV))
+    assert tuple(y.shape) == (2, 8, 6)
+    assert torch.allclose(y, layer.bias.detach().reshape(1, 8, 1).expand(2, 8, 6))

@@ -1,0 +1,199 @@
+"""CPU-only tests: host-side logic of the package and the C-ABI surface (no compute calls -- no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from _util import GOLDEN, load
+
+from alegnn_amd import SparseGSO, _lib, graphgen
+from alegnn_amd.modules.architectures import SelectionGNN
+from alegnn_amd.utils import graphML as gml
+from alegnn_amd.utils import graphTools as gt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------------
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gfhip.h")).read()
+    declared = sorted(set(re.findall(r"\b(gf_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in gfhip.h but not exported by libgfhip.so"
+    assert sorted(_lib.exported_symbols()) == declared, "ctypes signature table out of sync with gfhip.h"
+    m = re.search(r"#define GFHIP_VERSION (\d+)", hdr)
+    assert L.gf_version() == int(m.group(1))
+
+
+def test_c_abi_error_convention_without_gpu():
+    """Argument validation happens before any HIP call: status codes + thread-local message, no exceptions in C."""
+    L = _lib.lib()
+    assert L.gf_plan_info(None, None, None, None) == -2
+    assert b"plan is NULL" in L.gf_last_error()
+    rowptr = np.array([0, 2, 1], dtype=np.int32)           # not monotone
+    col = np.array([0, 1], dtype=np.int32)
+    val = np.array([1.0, 2.0], dtype=np.float32)
+    out = ctypes.c_void_p()
+    rc = L.gf_plan_create(2, 1, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, 0, 0, ctypes.byref(out))
+    assert rc == _lib.GF_ERR_SHAPE
+    with pytest.raises(AssertionError):                     # the reference raises AssertionError for shape violations
+        _lib.check(rc, "gf_plan_create")
+    rowptr = np.array([0, 1, 2], dtype=np.int32)
+    col = np.array([0, 5], dtype=np.int32)                  # column out of range
+    rc = L.gf_plan_create(2, 2, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, 0, 0, ctypes.byref(out))
+    assert rc == _lib.GF_ERR_SHAPE and b"column index" in L.gf_last_error()
+    assert L.gf_grad_taps_workspace_bytes(256, 10000, 32, 32, 1, 5) > 0
+    assert L.gf_spmm_hop(None, 0, None, None, 1, 32, None) == -2
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgfhip.so")
+    with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
+        _lib.lib()
+
+
+def test_no_cpu_fallback():
+    layer = gml.GraphFilter(4, 8, 3)
+    layer.addGSO(torch.eye(5).reshape(1, 5, 5))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.zeros(2, 4, 5))
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under the product package may import, call or link it."""
+    pkg = os.path.join(ROOT, "graph-neural-networks_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "lsigf_oracle", "oracle/_ref", "oracle."):
+                    assert needle not in src, f"{os.path.join(dirpath, f)} references the oracle ({needle!r})"
+
+
+# ---- GSO ingest --------------------------------------------------------------------------------------------
+def test_sparse_gso_from_any_forms_agree():
+    rng = np.random.RandomState(0)
+    S = (rng.rand(2, 9, 9) < 0.3) * rng.randn(2, 9, 9)
+    ref = SparseGSO.from_any(S)
+    assert ref.shape == (2, 9, 9) and ref.nnz == [int((S[e] != 0).sum()) for e in range(2)]
+    forms = [torch.tensor(S), [sp.csr_matrix(S[0]), sp.coo_matrix(S[1])], [S[0], S[1]], ref]
+    for f in forms:
+        g = SparseGSO.from_any(f)
+        for e in range(2):
+            assert (g.mats[e] != ref.mats[e]).nnz == 0
+    one = SparseGSO.from_any(torch.tensor(S[0]).to_sparse_csr())
+    assert (one.mats[0] != ref.mats[0]).nnz == 0
+    assert torch.equal(ref.to_dense(torch.float64), torch.tensor(S))
+    with pytest.raises(AssertionError):
+        SparseGSO.from_any(np.zeros((3, 4)))
+
+
+def test_graphgen_models():
+    A = graphgen.sbm(2000, avg_degree=10, seed=3)
+    assert A.shape == (2000, 2000) and abs(A.nnz / 2000 - 10) < 1.0
+    assert (abs(A - A.T)).nnz == 0 and A.diagonal().sum() == 0
+    B = graphgen.er(3000, avg_degree=8, seed=1, directed=True)
+    assert (abs(B - B.T)).nnz > 0 and abs(B.nnz / 3000 - 8) < 1.0
+    lam = np.max(np.abs(np.linalg.eigvals(graphgen.sbm(300, seed=2).toarray())))
+    assert abs(lam - 1.0) < 1e-6                              # S = A / lambda_max (examples/sourceLocGNN.py:752)
+    intra = sum(A[i * 400:(i + 1) * 400, i * 400:(i + 1) * 400].nnz for i in range(5))
+    assert 0.4 < intra / A.nnz < 0.6                          # 4:1 probabilities, 5 communities -> ~50 % intra edges
+
+
+# ---- graphTools mirror vs the reference's outputs ------------------------------------------------------------------
+def test_graphtools_matches_reference_outputs():
+    d = dict(np.load(os.path.join(GOLDEN, "graphtools_sbm100.npz")))
+    S = d["S"]
+    for key in [k for k in d if k.startswith("nbh_")]:
+        K, N, nb = (int(v) for v in key.split("_")[1:])
+        src = d["asym37"] if nb == 20 else S[None]
+        got = np.sort(gt.computeNeighborhood(src, K, N, nb, "matrix"), axis=1)
+        assert got.shape == d[key].shape and np.array_equal(got, d[key]), key
+        sparse_src = [sp.csr_matrix(m) for m in (src if src.ndim == 3 else src[None])]
+        got2 = np.sort(gt.computeNeighborhood(sparse_src, K, N, nb, "matrix"), axis=1)
+        assert np.array_equal(got2, d[key]), key + " (sparse input)"
+    for name in ("Degree", "EDS", "SpectralProxies"):
+        Sp, order = getattr(gt, "perm" + name)(S)
+        assert list(order) == list(d["order_" + name]), name
+        assert np.array_equal(Sp, d["S_" + name])
+    Sp, order = gt.permDegree(d["asym_E2"])
+    assert list(order) == list(d["order_Degree_E2"]) and np.array_equal(Sp, d["S_Degree_E2"])
+    Si, oi = gt.permIdentity(S)
+    assert oi == list(range(100)) and Si.shape == (100, 100)
+
+
+# ---- module surface ----------------------------------------------------------------------------------------------
+def test_graph_filter_surface_matches_reference():
+    torch.manual_seed(0)
+    layer = gml.GraphFilter(3, 7, 4, E=2, bias=True)
+    assert (layer.G, layer.F, layer.K, layer.E, layer.S) == (3, 7, 4, 2, None)
+    assert tuple(layer.weight.shape) == (7, 2, 4, 3) and tuple(layer.bias.shape) == (7, 1)     # graphML.py:2101-2103
+    assert list(layer.state_dict().keys()) == ["weight", "bias"]                                # S is not in the state_dict
+    bound = 1.0 / np.sqrt(3 * 4)                                                                # graphML.py:2111
+    assert float(layer.weight.abs().max()) <= bound and float(layer.bias.abs().max()) <= bound
+    assert "no GSO stored" in layer.extra_repr()
+    nob = gml.GraphFilter(3, 7, 4, bias=False)
+    assert nob.bias is None and list(nob.state_dict().keys()) == ["weight"]
+    with pytest.raises(AssertionError):
+        layer.addGSO(torch.zeros(5, 5))                   # needs 3 dims (graphML.py:2118)
+    with pytest.raises(AssertionError):
+        layer.addGSO(torch.zeros(1, 5, 5))                # E mismatch (graphML.py:2120)
+    with pytest.raises(AssertionError):
+        layer.addGSO(torch.zeros(2, 5, 6))                # not square (graphML.py:2122)
+    layer.addGSO(torch.zeros(2, 5, 5))
+    assert layer.N == 5 and "GSO stored" in layer.extra_repr()
+
+
+def _build(d, pool):
+    cfg = d["cfg"]
+    return SelectionGNN(cfg["dimNodeSignals"], cfg["nFilterTaps"], True, torch.nn.ReLU, cfg["nSelectedNodes"],
+                        getattr(gml, pool), cfg["poolingSize"], cfg["dimLayersMLP"], d["S"][0])
+
+
+@pytest.mark.parametrize("name", ["cfg1_sbm100", "cfg3_fbego"])
+def test_selection_gnn_checkpoint_compatibility(name):
+    d = load(os.path.join(GOLDEN, f"selgnn_{name}.npz"))
+    net = _build(d, d["cfg"]["pool"])
+    ref_sd = {k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")}
+    assert list(net.state_dict().keys()) == list(ref_sd.keys())                 # same names, same order
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(ref_sd[k].shape), k
+    net.load_state_dict(ref_sd, strict=True)                                    # reference checkpoint loads
+    assert net.N == [d["S"].shape[1]] + d["cfg"]["nSelectedNodes"]
+    assert isinstance(net.GFL[0], gml.GraphFilter) and isinstance(net.GFL[1], torch.nn.ReLU)
+
+
+def test_selection_gnn_ctor_options():
+    d = load(os.path.join(GOLDEN, "selgnn_cfg1_sbm100.npz"))
+    S = d["S"][0]
+    net = SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [10], gml.MaxPoolLocal, [2], [4], S, order="Degree")
+    g = dict(np.load(os.path.join(GOLDEN, "graphtools_sbm100.npz")))
+    assert list(net.order) == list(g["order_Degree"])                           # the reference's NameError path, fixed
+    assert np.array_equal(net.S.numpy()[0], g["S_Degree"])          # S is kept E x N x N (architectures.py:195)
+    with pytest.raises(NotImplementedError):
+        SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [10], gml.NoPool, [1], [], S, coarsening=True)
+    with pytest.raises(AssertionError):
+        SelectionGNN([1, 8, 8], [3], True, torch.nn.ReLU, [10], gml.NoPool, [1], [], S)
+    sparse_net = SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [100], gml.NoPool, [1], [], sp.csr_matrix(S))
+    assert sparse_net.E == 1 and sparse_net.N == [100, 100] and len(sparse_net.MLP) == 0
+    sparse_net.changeGSO(sp.csr_matrix(S[:50, :50]), nSelectedNodes=[50])
+    assert sparse_net.N == [50, 50] and sparse_net.GFL[0].N == 50
+
+
+def test_max_pool_local_semantics():
+    d = load(os.path.join(GOLDEN, "selgnn_cfg1_sbm100.npz"))
+    S = d["S"]
+    pool = gml.MaxPoolLocal(100, 10, 2)
+    pool.addGSO(torch.tensor(S))
+    x = torch.randn(3, 4, 100)
+    v = pool(x)
+    nbh = gt.computeNeighborhood(S, 2, 10, 100, "list")
+    want = torch.stack([x[:, :, nb].max(dim=2).values for nb in nbh], dim=2)
+    assert torch.equal(v, want) and "neighborhood" not in pool.state_dict()
