@@ -34,6 +34,7 @@ _SIGNATURES = {
     "gf_lsigf_backward": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_time_spmm_hop": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _c.POINTER(_c.c_float)]),
+    "gf_tune": (_c.c_int, [_c.c_char_p, _i32]),
 }
 
 

@@ -58,6 +58,13 @@ struct gf_csr_dev {
     float* val = nullptr;       // [nnz]
     int32_t* rowid = nullptr;   // [N]    stored position -> original row
     int32_t max_deg = 0;
+    // SELL-8 image of the same scheduled rows (slices of 8 consecutive stored rows, padded to the slice's longest row):
+    // entry (k, r) of slice s lives at sell_ent[(sell_kptr[s] + k) * 8 + r] = {col, bits(val)}; padding = {0, 0.0f}.
+    int32_t n_slices = 0;
+    int32_t* sell_kptr = nullptr;   // [n_slices + 1]  k-offsets (sum of slice widths)
+    int2* sell_ent = nullptr;       // [sell_kptr[n_slices] * 8]
+    int32_t* sell_rowid = nullptr;  // [n_slices * 8]  stored position -> original row, -1 past the last row
+    int64_t sell_pad_entries = 0;   // padding entries (wasted gathers), for diagnostics
 };
 
 struct gf_plan {
@@ -71,6 +78,18 @@ static inline hipStream_t gf_stream(void* s) { return reinterpret_cast<hipStream
 
 // tap-stack index helpers (see gfhip.h "Layouts")
 static inline int gf_num_taps(int E, int K) { return 1 + E * (K - 1); }
+
+// debugging / tuning knobs (gf_tune): not part of the numerical contract, every setting gives identical results
+struct gf_tuning {
+    int spmm_bt = 0;            // 0 = heuristic, else 1 / 2 / 4 batch entries per lane
+    int spmm_nl = 0;            // 0 = default, else 4 / 8 gather loads in flight per lane
+    int spmm_blocks_per_cu = 0; // 0 = default persistent grid (blocks per CU)
+    int spmm_generic = 0;       // 1 = force the generic one-thread-per-element kernel
+    int spmm_algo = 0;          // 0 = SELL-8 persistent wave kernel, 1 = CSR workgroup-staged kernel (first version)
+    int spmm_xcd = 1;           // 1 = XCD-aware tile order
+    int contract_generic = 0;   // 1 = force the generic contraction kernel
+};
+extern gf_tuning g_tune;
 
 // internal launchers shared between translation units
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,

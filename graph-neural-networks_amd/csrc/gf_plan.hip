@@ -21,6 +21,24 @@ void gf_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gf_last_error(void) { return g_err; }
+
+gf_tuning g_tune;
+
+extern "C" int gf_tune(const char* key, int32_t value) {
+    GF_REQUIRE_ARG(key != nullptr, "gf_tune: key is NULL");
+    if (!strcmp(key, "spmm_bt")) g_tune.spmm_bt = value;
+    else if (!strcmp(key, "spmm_nl")) g_tune.spmm_nl = value;
+    else if (!strcmp(key, "spmm_blocks_per_cu")) g_tune.spmm_blocks_per_cu = value;
+    else if (!strcmp(key, "spmm_generic")) g_tune.spmm_generic = value;
+    else if (!strcmp(key, "spmm_algo")) g_tune.spmm_algo = value;
+    else if (!strcmp(key, "spmm_xcd")) g_tune.spmm_xcd = value;
+    else if (!strcmp(key, "contract_generic")) g_tune.contract_generic = value;
+    else {
+        gf_set_error("gf_tune: unknown key '%s'", key);
+        return GF_ERR_ARG;
+    }
+    return GF_OK;
+}
 extern "C" int gf_version(void) { return GFHIP_VERSION; }
 
 // ---------------------------------------------------------------------------------------------------
@@ -127,6 +145,31 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, gf_csr_dev& d, int64_t&
     if ((rc = upload(s.col, &d.col, bytes))) return rc;
     if ((rc = upload(s.val, &d.val, bytes))) return rc;
     if ((rc = upload(rowid, &d.rowid, bytes))) return rc;
+
+    // SELL-8: slices of 8 consecutive scheduled rows; the degree-sorted schedule keeps padding small.
+    const int32_t ns = (n + 7) / 8;
+    std::vector<int32_t> kptr(ns + 1, 0), rid(ns * 8, -1);
+    for (int32_t sl = 0; sl < ns; ++sl) {
+        int32_t w = 0;
+        for (int32_t r = 0; r < 8 && sl * 8 + r < n; ++r) w = std::max(w, s.rowptr[sl * 8 + r + 1] - s.rowptr[sl * 8 + r]);
+        kptr[sl + 1] = kptr[sl] + w;
+    }
+    std::vector<int2> ent((size_t)kptr[ns] * 8, make_int2(0, 0));
+    for (int32_t sl = 0; sl < ns; ++sl)
+        for (int32_t r = 0; r < 8 && sl * 8 + r < n; ++r) {
+            const int32_t p = sl * 8 + r;
+            rid[p] = rowid[p];
+            for (int32_t q = s.rowptr[p]; q < s.rowptr[p + 1]; ++q) {
+                int32_t bits;
+                std::memcpy(&bits, &s.val[q], 4);
+                ent[((size_t)kptr[sl] + (q - s.rowptr[p])) * 8 + r] = make_int2(s.col[q], bits);
+            }
+        }
+    d.n_slices = ns;
+    d.sell_pad_entries = (int64_t)kptr[ns] * 8 - (int64_t)s.col.size();
+    if ((rc = upload(kptr, &d.sell_kptr, bytes))) return rc;
+    if ((rc = upload(ent, &d.sell_ent, bytes))) return rc;
+    if ((rc = upload(rid, &d.sell_rowid, bytes))) return rc;
     return GF_OK;
 }
 
@@ -135,6 +178,9 @@ void free_csr(gf_csr_dev& d) {
     if (d.col) (void)hipFree(d.col);
     if (d.val) (void)hipFree(d.val);
     if (d.rowid) (void)hipFree(d.rowid);
+    if (d.sell_kptr) (void)hipFree(d.sell_kptr);
+    if (d.sell_ent) (void)hipFree(d.sell_ent);
+    if (d.sell_rowid) (void)hipFree(d.sell_rowid);
     d = gf_csr_dev{};
 }
 

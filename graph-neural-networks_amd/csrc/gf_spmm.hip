@@ -1,20 +1,31 @@
 // gf_spmm.hip -- the K-hop GSO-signal product: X_k = op(S) X_{k-1} on node-major signals.
 // Replaces the K-1 dense broadcast GEMMs `x = torch.matmul(x, S)` of reference graphML.py:158-161
-// (O(B*G*N^2) each) with CSR SpMM (O(B*G*nnz)), and the growing torch.cat (graphML.py:161) with in-place
+// (O(B*G*N^2) each) with sparse products (O(B*G*nnz)), and the growing torch.cat (graphML.py:161) with in-place
 // writes into tap slot k of the stack Z[T,B,N,G].
 //
-// HBM-bound.  Algorithmic bytes per hop:  2*B*N*W*4 + nnz*8 + (N+1)*4.
+// HBM-bound by the algorithmic count:  bytes/hop = 2*B*N*W*4 + nnz*8 + (N+1)*4.
+// What the hardware actually has to serve is the gather stream nnz*B*W*4 (each signal row is re-read once per
+// neighbour, ~10x the algorithmic read); it can only come out of cache, so the design goal is: keep the gather
+// panel L2-resident and keep the vector-memory pipe (64 B/clk/CU) saturated with 128-byte line gathers.
 //
-// Kernel shape (W = row width in floats, LG = W/4 lanes per row, float4 per lane):
-//   * a 256-thread workgroup owns RPB = 256/LG consecutive rows of the (degree-sorted) schedule for BT batch
-//     entries; its CSR segment (col, val) is staged in LDS with coalesced loads, column indices pre-scaled
-//     to float offsets; each LG-lane group then walks its own row out of LDS (broadcast reads), gathering one
-//     full W*4-byte line per neighbour per batch entry and accumulating in registers -- a segmented reduction
-//     with the segment (= row) pinned to the lane group, so no atomics and a fixed summation order.
-//   * rows in one wavefront have near-equal degree (plan schedule), so the walk is nearly divergence-free.
-//   * blockIdx -> (batch tile, row block) is XCD-aware: workgroup L runs on XCD L%8 (observed dispatch order),
-//     so batch tile t is pinned to XCD t%8 and all row blocks of one batch tile are swept by one XCD: the
-//     N*W*4*BT-byte gather panel is shared through ONE L2 instead of being replicated in eight.
+// Kernel A (default) -- SELL-8, persistent, wave-autonomous:
+//   * the plan stores the degree-sorted rows as SELL-8 slices (8 rows padded to the slice's longest row, entries
+//     k-major).  One wavefront owns one slice: lane = row*8 + sub-lane, 8 sub-lanes x float4 = one 128-byte line per
+//     row per neighbour (W = 32); W = 64..256 -> several float4 per lane, W < 32 -> spare sub-lanes take more batch
+//     entries.  All 8 rows of a slice walk the same (wave-uniform) number of neighbours: no divergence, static
+//     software pipelining, and exact s_waitcnt counts.
+//   * the slice's (col, val) stream is staged through a per-wave LDS ring (coalesced 512-byte reads, then broadcast
+//     ds_read_b64 per neighbour): index traffic stays off the vector-memory return path that the gathers need.
+//     The NEXT slice's entries are loaded while the current slice is gathered -> a wave never sits in a start-up
+//     latency chain (rowptr -> col/val -> gather), and no workgroup barrier exists at all.
+//   * waves are persistent and walk work items (batch tile, slice) in an XCD-aware order: workgroup L runs on XCD
+//     L%8 (observed dispatch order; a wrong guess costs speed, never correctness), batch tile t is pinned to XCD t%8
+//     and every wave of that XCD sweeps the slices of the same batch tile together -> the N*W*4*BT-byte gather
+//     panel is shared through ONE 4 MiB L2 instead of being replicated in eight.
+//   * each (row, batch entry) sum runs over the row's entries in ascending column order in one lane group: fixed
+//     summation order, no atomics -> bitwise deterministic.  (Padding entries are {col 0, val 0}: they add +0.)
+// Kernel B -- CSR, one workgroup per 256/LG rows with its segment staged in LDS (the first version; kept for A/B).
+// Kernel C -- generic: any W (G = 1, odd widths), one thread per output element.
 #include <stdlib.h>
 
 #include "gf_common.h"
@@ -22,7 +33,8 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kChunk = 2048;  // CSR entries staged per pass: 16 KB of LDS
+constexpr int kChunk = 2048;  // kernel B: CSR entries staged per pass (16 KB of LDS)
+constexpr int kCK = 32;       // kernel A: neighbours (k) per LDS ring slot -> 32*8 entries * 8 B = 2 KB per slot
 
 __device__ __forceinline__ void fma4(float4& a, float s, const float4& x) {
     a.x = fmaf(s, x.x, a.x);
@@ -31,6 +43,183 @@ __device__ __forceinline__ void fma4(float4& a, float s, const float4& x) {
     a.w = fmaf(s, x.w, a.w);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel A
+//   LPR = sub-lanes per row (1, 2, 4, 8), VPL = float4 per lane per neighbour, W = 4 * LPR * VPL
+//   BL  = 8 / LPR batch entries side by side in one wave, BT = batch entries per lane (register tile)
+//   NL  = gather instructions in flight per lane per pipeline step (U = NL / (BT * VPL) neighbours)
+// ------------------------------------------------------------------------------------------------------------------
+template <int LPR, int VPL, int BT, int NL>
+__global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __restrict__ kptr, const int2* __restrict__ ent,
+                                                             const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
+                                                             float* __restrict__ Xout, int N, int B, int nSlices, int nBTiles,
+                                                             int xcd_map) {
+    constexpr int BL = 8 / LPR;
+    constexpr int W = 4 * LPR * VPL;
+    constexpr int BTW = BL * BT;  // batch entries per work item
+    constexpr int U = (NL / (BT * VPL)) > 0 ? (NL / (BT * VPL)) : 1;
+    __shared__ int2 s_ent[kThreads / 64][2][kCK * 8];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane >> 3, sub = lane & 7;
+    const int bl = sub / LPR, li = sub - bl * LPR;
+
+    // ---- persistent work distribution ----------------------------------------------------------------------------
+    int64_t nItems, item, stride;
+    int bt_first, bt_step;
+    if (xcd_map) {
+        const int xcd = blockIdx.x & 7;
+        const int nBTx = (nBTiles > xcd) ? (nBTiles - xcd + 7) / 8 : 0;
+        nItems = (int64_t)nBTx * nSlices;
+        item = (int64_t)(blockIdx.x >> 3) * (kThreads / 64) + wave;
+        stride = (int64_t)(gridDim.x >> 3) * (kThreads / 64);
+        bt_first = xcd;
+        bt_step = 8;
+    } else {
+        nItems = (int64_t)nBTiles * nSlices;
+        item = (int64_t)blockIdx.x * (kThreads / 64) + wave;
+        stride = (int64_t)gridDim.x * (kThreads / 64);
+        bt_first = 0;
+        bt_step = 1;
+    }
+    if (item >= nItems) return;  // wave-uniform; there are no workgroup barriers in this kernel
+
+    int2* ring0 = &s_ent[wave][0][0];
+    int2* ring1 = &s_ent[wave][1][0];
+
+    // entries of k-range [ka, kb) (kb - ka <= kCK) -> 4 registers per lane, coalesced 512-byte reads
+    int2 pre[4];
+    auto issue_entries = [&](int ka, int kb) {
+        const int cnt = (kb - ka) * 8;
+        const int2* src = ent + (int64_t)ka * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = j * 64 + lane;
+            pre[j] = (e < cnt) ? src[e] : make_int2(0, 0);
+        }
+    };
+    auto commit_entries = [&](int2* dst) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j * 64 + lane] = pre[j];
+    };
+
+    int s = (int)(item % nSlices);
+    int tl = (int)(item / nSlices);
+    int k0 = kptr[s], k1 = kptr[s + 1];
+    issue_entries(k0, min(k1, k0 + kCK));
+    commit_entries(ring0);
+    int cur = 0;
+
+    int64_t nxt = item + stride;
+    bool has_next = nxt < nItems;
+    int sn = 0, k0n = 0, k1n = 0;
+    if (has_next) {
+        sn = (int)(nxt % nSlices);
+        k0n = kptr[sn];
+        k1n = kptr[sn + 1];
+    }
+
+    for (;;) {
+        const int b0 = (bt_first + tl * bt_step) * BTW;
+        const float* xb[BT];
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+            const int b = min(b0 + t * BL + bl, B - 1);  // clamp loads of a ragged last tile; stores are masked
+            xb[t] = Xin + (int64_t)b * N * W + li * 4;
+        }
+        const int orow = rowid[s * 8 + r];  // -1 past the last row; issued early, consumed at the store
+        float4 acc[BT][VPL];
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) acc[t][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        for (int kc = k0;;) {  // ring slots of this slice (one for ordinary rows, many for hub rows)
+            const int kend = min(k1, kc + kCK);
+            // -- prefetch the next ring slot: same slice's next chunk, or the next work item's first chunk
+            bool fetch = true;
+            if (kend < k1)
+                issue_entries(kend, min(k1, kend + kCK));
+            else if (has_next)
+                issue_entries(k0n, min(k1n, k0n + kCK));
+            else
+                fetch = false;
+
+            // -- gather + accumulate the nk neighbours staged in the current slot
+            const int2* eb = (cur ? ring1 : ring0) + r;
+            const int nk = kend - kc;
+            int k = 0;
+            for (; k + U <= nk; k += U) {
+                int2 e[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) e[u] = eb[(k + u) * 8];
+                float4 x[U][BT][VPL];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned off = __umul24((unsigned)e[u].x, (unsigned)W);
+#pragma unroll
+                    for (int t = 0; t < BT; ++t)
+#pragma unroll
+                        for (int v = 0; v < VPL; ++v) x[u][t][v] = *reinterpret_cast<const float4*>(xb[t] + off + v * (LPR * 4));
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {  // ascending k: fixed summation order
+                    const float val = __int_as_float(e[u].y);
+#pragma unroll
+                    for (int t = 0; t < BT; ++t)
+#pragma unroll
+                        for (int v = 0; v < VPL; ++v) fma4(acc[t][v], val, x[u][t][v]);
+                }
+            }
+            for (; k < nk; ++k) {
+                const int2 e = eb[k * 8];
+                const unsigned off = __umul24((unsigned)e.x, (unsigned)W);
+                const float val = __int_as_float(e.y);
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v)
+                        fma4(acc[t][v], val, *reinterpret_cast<const float4*>(xb[t] + off + v * (LPR * 4)));
+            }
+
+            if (fetch) commit_entries(cur ? ring0 : ring1);  // LDS ops of one wave execute in order: no barrier needed
+            cur ^= 1;
+            if (kend >= k1) break;
+            kc = kend;
+        }
+
+        if (orow >= 0) {
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                const int b = b0 + t * BL + bl;
+                if (b < B) {
+                    float* o = Xout + (int64_t)b * N * W + (int64_t)orow * W + li * 4;
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) *reinterpret_cast<float4*>(o + v * (LPR * 4)) = acc[t][v];
+                }
+            }
+        }
+
+        if (!has_next) break;
+        item = nxt;
+        s = sn;
+        tl = (int)(item / nSlices);
+        k0 = k0n;
+        k1 = k1n;
+        nxt = item + stride;
+        has_next = nxt < nItems;
+        if (has_next) {
+            sn = (int)(nxt % nSlices);
+            k0n = kptr[sn];
+            k1n = kptr[sn + 1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel B: CSR, workgroup-staged segment
+// ------------------------------------------------------------------------------------------------------------------
 template <int LG, int BT>
 __global__ __launch_bounds__(kThreads) void spmm_hop_vec_kernel(const int32_t* __restrict__ rowptr,
                                                                 const int32_t* __restrict__ col,
@@ -75,14 +264,14 @@ __global__ __launch_bounds__(kThreads) void spmm_hop_vec_kernel(const int32_t* _
     float4 acc[BT];
 #pragma unroll
     for (int t = 0; t < BT; ++t) {
-        const int b = min(b0 + t, B - 1);  // clamp loads of a ragged last tile; its stores are masked below
+        const int b = min(b0 + t, B - 1);
         xb[t] = Xin + (int64_t)b * N * W + li * 4;
         acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     for (int base = seg_lo; base < seg_hi; base += kChunk) {
         const int cnt = min(kChunk, seg_hi - base);
-        if (base != seg_lo) __syncthreads();  // everyone is done with the previous chunk
+        if (base != seg_lo) __syncthreads();
         for (int i = tid; i < cnt; i += kThreads) {
             s_off[i] = col[base + i] * W;
             s_val[i] = val[base + i];
@@ -102,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void spmm_hop_vec_kernel(const int32_t* _
                 x3[t] = *reinterpret_cast<const float4*>(xb[t] + o3);
             }
 #pragma unroll
-            for (int t = 0; t < BT; ++t) {  // fixed order q, q+1, q+2, q+3: deterministic
+            for (int t = 0; t < BT; ++t) {
                 fma4(acc[t], v0, x0[t]);
                 fma4(acc[t], v1, x1[t]);
                 fma4(acc[t], v2, x2[t]);
@@ -125,7 +314,9 @@ __global__ __launch_bounds__(kThreads) void spmm_hop_vec_kernel(const int32_t* _
     }
 }
 
-// any width W (G = 1, odd G, N*W >= 2^31): one thread per output element, CSR read through the caches.
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel C: any width W (G = 1, odd G, N*W >= 2^24): one thread per output element, CSR read through the caches.
+// ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void spmm_hop_generic_kernel(const int32_t* __restrict__ rowptr,
                                                                     const int32_t* __restrict__ col,
                                                                     const float* __restrict__ val,
@@ -144,14 +335,61 @@ __global__ __launch_bounds__(kThreads) void spmm_hop_generic_kernel(const int32_
     }
 }
 
-int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
+// ------------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------------
+int pick_bt(int N, int W, int B, int bl) {
+    if (g_tune.spmm_bt == 1 || g_tune.spmm_bt == 2 || g_tune.spmm_bt == 4) return g_tune.spmm_bt;
+    // keep the gather panel of one work item (N*W*4 bytes per batch entry) inside one XCD's 4 MiB L2
+    const int64_t panel = (int64_t)N * W * 4 * bl;
+    int bt = 1;
+    if (panel * 2 <= (5 << 19) && B >= 16 * bl) bt = 2;
+    if (panel * 4 <= (5 << 19) && B >= 32 * bl) bt = 4;
+    return bt;
+}
+
+template <int LPR, int VPL>
+int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st) {
+    constexpr int BL = 8 / LPR, W = 4 * LPR * VPL;
+    int bt = pick_bt(N, W, B, BL);
+    while (bt * VPL > 8) bt >>= 1;  // bound the register tile
+    const int nl = (g_tune.spmm_nl == 4 || g_tune.spmm_nl == 8) ? g_tune.spmm_nl : 8;
+    const int nBTiles = (B + BL * bt - 1) / (BL * bt);
+    const int64_t items = (int64_t)nBTiles * m.n_slices;
+    const int bpc = g_tune.spmm_blocks_per_cu > 0 ? g_tune.spmm_blocks_per_cu : 6;
+    int64_t nblk = 256 * bpc;  // persistent: 256 CUs x bpc workgroups of 4 waves, a multiple of 8 (XCDs)
+    const int64_t need = ((items + 3) / 4 + 7) / 8 * 8;
+    if (nblk > need) nblk = need;
+    if (nblk < 8) nblk = 8;
+    dim3 grid((unsigned)nblk), block(kThreads);
+    // XCD pinning only when the batch tiles spread evenly over the 8 XCDs (else balance beats locality)
+    const int xcd = (g_tune.spmm_xcd && (nBTiles % 8 == 0 || nBTiles >= 64)) ? 1 : 0;
+#define GF_SELL(BTV, NLV)                                                                                               \
+    hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, NLV>), grid, block, 0, st, m.sell_kptr, m.sell_ent, m.sell_rowid, \
+                       Xin, Xout, N, B, m.n_slices, nBTiles, xcd)
+    if (nl == 8) {
+        switch (bt) {
+            case 1: GF_SELL(1, 8); break;
+            case 2: GF_SELL(2, 8); break;
+            default: GF_SELL(4, 8); break;
+        }
+    } else {
+        switch (bt) {
+            case 1: GF_SELL(1, 4); break;
+            case 2: GF_SELL(2, 4); break;
+            default: GF_SELL(4, 4); break;
+        }
+    }
+#undef GF_SELL
+    GF_LAUNCH_CHECK("spmm_sell_kernel");
+    return GF_OK;
 }
 
 template <int LG>
-int launch_vec(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, int bt, int xcd_map, hipStream_t st) {
+int launch_vec(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st) {
     constexpr int RPB = kThreads / LG;
+    const int bt = pick_bt(N, LG * 4, B, 1);
+    const int xcd_map = g_tune.spmm_xcd;
     const int nRowBlocks = (N + RPB - 1) / RPB;
     const int nBTiles = (B + bt - 1) / bt;
     const int64_t nblk = xcd_map ? (int64_t)((nBTiles + 7) / 8) * 8 * nRowBlocks : (int64_t)nBTiles * nRowBlocks;
@@ -182,28 +420,31 @@ extern "C" int gf_spmm_hop(const gf_plan* plan, int32_t op, const float* Xin, fl
     const int N = plan->n;
     hipStream_t st = gf_stream(stream);
 
-    static const int env_bt = env_int("GFHIP_SPMM_BT", 0);
-    static const int env_xcd = env_int("GFHIP_SPMM_XCD", 1);
-    static const int env_generic = env_int("GFHIP_SPMM_GENERIC", 0);
-
-    const int lg = W / 4;
-    const bool pow2 = lg > 0 && (lg & (lg - 1)) == 0;
-    const bool vec_ok = !env_generic && (W % 4 == 0) && pow2 && lg <= 64 && (int64_t)N * W < (int64_t)INT32_MAX;
-    if (vec_ok) {
-        // batch-tile heuristic: keep the BT-entry gather panel (N*W*4*BT bytes) inside one XCD's 4 MiB L2
-        const int64_t panel = (int64_t)N * W * 4;
-        int bt = 1;
-        if (panel * 2 <= (5 << 19) && B >= 16) bt = 2;
-        if (panel * 4 <= (5 << 19) && B >= 32) bt = 4;
-        if (env_bt == 1 || env_bt == 2 || env_bt == 4) bt = env_bt;
-        switch (lg) {
-            case 1: return launch_vec<1>(m, Xin, Xout, N, B, bt, env_xcd, st);
-            case 2: return launch_vec<2>(m, Xin, Xout, N, B, bt, env_xcd, st);
-            case 4: return launch_vec<4>(m, Xin, Xout, N, B, bt, env_xcd, st);
-            case 8: return launch_vec<8>(m, Xin, Xout, N, B, bt, env_xcd, st);
-            case 16: return launch_vec<16>(m, Xin, Xout, N, B, bt, env_xcd, st);
-            case 32: return launch_vec<32>(m, Xin, Xout, N, B, bt, env_xcd, st);
-            default: return launch_vec<64>(m, Xin, Xout, N, B, bt, env_xcd, st);
+    const bool fits24 = (int64_t)N < (1 << 24) && (int64_t)N * W < (int64_t)INT32_MAX;  // __umul24 offsets
+    if (!g_tune.spmm_generic && fits24) {
+        if (g_tune.spmm_algo == 0) {
+            switch (W) {
+                case 4: return launch_sell<1, 1>(m, Xin, Xout, N, B, st);
+                case 8: return launch_sell<2, 1>(m, Xin, Xout, N, B, st);
+                case 16: return launch_sell<4, 1>(m, Xin, Xout, N, B, st);
+                case 32: return launch_sell<8, 1>(m, Xin, Xout, N, B, st);
+                case 64: return launch_sell<8, 2>(m, Xin, Xout, N, B, st);
+                case 96: return launch_sell<8, 3>(m, Xin, Xout, N, B, st);
+                case 128: return launch_sell<8, 4>(m, Xin, Xout, N, B, st);
+                case 256: return launch_sell<8, 8>(m, Xin, Xout, N, B, st);
+                default: break;
+            }
+        } else {
+            switch (W) {
+                case 4: return launch_vec<1>(m, Xin, Xout, N, B, st);
+                case 8: return launch_vec<2>(m, Xin, Xout, N, B, st);
+                case 16: return launch_vec<4>(m, Xin, Xout, N, B, st);
+                case 32: return launch_vec<8>(m, Xin, Xout, N, B, st);
+                case 64: return launch_vec<16>(m, Xin, Xout, N, B, st);
+                case 128: return launch_vec<32>(m, Xin, Xout, N, B, st);
+                case 256: return launch_vec<64>(m, Xin, Xout, N, B, st);
+                default: break;
+            }
         }
     }
     const int64_t total = (int64_t)B * N * W;
