@@ -43,6 +43,24 @@ __device__ __forceinline__ void fma4(float4& a, float s, const float4& x) {
     a.w = fmaf(s, x.w, a.w);
 }
 
+// Output rows are written once and never re-read by this kernel; a plain store leaves the line in the XCD's L2
+// where it competes with the gather panel for the 4 MiB.  mode 1 = write-through (sc1: the line leaves L2),
+// mode 2 = non-temporal hint, mode 0 = plain.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_row(float* p, const float4& v, int mode) {
+    if (mode == 1) {
+        const f32x4 d = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+    } else if (mode == 2) {
+        __builtin_nontemporal_store(v.x, p);
+        __builtin_nontemporal_store(v.y, p + 1);
+        __builtin_nontemporal_store(v.z, p + 2);
+        __builtin_nontemporal_store(v.w, p + 3);
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Kernel A
 //   LPR = sub-lanes per row (1, 2, 4, 8), VPL = float4 per lane per neighbour, W = 4 * LPR * VPL
@@ -53,7 +71,7 @@ template <int LPR, int VPL, int BT, int NL>
 __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __restrict__ kptr, const int2* __restrict__ ent,
                                                              const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
                                                              float* __restrict__ Xout, int N, int B, int nSlices, int nBTiles,
-                                                             int xcd_map) {
+                                                             int lanes, int parts, int store_mode) {
     constexpr int BL = 8 / LPR;
     constexpr int W = 4 * LPR * VPL;
     constexpr int BTW = BL * BT;  // batch entries per work item
@@ -65,25 +83,17 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
     const int r = lane >> 3, sub = lane & 7;
     const int bl = sub / LPR, li = sub - bl * LPR;
 
-    // ---- persistent work distribution ----------------------------------------------------------------------------
-    int64_t nItems, item, stride;
-    int bt_first, bt_step;
-    if (xcd_map) {
-        const int xcd = blockIdx.x & 7;
-        const int nBTx = (nBTiles > xcd) ? (nBTiles - xcd + 7) / 8 : 0;
-        nItems = (int64_t)nBTx * nSlices;
-        item = (int64_t)(blockIdx.x >> 3) * (kThreads / 64) + wave;
-        stride = (int64_t)(gridDim.x >> 3) * (kThreads / 64);
-        bt_first = xcd;
-        bt_step = 8;
-    } else {
-        nItems = (int64_t)nBTiles * nSlices;
-        item = (int64_t)blockIdx.x * (kThreads / 64) + wave;
-        stride = (int64_t)gridDim.x * (kThreads / 64);
-        bt_first = 0;
-        bt_step = 1;
-    }
-    if (item >= nItems) return;  // wave-uniform; there are no workgroup barriers in this kernel
+    // ---- persistent work distribution ----------------------------------------------------------------------------------
+    // XCD x = blockIdx % 8 serves batch-tile lane x % lanes (tiles lane, lane + lanes, ... strictly in order) and slice
+    // partition x / lanes of `parts`; its waves stride over that partition's slices.  lanes * parts <= 8.
+    const int xcd = blockIdx.x & 7;
+    const int lane_t = xcd % lanes, part = xcd / lanes;
+    if (part >= parts) return;  // wave-uniform; there are no workgroup barriers in this kernel
+    const int nTiles = (nBTiles > lane_t) ? (nBTiles - lane_t + lanes - 1) / lanes : 0;
+    const int WX = (gridDim.x >> 3) * (kThreads / 64) * parts;
+    const int wl = ((blockIdx.x >> 3) * (kThreads / 64) + wave) * parts + part;
+    const int bt_first = lane_t, bt_step = lanes;
+    if (wl >= nSlices || nTiles == 0) return;
 
     int2* ring0 = &s_ent[wave][0][0];
     int2* ring1 = &s_ent[wave][1][0];
@@ -104,18 +114,21 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
         for (int j = 0; j < 4; ++j) dst[j * 64 + lane] = pre[j];
     };
 
-    int s = (int)(item % nSlices);
-    int tl = (int)(item / nSlices);
+    int s = wl, tl = 0;
     int k0 = kptr[s], k1 = kptr[s + 1];
     issue_entries(k0, min(k1, k0 + kCK));
     commit_entries(ring0);
     int cur = 0;
 
-    int64_t nxt = item + stride;
-    bool has_next = nxt < nItems;
-    int sn = 0, k0n = 0, k1n = 0;
+    // successor of (tl, s): next slice of the same tile, else this wave's first slice of the next tile
+    int sn = s + WX, tln = tl;
+    if (sn >= nSlices) {
+        sn = wl;
+        tln = tl + 1;
+    }
+    bool has_next = tln < nTiles;
+    int k0n = 0, k1n = 0;
     if (has_next) {
-        sn = (int)(nxt % nSlices);
         k0n = kptr[sn];
         k1n = kptr[sn + 1];
     }
@@ -196,21 +209,23 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
                 if (b < B) {
                     float* o = Xout + (int64_t)b * N * W + (int64_t)orow * W + li * 4;
 #pragma unroll
-                    for (int v = 0; v < VPL; ++v) *reinterpret_cast<float4*>(o + v * (LPR * 4)) = acc[t][v];
+                    for (int v = 0; v < VPL; ++v) store_row(o + v * (LPR * 4), acc[t][v], store_mode);
                 }
             }
         }
 
         if (!has_next) break;
-        item = nxt;
         s = sn;
-        tl = (int)(item / nSlices);
+        tl = tln;
         k0 = k0n;
         k1 = k1n;
-        nxt = item + stride;
-        has_next = nxt < nItems;
+        sn = s + WX;
+        if (sn >= nSlices) {
+            sn = wl;
+            tln = tl + 1;
+        }
+        has_next = tln < nTiles;
         if (has_next) {
-            sn = (int)(nxt % nSlices);
             k0n = kptr[sn];
             k1n = kptr[sn + 1];
         }
@@ -226,7 +241,8 @@ __global__ __launch_bounds__(kThreads) void spmm_hop_vec_kernel(const int32_t* _
                                                                 const float* __restrict__ val,
                                                                 const int32_t* __restrict__ rowid,
                                                                 const float* __restrict__ Xin, float* __restrict__ Xout,
-                                                                int N, int B, int nRowBlocks, int nBTiles, int xcd_map) {
+                                                                int N, int B, int nRowBlocks, int nBTiles, int xcd_map,
+                                                                int store_mode) {
     constexpr int RPB = kThreads / LG;
     constexpr int W = LG * 4;
     __shared__ int32_t s_off[kChunk];  // neighbour row offset in floats (col * W)
@@ -310,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void spmm_hop_vec_kernel(const int32_t* _
         const int64_t orow = (int64_t)rowid[p] * W + li * 4;
 #pragma unroll
         for (int t = 0; t < BT; ++t)
-            if (b0 + t < B) *reinterpret_cast<float4*>(Xout + (int64_t)(b0 + t) * N * W + orow) = acc[t];
+            if (b0 + t < B) store_row(Xout + (int64_t)(b0 + t) * N * W + orow, acc[t], store_mode);
     }
 }
 
@@ -340,11 +356,12 @@ __global__ __launch_bounds__(kThreads) void spmm_hop_generic_kernel(const int32_
 // ------------------------------------------------------------------------------------------------------------------
 int pick_bt(int N, int W, int B, int bl) {
     if (g_tune.spmm_bt == 1 || g_tune.spmm_bt == 2 || g_tune.spmm_bt == 4) return g_tune.spmm_bt;
-    // keep the gather panel of one work item (N*W*4 bytes per batch entry) inside one XCD's 4 MiB L2
+    // Two consecutive batch tiles are live in an XCD's L2 while its waves cross a tile boundary: keep 2 gather panels
+    // (N*W*4 bytes per batch entry each) inside ~3 of the 4 MiB.
     const int64_t panel = (int64_t)N * W * 4 * bl;
     int bt = 1;
-    if (panel * 2 <= (5 << 19) && B >= 16 * bl) bt = 2;
-    if (panel * 4 <= (5 << 19) && B >= 32 * bl) bt = 4;
+    if (panel * 2 * 2 <= (3 << 20) && B >= 16 * bl) bt = 2;
+    if (panel * 4 * 2 <= (3 << 20) && B >= 32 * bl) bt = 4;
     return bt;
 }
 
@@ -354,19 +371,24 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     int bt = pick_bt(N, W, B, BL);
     while (bt * VPL > 8) bt >>= 1;  // bound the register tile
     const int nl = (g_tune.spmm_nl == 4 || g_tune.spmm_nl == 8) ? g_tune.spmm_nl : 8;
-    const int nBTiles = (B + BL * bt - 1) / (BL * bt);
-    const int64_t items = (int64_t)nBTiles * m.n_slices;
+    int nBTiles = (B + BL * bt - 1) / (BL * bt);
+    while (nBTiles < 8 && bt > 1) {  // too few batch tiles to give every XCD one: shrink the register tile first
+        bt >>= 1;
+        nBTiles = (B + BL * bt - 1) / (BL * bt);
+    }
+    // XCD roles: `lanes` batch-tile lanes x `parts` slice partitions (lanes * parts <= 8); spmm_xcd = 0 ignores the XCD
+    // structure (every XCD works on the same tile).
+    const int lanes = !g_tune.spmm_xcd ? 1 : (nBTiles >= 8 ? 8 : nBTiles);
+    const int parts = 8 / lanes;
     const int bpc = g_tune.spmm_blocks_per_cu > 0 ? g_tune.spmm_blocks_per_cu : 6;
-    int64_t nblk = 256 * bpc;  // persistent: 256 CUs x bpc workgroups of 4 waves, a multiple of 8 (XCDs)
-    const int64_t need = ((items + 3) / 4 + 7) / 8 * 8;
-    if (nblk > need) nblk = need;
-    if (nblk < 8) nblk = 8;
-    dim3 grid((unsigned)nblk), block(kThreads);
-    // XCD pinning only when the batch tiles spread evenly over the 8 XCDs (else balance beats locality)
-    const int xcd = (g_tune.spmm_xcd && (nBTiles % 8 == 0 || nBTiles >= 64)) ? 1 : 0;
+    int wavesPerXcd = 32 * bpc * (kThreads / 64);  // 32 CUs per XCD
+    const int sliceShare = (m.n_slices + parts - 1) / parts;
+    if (wavesPerXcd > sliceShare) wavesPerXcd = sliceShare;
+    const int blocksPerXcd = (wavesPerXcd + 3) / 4 > 0 ? (wavesPerXcd + 3) / 4 : 1;
+    dim3 grid((unsigned)(8 * blocksPerXcd)), block(kThreads);
 #define GF_SELL(BTV, NLV)                                                                                               \
     hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, NLV>), grid, block, 0, st, m.sell_kptr, m.sell_ent, m.sell_rowid, \
-                       Xin, Xout, N, B, m.n_slices, nBTiles, xcd)
+                       Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, g_tune.spmm_store)
     if (nl == 8) {
         switch (bt) {
             case 1: GF_SELL(1, 8); break;
@@ -397,7 +419,7 @@ int launch_vec(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B,
     dim3 grid((unsigned)nblk), block(kThreads);
 #define GF_LAUNCH_BT(BTV)                                                                                           \
     hipLaunchKernelGGL((spmm_hop_vec_kernel<LG, BTV>), grid, block, 0, st, m.rowptr, m.col, m.val, m.rowid, Xin, Xout, \
-                       N, B, nRowBlocks, nBTiles, xcd_map)
+                       N, B, nRowBlocks, nBTiles, xcd_map, g_tune.spmm_store)
     switch (bt) {
         case 1: GF_LAUNCH_BT(1); break;
         case 2: GF_LAUNCH_BT(2); break;

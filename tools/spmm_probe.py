@@ -6,12 +6,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-neural-networks_amd")]
 import torch
 from alegnn_amd import SparseGSO, _lib, graphgen
+import ctypes
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+for kv in sys.argv[3:]:                                  # knob=value ... (gf_tune)
+    k, v = kv.split("=")
+    assert _lib.lib().gf_tune(k.encode(), int(v)) == 0, kv
 model, N, B, W = {"cfg2": ("sbm", 10_000, 256, 32), "cfg4": ("er", 100_000, 128, 32)}[name]
 A = (graphgen.sbm if model == "sbm" else graphgen.er)(N, seed=0)
 dev = torch.device("cuda:0")
-plans = SparseGSO([A]).plans(dev) if False else None
 gso = SparseGSO([A]); plans = gso.plans(dev)
 X0 = torch.randn(B, N, W, device=dev); X1 = torch.empty_like(X0)
 L = _lib.lib(); st = torch.cuda.current_stream().cuda_stream
