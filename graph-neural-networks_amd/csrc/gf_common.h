@@ -82,8 +82,7 @@ static inline int gf_num_taps(int E, int K) { return 1 + E * (K - 1); }
 // debugging / tuning knobs (gf_tune): not part of the numerical contract, every setting gives identical results
 struct gf_tuning {
     int spmm_bt = 0;            // 0 = heuristic, else 1 / 2 / 4 batch entries per lane
-    int spmm_nl = 0;            // 0 = default, else 4 / 8 gather loads in flight per lane
-    int spmm_blocks_per_cu = 0; // 0 = default persistent grid (blocks per CU)
+    int spmm_spw = 0;           // 0 = default (2), else 1 / 2 / 4 consecutive slices per wave
     int spmm_generic = 0;       // 1 = force the generic one-thread-per-element kernel
     int spmm_algo = 0;          // 0 = SELL-8 persistent wave kernel, 1 = CSR workgroup-staged kernel (first version)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order

@@ -27,8 +27,7 @@ gf_tuning g_tune;
 extern "C" int gf_tune(const char* key, int32_t value) {
     GF_REQUIRE_ARG(key != nullptr, "gf_tune: key is NULL");
     if (!strcmp(key, "spmm_bt")) g_tune.spmm_bt = value;
-    else if (!strcmp(key, "spmm_nl")) g_tune.spmm_nl = value;
-    else if (!strcmp(key, "spmm_blocks_per_cu")) g_tune.spmm_blocks_per_cu = value;
+    else if (!strcmp(key, "spmm_spw")) g_tune.spmm_spw = value;
     else if (!strcmp(key, "spmm_generic")) g_tune.spmm_generic = value;
     else if (!strcmp(key, "spmm_algo")) g_tune.spmm_algo = value;
     else if (!strcmp(key, "spmm_xcd")) g_tune.spmm_xcd = value;

@@ -8,22 +8,23 @@
 // neighbour, ~10x the algorithmic read); it can only come out of cache, so the design goal is: keep the gather
 // panel L2-resident and keep the vector-memory pipe (64 B/clk/CU) saturated with 128-byte line gathers.
 //
-// Kernel A (default) -- SELL-8, persistent, wave-autonomous:
+// Kernel A (default) -- SELL-8, wave-autonomous, dispatch-ordered:
 //   * the plan stores the degree-sorted rows as SELL-8 slices (8 rows padded to the slice's longest row, entries
-//     k-major).  One wavefront owns one slice: lane = row*8 + sub-lane, 8 sub-lanes x float4 = one 128-byte line per
-//     row per neighbour (W = 32); W = 64..256 -> several float4 per lane, W < 32 -> spare sub-lanes take more batch
-//     entries.  All 8 rows of a slice walk the same (wave-uniform) number of neighbours: no divergence, static
-//     software pipelining, and exact s_waitcnt counts.
+//     k-major).  One wavefront owns one slice at a time: lane = row*8 + sub-lane, 8 sub-lanes x float4 = one 128-byte
+//     line per row per neighbour (W = 32); W = 64..256 -> several float4 per lane, W < 32 -> spare sub-lanes take more
+//     batch entries.  All 8 rows of a slice walk the same (wave-uniform) number of neighbours: no divergence, and all
+//     of a slice's gathers (up to 16 per lane) are issued before the first FMA -- one memory round trip per slice.
 //   * the slice's (col, val) stream is staged through a per-wave LDS ring (coalesced 512-byte reads, then broadcast
-//     ds_read_b64 per neighbour): index traffic stays off the vector-memory return path that the gathers need.
-//     The NEXT slice's entries are loaded while the current slice is gathered -> a wave never sits in a start-up
-//     latency chain (rowptr -> col/val -> gather), and no workgroup barrier exists at all.
-//   * waves are persistent and walk work items (batch tile, slice) in an XCD-aware order: workgroup L runs on XCD
-//     L%8 (observed dispatch order; a wrong guess costs speed, never correctness), batch tile t is pinned to XCD t%8
-//     and every wave of that XCD sweeps the slices of the same batch tile together -> the N*W*4*BT-byte gather
-//     panel is shared through ONE 4 MiB L2 instead of being replicated in eight.
+//     ds_read_b64 per neighbour): index traffic stays off the vector-memory return path that the gathers need, and the
+//     next slice's entries are fetched while the current slice is gathered.  No workgroup barrier exists at all.
+//   * blockIdx -> (XCD role, batch tile, slice group) follows the hardware dispatch order: workgroup L runs on XCD L%8
+//     (observed; a wrong guess costs speed, never correctness), batch tile t is pinned to XCD t%8 and the dispatcher
+//     hands an XCD its tiles strictly in order, so at most ~2 gather panels (N*W*4*BT bytes each) are live in that
+//     XCD's 4 MiB L2.  (A persistent variant with statically strided waves was measured and rejected: waves drift apart
+//     by many tiles, 30 % L2 hits vs 76 % -- profiles/r01_c_l2_residency.)  Output rows are stored write-through (sc1)
+//     so they do not evict the panel.
 //   * each (row, batch entry) sum runs over the row's entries in ascending column order in one lane group: fixed
-//     summation order, no atomics -> bitwise deterministic.  (Padding entries are {col 0, val 0}: they add +0.)
+//     summation order, no atomics -> bitwise deterministic.
 // Kernel B -- CSR, one workgroup per 256/LG rows with its segment staged in LDS (the first version; kept for A/B).
 // Kernel C -- generic: any W (G = 1, odd widths), one thread per output element.
 #include <stdlib.h>
@@ -65,17 +66,17 @@ __device__ __forceinline__ void store_row(float* p, const float4& v, int mode) {
 // Kernel A
 //   LPR = sub-lanes per row (1, 2, 4, 8), VPL = float4 per lane per neighbour, W = 4 * LPR * VPL
 //   BL  = 8 / LPR batch entries side by side in one wave, BT = batch entries per lane (register tile)
-//   NL  = gather instructions in flight per lane per pipeline step (U = NL / (BT * VPL) neighbours)
+//   SPW = consecutive slices one wave walks (the second slice's entries are fetched while the first is gathered)
 // ------------------------------------------------------------------------------------------------------------------
-template <int LPR, int VPL, int BT, int NL>
+template <int LPR, int VPL, int BT, int SPW>
 __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __restrict__ kptr, const int2* __restrict__ ent,
                                                              const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
                                                              float* __restrict__ Xout, int N, int B, int nSlices, int nBTiles,
-                                                             int lanes, int parts, int store_mode) {
+                                                             int lanes, int parts, int blocksPerTile, int store_mode) {
     constexpr int BL = 8 / LPR;
     constexpr int W = 4 * LPR * VPL;
-    constexpr int BTW = BL * BT;  // batch entries per work item
-    constexpr int U = (NL / (BT * VPL)) > 0 ? (NL / (BT * VPL)) : 1;
+    constexpr int BTW = BL * BT;  // batch entries per tile
+    constexpr int UMAX = (16 / (BT * VPL)) > 0 ? (16 / (BT * VPL)) : 1;  // neighbours whose gathers are in flight together
     __shared__ int2 s_ent[kThreads / 64][2][kCK * 8];
 
     const int lane = threadIdx.x & 63;
@@ -83,17 +84,20 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
     const int r = lane >> 3, sub = lane & 7;
     const int bl = sub / LPR, li = sub - bl * LPR;
 
-    // ---- persistent work distribution ----------------------------------------------------------------------------------
-    // XCD x = blockIdx % 8 serves batch-tile lane x % lanes (tiles lane, lane + lanes, ... strictly in order) and slice
-    // partition x / lanes of `parts`; its waves stride over that partition's slices.  lanes * parts <= 8.
-    const int xcd = blockIdx.x & 7;
+    // ---- work assignment, in HARDWARE DISPATCH ORDER -----------------------------------------------------------------
+    // workgroup L runs on XCD L % 8 (observed; a wrong guess costs speed only).  XCD x serves batch-tile lane x % lanes
+    // (tiles lane, lane + lanes, ... in dispatch order, so an XCD has at most ~2 gather panels live in its L2 at a time)
+    // and slice partition x / lanes of `parts`.  lanes * parts <= 8.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int lane_t = xcd % lanes, part = xcd / lanes;
-    if (part >= parts) return;  // wave-uniform; there are no workgroup barriers in this kernel
-    const int nTiles = (nBTiles > lane_t) ? (nBTiles - lane_t + lanes - 1) / lanes : 0;
-    const int WX = (gridDim.x >> 3) * (kThreads / 64) * parts;
-    const int wl = ((blockIdx.x >> 3) * (kThreads / 64) + wave) * parts + part;
-    const int bt_first = lane_t, bt_step = lanes;
-    if (wl >= nSlices || nTiles == 0) return;
+    if (part >= parts) return;  // all exits are wave-uniform; this kernel has no workgroup barrier
+    const int tl = slot / blocksPerTile, blk = slot - tl * blocksPerTile;
+    const int tile = lane_t + tl * lanes;
+    if (tile >= nBTiles) return;
+    const int nSlP = (nSlices - part + parts - 1) / parts;  // slices of this partition: part, part + parts, ...
+    const int i0 = (blk * (kThreads / 64) + wave) * SPW;
+    if (i0 >= nSlP) return;
+    const int ns = min(SPW, nSlP - i0);
 
     int2* ring0 = &s_ent[wave][0][0];
     int2* ring1 = &s_ent[wave][1][0];
@@ -114,32 +118,26 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
         for (int j = 0; j < 4; ++j) dst[j * 64 + lane] = pre[j];
     };
 
-    int s = wl, tl = 0;
+    const int b0 = tile * BTW;
+    const float* xb[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) {
+        const int b = min(b0 + t * BL + bl, B - 1);  // clamp loads of a ragged last tile; stores are masked
+        xb[t] = Xin + (int64_t)b * N * W + li * 4;
+    }
+
+    int s = part + parts * i0;
     int k0 = kptr[s], k1 = kptr[s + 1];
     issue_entries(k0, min(k1, k0 + kCK));
     commit_entries(ring0);
     int cur = 0;
 
-    // successor of (tl, s): next slice of the same tile, else this wave's first slice of the next tile
-    int sn = s + WX, tln = tl;
-    if (sn >= nSlices) {
-        sn = wl;
-        tln = tl + 1;
-    }
-    bool has_next = tln < nTiles;
-    int k0n = 0, k1n = 0;
-    if (has_next) {
-        k0n = kptr[sn];
-        k1n = kptr[sn + 1];
-    }
-
-    for (;;) {
-        const int b0 = (bt_first + tl * bt_step) * BTW;
-        const float* xb[BT];
-#pragma unroll
-        for (int t = 0; t < BT; ++t) {
-            const int b = min(b0 + t * BL + bl, B - 1);  // clamp loads of a ragged last tile; stores are masked
-            xb[t] = Xin + (int64_t)b * N * W + li * 4;
+    for (int j = 0; j < ns; ++j) {
+        const bool has_next = j + 1 < ns;
+        int k0n = 0, k1n = 0;
+        if (has_next) {
+            k0n = kptr[s + parts];
+            k1n = kptr[s + parts + 1];
         }
         const int orow = rowid[s * 8 + r];  // -1 past the last row; issued early, consumed at the store
         float4 acc[BT][VPL];
@@ -150,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
 
         for (int kc = k0;;) {  // ring slots of this slice (one for ordinary rows, many for hub rows)
             const int kend = min(k1, kc + kCK);
-            // -- prefetch the next ring slot: same slice's next chunk, or the next work item's first chunk
+            // -- prefetch the next ring slot: this slice's next chunk, or the next slice's first chunk
             bool fetch = true;
             if (kend < k1)
                 issue_entries(kend, min(k1, kend + kCK));
@@ -159,41 +157,34 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
             else
                 fetch = false;
 
-            // -- gather + accumulate the nk neighbours staged in the current slot
+            // -- gather + accumulate the nk neighbours staged in the current slot, UMAX neighbours at a time: all their
+            //    gathers are issued before the first FMA (cnt is wave-uniform: scalar branches, exact counts, no padding)
             const int2* eb = (cur ? ring1 : ring0) + r;
             const int nk = kend - kc;
-            int k = 0;
-            for (; k + U <= nk; k += U) {
-                int2 e[U];
+            for (int k = 0; k < nk; k += UMAX) {
+                const int cnt = min(UMAX, nk - k);
+                float4 x[UMAX][BT][VPL];
+                float vals[UMAX];
 #pragma unroll
-                for (int u = 0; u < U; ++u) e[u] = eb[(k + u) * 8];
-                float4 x[U][BT][VPL];
+                for (int u = 0; u < UMAX; ++u)
+                    if (u < cnt) {
+                        const int2 e = eb[(k + u) * 8];
+                        vals[u] = __int_as_float(e.y);
+                        const unsigned off = __umul24((unsigned)e.x, (unsigned)W);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const unsigned off = __umul24((unsigned)e[u].x, (unsigned)W);
+                        for (int t = 0; t < BT; ++t)
 #pragma unroll
-                    for (int t = 0; t < BT; ++t)
+                            for (int v = 0; v < VPL; ++v)
+                                x[u][t][v] = *reinterpret_cast<const float4*>(xb[t] + off + v * (LPR * 4));
+                    }
 #pragma unroll
-                        for (int v = 0; v < VPL; ++v) x[u][t][v] = *reinterpret_cast<const float4*>(xb[t] + off + v * (LPR * 4));
-                }
+                for (int u = 0; u < UMAX; ++u)  // ascending k: fixed summation order
+                    if (u < cnt) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {  // ascending k: fixed summation order
-                    const float val = __int_as_float(e[u].y);
+                        for (int t = 0; t < BT; ++t)
 #pragma unroll
-                    for (int t = 0; t < BT; ++t)
-#pragma unroll
-                        for (int v = 0; v < VPL; ++v) fma4(acc[t][v], val, x[u][t][v]);
-                }
-            }
-            for (; k < nk; ++k) {
-                const int2 e = eb[k * 8];
-                const unsigned off = __umul24((unsigned)e.x, (unsigned)W);
-                const float val = __int_as_float(e.y);
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int v = 0; v < VPL; ++v)
-                        fma4(acc[t][v], val, *reinterpret_cast<const float4*>(xb[t] + off + v * (LPR * 4)));
+                            for (int v = 0; v < VPL; ++v) fma4(acc[t][v], vals[u], x[u][t][v]);
+                    }
             }
 
             if (fetch) commit_entries(cur ? ring0 : ring1);  // LDS ops of one wave execute in order: no barrier needed
@@ -213,22 +204,9 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
                 }
             }
         }
-
-        if (!has_next) break;
-        s = sn;
-        tl = tln;
+        s += parts;
         k0 = k0n;
         k1 = k1n;
-        sn = s + WX;
-        if (sn >= nSlices) {
-            sn = wl;
-            tln = tl + 1;
-        }
-        has_next = tln < nTiles;
-        if (has_next) {
-            k0n = kptr[sn];
-            k1n = kptr[sn + 1];
-        }
     }
 }
 
@@ -370,7 +348,6 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     constexpr int BL = 8 / LPR, W = 4 * LPR * VPL;
     int bt = pick_bt(N, W, B, BL);
     while (bt * VPL > 8) bt >>= 1;  // bound the register tile
-    const int nl = (g_tune.spmm_nl == 4 || g_tune.spmm_nl == 8) ? g_tune.spmm_nl : 8;
     int nBTiles = (B + BL * bt - 1) / (BL * bt);
     while (nBTiles < 8 && bt > 1) {  // too few batch tiles to give every XCD one: shrink the register tile first
         bt >>= 1;
@@ -380,28 +357,28 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     // structure (every XCD works on the same tile).
     const int lanes = !g_tune.spmm_xcd ? 1 : (nBTiles >= 8 ? 8 : nBTiles);
     const int parts = 8 / lanes;
-    const int bpc = g_tune.spmm_blocks_per_cu > 0 ? g_tune.spmm_blocks_per_cu : 6;
-    int wavesPerXcd = 32 * bpc * (kThreads / 64);  // 32 CUs per XCD
+    const int spw = (g_tune.spmm_spw == 1 || g_tune.spmm_spw == 2 || g_tune.spmm_spw == 4) ? g_tune.spmm_spw : 2;
     const int sliceShare = (m.n_slices + parts - 1) / parts;
-    if (wavesPerXcd > sliceShare) wavesPerXcd = sliceShare;
-    const int blocksPerXcd = (wavesPerXcd + 3) / 4 > 0 ? (wavesPerXcd + 3) / 4 : 1;
-    dim3 grid((unsigned)(8 * blocksPerXcd)), block(kThreads);
-#define GF_SELL(BTV, NLV)                                                                                               \
-    hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, NLV>), grid, block, 0, st, m.sell_kptr, m.sell_ent, m.sell_rowid, \
-                       Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, g_tune.spmm_store)
-    if (nl == 8) {
-        switch (bt) {
-            case 1: GF_SELL(1, 8); break;
-            case 2: GF_SELL(2, 8); break;
-            default: GF_SELL(4, 8); break;
-        }
-    } else {
-        switch (bt) {
-            case 1: GF_SELL(1, 4); break;
-            case 2: GF_SELL(2, 4); break;
-            default: GF_SELL(4, 4); break;
-        }
+    const int blocksPerTile = (sliceShare + 4 * spw - 1) / (4 * spw);
+    const int tilesPerLane = (nBTiles + lanes - 1) / lanes;
+    const int64_t nblk = (int64_t)8 * tilesPerLane * blocksPerTile;
+    GF_REQUIRE_SHAPE(nblk < (int64_t)INT32_MAX, "gf_spmm_hop: grid of %lld blocks too large", (long long)nblk);
+    dim3 grid((unsigned)nblk), block(kThreads);
+#define GF_SELL(BTV, SPWV)                                                                                               \
+    hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV>), grid, block, 0, st, m.sell_kptr, m.sell_ent, m.sell_rowid, \
+                       Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store)
+#define GF_SELL_BT(SPWV)             \
+    switch (bt) {                    \
+        case 1: GF_SELL(1, SPWV); break; \
+        case 2: GF_SELL(2, SPWV); break; \
+        default: GF_SELL(4, SPWV); break; \
     }
+    switch (spw) {
+        case 1: GF_SELL_BT(1); break;
+        case 2: GF_SELL_BT(2); break;
+        default: GF_SELL_BT(4); break;
+    }
+#undef GF_SELL_BT
 #undef GF_SELL
     GF_LAUNCH_CHECK("spmm_sell_kernel");
     return GF_OK;
