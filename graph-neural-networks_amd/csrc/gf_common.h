@@ -86,6 +86,7 @@ struct gf_tuning {
     int spmm_generic = 0;       // 1 = force the generic one-thread-per-element kernel
     int spmm_algo = 0;          // 0 = SELL-8 persistent wave kernel, 1 = CSR workgroup-staged kernel (first version)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
+    int spmm_load = 0;          // gather loads: 0 = plain, 1 = non-temporal
     int spmm_store = 1;         // output rows: 0 = plain stores, 1 = write-through (sc1), 2 = non-temporal
     int contract_generic = 0;   // 1 = force the generic contraction kernel
 };

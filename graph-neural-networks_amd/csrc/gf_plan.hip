@@ -32,6 +32,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_algo")) g_tune.spmm_algo = value;
     else if (!strcmp(key, "spmm_xcd")) g_tune.spmm_xcd = value;
     else if (!strcmp(key, "spmm_store")) g_tune.spmm_store = value;
+    else if (!strcmp(key, "spmm_load")) g_tune.spmm_load = value;
     else if (!strcmp(key, "contract_generic")) g_tune.contract_generic = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);

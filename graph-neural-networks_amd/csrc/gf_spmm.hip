@@ -62,13 +62,24 @@ __device__ __forceinline__ void store_row(float* p, const float4& v, int mode) {
     }
 }
 
+// gather load of one float4: NTL = 1 adds the non-temporal hint (the line is not kept in the CU's L1 -- a gathered
+// line is never reused by the same CU, so caching it only costs L1 fill bandwidth).
+template <int NTL>
+__device__ __forceinline__ float4 load_row(const float* p) {
+    if (NTL) {
+        const f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        return make_float4(d.x, d.y, d.z, d.w);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Kernel A
 //   LPR = sub-lanes per row (1, 2, 4, 8), VPL = float4 per lane per neighbour, W = 4 * LPR * VPL
 //   BL  = 8 / LPR batch entries side by side in one wave, BT = batch entries per lane (register tile)
 //   SPW = consecutive slices one wave walks (the second slice's entries are fetched while the first is gathered)
 // ------------------------------------------------------------------------------------------------------------------
-template <int LPR, int VPL, int BT, int SPW>
+template <int LPR, int VPL, int BT, int SPW, int NTL>
 __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __restrict__ kptr, const int2* __restrict__ ent,
                                                              const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
                                                              float* __restrict__ Xout, int N, int B, int nSlices, int nBTiles,
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
                         for (int t = 0; t < BT; ++t)
 #pragma unroll
                             for (int v = 0; v < VPL; ++v)
-                                x[u][t][v] = *reinterpret_cast<const float4*>(xb[t] + off + v * (LPR * 4));
+                                x[u][t][v] = load_row<NTL>(xb[t] + off + v * (LPR * 4));
                     }
 #pragma unroll
                 for (int u = 0; u < UMAX; ++u)  // ascending k: fixed summation order
@@ -364,9 +375,13 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     const int64_t nblk = (int64_t)8 * tilesPerLane * blocksPerTile;
     GF_REQUIRE_SHAPE(nblk < (int64_t)INT32_MAX, "gf_spmm_hop: grid of %lld blocks too large", (long long)nblk);
     dim3 grid((unsigned)nblk), block(kThreads);
-#define GF_SELL(BTV, SPWV)                                                                                               \
-    hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV>), grid, block, 0, st, m.sell_kptr, m.sell_ent, m.sell_rowid, \
-                       Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store)
+#define GF_SELL(BTV, SPWV)                                                                                                  \
+    if (g_tune.spmm_load)                                                                                                   \
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 1>), grid, block, 0, st, m.sell_kptr, m.sell_ent,         \
+                           m.sell_rowid, Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store); \
+    else                                                                                                                    \
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0>), grid, block, 0, st, m.sell_kptr, m.sell_ent,         \
+                           m.sell_rowid, Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store)
 #define GF_SELL_BT(SPWV)             \
     switch (bt) {                    \
         case 1: GF_SELL(1, SPWV); break; \
