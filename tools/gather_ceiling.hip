@@ -1,0 +1,67 @@
+// gather_ceiling.hip -- how fast can gfx950 serve random full-line (128 B) gathers out of an L2-resident panel?
+// Standalone microbenchmark (hipcc --offload-arch=gfx950 tools/gather_ceiling.hip -o tools/gather_ceiling).
+// Each 8-lane group loads one 128-byte row (float4 per lane) at a pseudo-random row of a panel; NLOAD loads are in
+// flight per lane; block b uses panel b % 8 (one panel per XCD, as the SpMM tile mapping does).  No stores except one
+// sink per thread, no LDS, no index traffic: an upper bound for the SpMM hop's gather stream.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int MODE, int NLOAD>
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ X, int rows_mask, long panel_floats, int iters,
+                                                      float* __restrict__ sink) {
+    const int li = threadIdx.x & 7;
+    const unsigned gid = (blockIdx.x * 256 + threadIdx.x) >> 3;
+    const float* P = X + (long)(blockIdx.x & 7) * panel_floats + li * 4;
+    unsigned h = gid * 2654435761u + 12345u;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        f32x4 v[NLOAD];
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) {
+            h = h * 1664525u + 1013904223u;
+            const unsigned row = (h >> 8) & rows_mask;
+            const f32x4* p = reinterpret_cast<const f32x4*>(P + (long)row * 32);
+            if (MODE == 1) v[u] = __builtin_nontemporal_load(p);
+            else v[u] = *p;
+        }
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) acc += v[u];
+    }
+    if (acc.x == 123.456f) sink[0] = acc.y + acc.z + acc.w;
+}
+
+template <int MODE, int NLOAD>
+void run(const char* label, const float* X, int rows, long panel_floats, int blocks, float* sink) {
+    const int iters = 64;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    gather_kernel<MODE, NLOAD><<<blocks, 256>>>(X, rows - 1, panel_floats, iters, sink);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) gather_kernel<MODE, NLOAD><<<blocks, 256>>>(X, rows - 1, panel_floats, iters, sink);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    const double bytes = (double)blocks * 32 * iters * NLOAD * 128.0;
+    printf("  %-28s panel %7.2f MB  blocks %6d  %8.1f us  %8.1f GB/s gathered\n", label, rows * 128.0 / 1e6, blocks, ms * 1e3, bytes / ms / 1e6);
+}
+
+int main() {
+    const int sizes[] = {8192, 16384, 32768, 131072};   // rows per panel: 1, 2, 4, 16 MB
+    for (int rows : sizes) {
+        const long pf = (long)rows * 32;
+        float* X; float* sink;
+        CK(hipMalloc(&X, pf * 8 * sizeof(float))); CK(hipMalloc(&sink, 64));
+        CK(hipMemset(X, 0, pf * 8 * sizeof(float)));
+        for (int blocks : {2048, 4096, 8192}) {
+            run<0, 4>("plain  4 in flight", X, rows, pf, blocks, sink);
+            run<0, 8>("plain  8 in flight", X, rows, pf, blocks, sink);
+            run<0, 16>("plain 16 in flight", X, rows, pf, blocks, sink);
+            run<1, 8>("nt     8 in flight", X, rows, pf, blocks, sink);
+            run<1, 16>("nt    16 in flight", X, rows, pf, blocks, sink);
+        }
+        CK(hipFree(X)); CK(hipFree(sink));
+    }
+    return 0;
+}

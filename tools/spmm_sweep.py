@@ -31,15 +31,13 @@ for name in (sys.argv[1:] or ["cfg2", "cfg4"]):
     nbytes = 2 * B * N * W * 4 + A.nnz * 8 + (N + 1) * 4
     print(f"== {name}: N={N} nnz={A.nnz} B={B} W={W}  algorithmic MB/hop={nbytes/1e6:.1f}  roof@8TB/s={nbytes/8e12*1e6:.1f} us")
     rows = []
-    for bt, store in itertools.product((1, 2), (0, 1)):
+    for bt, store in itertools.product((1, 2), (1,)):
         tune(spmm_algo=1, spmm_bt=bt, spmm_xcd=1, spmm_store=store)
         rows.append((time_hop(plans[0], X0, X1, B, W), f"algo=csr  bt={bt} store={store}"))
-    for bt, spw, store in itertools.product((1, 2, 4), (1, 2, 4), (0, 1, 2)):
-        tune(spmm_algo=0, spmm_bt=bt, spmm_spw=spw, spmm_xcd=1, spmm_store=store)
-        rows.append((time_hop(plans[0], X0, X1, B, W), f"algo=sell bt={bt} spw={spw} store={store}"))
-    tune(spmm_algo=0, spmm_bt=1, spmm_spw=2, spmm_xcd=0, spmm_store=1)
-    rows.append((time_hop(plans[0], X0, X1, B, W), "algo=sell bt=1 spw=2 store=1 xcd=0"))
-    tune(spmm_algo=0, spmm_bt=0, spmm_spw=0, spmm_xcd=1, spmm_store=1)
+    for bt, spw, store, ld in itertools.product((1, 2, 4), (1, 2), (1, 2), (0, 1)):
+        tune(spmm_algo=0, spmm_bt=bt, spmm_spw=spw, spmm_xcd=1, spmm_store=store, spmm_load=ld)
+        rows.append((time_hop(plans[0], X0, X1, B, W), f"algo=sell bt={bt} spw={spw} store={store} load={ld}"))
+    tune(spmm_algo=0, spmm_bt=0, spmm_spw=0, spmm_xcd=1, spmm_store=1, spmm_load=0)
     rows.append((time_hop(plans[0], X0, X1, B, W), "DEFAULT (heuristics)"))
     for ms, label in sorted(rows):
         print(f"  {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s  {100*nbytes/ms/1e6/8000:5.1f}%  {label}")
