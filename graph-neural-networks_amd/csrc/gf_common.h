@@ -86,6 +86,8 @@ struct gf_tuning {
     int spmm_generic = 0;       // 1 = force the generic one-thread-per-element kernel
     int spmm_algo = 0;          // 0 = SELL-8 persistent wave kernel, 1 = CSR workgroup-staged kernel (first version)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
+    int spmm_ucap = 0;          // 0/16 = up to 16 gathers in flight per lane, 8 = up to 8 (fewer registers, more waves)
+    int spmm_pf = 0;            // workgroups per tile that prefetch the next tile's gather panel into L2 (0 = off)
     int spmm_load = 0;          // gather loads: 0 = plain, 1 = non-temporal
     int spmm_store = 1;         // output rows: 0 = plain stores, 1 = write-through (sc1), 2 = non-temporal
     int contract_generic = 0;   // 1 = force the generic contraction kernel

@@ -33,6 +33,8 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_xcd")) g_tune.spmm_xcd = value;
     else if (!strcmp(key, "spmm_store")) g_tune.spmm_store = value;
     else if (!strcmp(key, "spmm_load")) g_tune.spmm_load = value;
+    else if (!strcmp(key, "spmm_pf")) g_tune.spmm_pf = value;
+    else if (!strcmp(key, "spmm_ucap")) g_tune.spmm_ucap = value;
     else if (!strcmp(key, "contract_generic")) g_tune.contract_generic = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);

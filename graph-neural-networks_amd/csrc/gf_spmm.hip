@@ -79,15 +79,15 @@ __device__ __forceinline__ float4 load_row(const float* p) {
 //   BL  = 8 / LPR batch entries side by side in one wave, BT = batch entries per lane (register tile)
 //   SPW = consecutive slices one wave walks (the second slice's entries are fetched while the first is gathered)
 // ------------------------------------------------------------------------------------------------------------------
-template <int LPR, int VPL, int BT, int SPW, int NTL>
+template <int LPR, int VPL, int BT, int SPW, int NTL, int UCAP>
 __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __restrict__ kptr, const int2* __restrict__ ent,
                                                              const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
                                                              float* __restrict__ Xout, int N, int B, int nSlices, int nBTiles,
-                                                             int lanes, int parts, int blocksPerTile, int store_mode) {
+                                                             int lanes, int parts, int blocksPerTile, int store_mode, int pf_blocks) {
     constexpr int BL = 8 / LPR;
     constexpr int W = 4 * LPR * VPL;
     constexpr int BTW = BL * BT;  // batch entries per tile
-    constexpr int UMAX = (16 / (BT * VPL)) > 0 ? (16 / (BT * VPL)) : 1;  // neighbours whose gathers are in flight together
+    constexpr int UMAX = (UCAP / (BT * VPL)) > 0 ? (UCAP / (BT * VPL)) : 1;  // neighbours whose gathers are in flight together
     __shared__ int2 s_ent[kThreads / 64][2][kCK * 8];
 
     const int lane = threadIdx.x & 63;
@@ -102,9 +102,36 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int lane_t = xcd % lanes, part = xcd / lanes;
     if (part >= parts) return;  // all exits are wave-uniform; this kernel has no workgroup barrier
-    const int tl = slot / blocksPerTile, blk = slot - tl * blocksPerTile;
+    const int tl = slot / blocksPerTile;
+    int blk = slot - tl * blocksPerTile;
     const int tile = lane_t + tl * lanes;
     if (tile >= nBTiles) return;
+    if (blk < pf_blocks) {
+        // ---- prefetch role: the first pf_blocks workgroups of every tile stream the NEXT tile's gather panel into this
+        // XCD's L2 with sequential full-line reads, so the gathers of that tile hit L2 instead of waiting out HBM latency
+        // on a demand miss (every vmcnt(0) batch of ~100 random lines contained at least one).  Part 0 only.
+        const int ntile = tile + lanes;
+        if (part != 0 || ntile >= nBTiles) return;
+        const int nb0 = ntile * BTW;
+        const int nb = min(BTW, B - nb0);
+        const int64_t n4 = (int64_t)nb * N * W / 4;  // float4 count of the panel (batch entries of a tile are contiguous)
+        const f32x4* src = reinterpret_cast<const f32x4*>(Xin + (int64_t)nb0 * N * W);
+        f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+        const int64_t step = (int64_t)pf_blocks * kThreads;
+        for (int64_t i = (int64_t)blk * kThreads + threadIdx.x; i < n4; i += step * 16) {
+            f32x4 v[16];  // 16 independent 16-byte loads per lane in flight: 64 KB per workgroup per round
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int64_t j = i + (int64_t)u * step;
+                v[u] = (j < n4) ? src[j] : sink;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sink += v[u];
+        }
+        if (sink.x == 1.2345e30f && sink.y == -7.0f) Xout[0] = sink.z + sink.w;  // keeps the loads alive; never true in practice
+        return;
+    }
+    blk -= pf_blocks;
     const int nSlP = (nSlices - part + parts - 1) / parts;  // slices of this partition: part, part + parts, ...
     const int i0 = (blk * (kThreads / 64) + wave) * SPW;
     if (i0 >= nSlP) return;
@@ -174,14 +201,16 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
             const int nk = kend - kc;
             for (int k = 0; k < nk; k += UMAX) {
                 const int cnt = min(UMAX, nk - k);
+                // all of the chunk's (col, val) pairs first -- unconditional, back-to-back broadcast reads and ONE lgkmcnt wait
+                // (the slot is always fully written, zero-padded), then the gathers, each behind a scalar branch
+                int2 e[UMAX];
+#pragma unroll
+                for (int u = 0; u < UMAX; ++u) e[u] = eb[(k + u) * 8];
                 float4 x[UMAX][BT][VPL];
-                float vals[UMAX];
 #pragma unroll
                 for (int u = 0; u < UMAX; ++u)
                     if (u < cnt) {
-                        const int2 e = eb[(k + u) * 8];
-                        vals[u] = __int_as_float(e.y);
-                        const unsigned off = __umul24((unsigned)e.x, (unsigned)W);
+                        const unsigned off = __umul24((unsigned)e[u].x, (unsigned)W);
 #pragma unroll
                         for (int t = 0; t < BT; ++t)
 #pragma unroll
@@ -191,10 +220,11 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
 #pragma unroll
                 for (int u = 0; u < UMAX; ++u)  // ascending k: fixed summation order
                     if (u < cnt) {
+                        const float val = __int_as_float(e[u].y);
 #pragma unroll
                         for (int t = 0; t < BT; ++t)
 #pragma unroll
-                            for (int v = 0; v < VPL; ++v) fma4(acc[t][v], vals[u], x[u][t][v]);
+                            for (int v = 0; v < VPL; ++v) fma4(acc[t][v], val, x[u][t][v]);
                     }
             }
 
@@ -354,6 +384,8 @@ int pick_bt(int N, int W, int B, int bl) {
     return bt;
 }
 
+static inline int tilesPerLaneOf(int nBTiles, int lanes) { return (nBTiles + lanes - 1) / lanes; }
+
 template <int LPR, int VPL>
 int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st) {
     constexpr int BL = 8 / LPR, W = 4 * LPR * VPL;
@@ -370,18 +402,20 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     const int parts = 8 / lanes;
     const int spw = (g_tune.spmm_spw == 1 || g_tune.spmm_spw == 2 || g_tune.spmm_spw == 4) ? g_tune.spmm_spw : 2;
     const int sliceShare = (m.n_slices + parts - 1) / parts;
-    const int blocksPerTile = (sliceShare + 4 * spw - 1) / (4 * spw);
+    const int pf = (g_tune.spmm_pf >= 0 && tilesPerLaneOf(nBTiles, lanes) > 1) ? g_tune.spmm_pf : 0;
+    const int blocksPerTile = (sliceShare + 4 * spw - 1) / (4 * spw) + pf;
     const int tilesPerLane = (nBTiles + lanes - 1) / lanes;
     const int64_t nblk = (int64_t)8 * tilesPerLane * blocksPerTile;
     GF_REQUIRE_SHAPE(nblk < (int64_t)INT32_MAX, "gf_spmm_hop: grid of %lld blocks too large", (long long)nblk);
     dim3 grid((unsigned)nblk), block(kThreads);
-#define GF_SELL(BTV, SPWV)                                                                                                  \
-    if (g_tune.spmm_load)                                                                                                   \
-        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 1>), grid, block, 0, st, m.sell_kptr, m.sell_ent,         \
-                           m.sell_rowid, Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store); \
-    else                                                                                                                    \
-        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0>), grid, block, 0, st, m.sell_kptr, m.sell_ent,         \
-                           m.sell_rowid, Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store)
+#define GF_SELL_ARGS m.sell_kptr, m.sell_ent, m.sell_rowid, Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store, pf
+#define GF_SELL(BTV, SPWV)                                                                                          \
+    if (g_tune.spmm_load)                                                                                           \
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 1, 16>), grid, block, 0, st, GF_SELL_ARGS);       \
+    else if (g_tune.spmm_ucap == 8)                                                                                 \
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0, 8>), grid, block, 0, st, GF_SELL_ARGS);        \
+    else                                                                                                            \
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0, 16>), grid, block, 0, st, GF_SELL_ARGS)
 #define GF_SELL_BT(SPWV)             \
     switch (bt) {                    \
         case 1: GF_SELL(1, SPWV); break; \
@@ -395,6 +429,7 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     }
 #undef GF_SELL_BT
 #undef GF_SELL
+#undef GF_SELL_ARGS
     GF_LAUNCH_CHECK("spmm_sell_kernel");
     return GF_OK;
 }

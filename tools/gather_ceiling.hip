@@ -34,6 +34,45 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ X
     if (acc.x == 123.456f) sink[0] = acc.y + acc.z + acc.w;
 }
 
+// short-lived variant: what the hop kernel's waves look like -- ITERS rounds of NLOAD gathers, then ONE 128-byte row store
+template <int NLOAD, int ITERS, int DEP>
+__global__ __launch_bounds__(256) void gather_short_kernel(const float* __restrict__ X, int rows_mask, long panel_floats,
+                                                            const int* __restrict__ idx, float* __restrict__ out) {
+    const int li = threadIdx.x & 7;
+    const unsigned gid = (blockIdx.x * 256 + threadIdx.x) >> 3;
+    const float* P = X + (long)(blockIdx.x & 7) * panel_floats + li * 4;
+    unsigned h = gid * 2654435761u + 12345u;
+    if (DEP) h += idx[gid & 1023];   // a dependent index load in front of the first gather (like kptr -> entries -> gather)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        f32x4 v[NLOAD];
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) {
+            h = h * 1664525u + 1013904223u;
+            const unsigned row = (h >> 8) & rows_mask;
+            v[u] = *reinterpret_cast<const f32x4*>(P + (long)row * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) acc += v[u];
+    }
+    *reinterpret_cast<f32x4*>(out + ((long)gid * 32 + li * 4)) = acc;
+}
+
+template <int NLOAD, int ITERS, int DEP>
+void run_short(const float* X, int rows, long panel_floats, long groups, const int* idx, float* out) {
+    const int blocks = (int)(groups / 32);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    gather_short_kernel<NLOAD, ITERS, DEP><<<blocks, 256>>>(X, rows - 1, panel_floats, idx, out);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) gather_short_kernel<NLOAD, ITERS, DEP><<<blocks, 256>>>(X, rows - 1, panel_floats, idx, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    const double bytes = (double)groups * ITERS * NLOAD * 128.0;
+    printf("  short-lived: %2d x %2d gathers + 1 row store per lane group, dep=%d, %7ld groups (%6d blocks)  %8.1f us  %8.1f GB/s gathered\n",
+           ITERS, NLOAD, DEP, groups, blocks, ms * 1e3, bytes / ms / 1e6);
+}
+
 template <int MODE, int NLOAD>
 void run(const char* label, const float* X, int rows, long panel_floats, int blocks, float* sink) {
     const int iters = 64;
@@ -48,13 +87,29 @@ void run(const char* label, const float* X, int rows, long panel_floats, int blo
 }
 
 int main() {
+    {   // the cfg2 hop has 2.56M (row, batch entry) pairs of ~10 gathers each: same amount of work in different wave shapes
+        const int rows = 8192; const long pf = (long)rows * 32; const long groups = 2560000 / 32 * 32;
+        float *X, *out; int* idx;
+        CK(hipMalloc(&X, pf * 8 * sizeof(float))); CK(hipMalloc(&out, groups * 128)); CK(hipMalloc(&idx, 4096));
+        CK(hipMemset(X, 0, pf * 8 * sizeof(float))); CK(hipMemset(idx, 0, 4096));
+        run_short<12, 1, 0>(X, rows, pf, groups, idx, out);
+        run_short<12, 1, 1>(X, rows, pf, groups, idx, out);
+        run_short<6, 2, 0>(X, rows, pf, groups, idx, out);
+        run_short<4, 3, 0>(X, rows, pf, groups, idx, out);
+        run_short<4, 3, 1>(X, rows, pf, groups, idx, out);
+        run_short<12, 2, 0>(X, rows, pf, groups / 2, idx, out);
+        run_short<12, 4, 0>(X, rows, pf, groups / 4, idx, out);
+        run_short<12, 8, 0>(X, rows, pf, groups / 8, idx, out);
+        run_short<12, 16, 0>(X, rows, pf, groups / 16, idx, out);
+        CK(hipFree(X)); CK(hipFree(out)); CK(hipFree(idx));
+    }
     const int sizes[] = {8192, 16384, 32768, 131072};   // rows per panel: 1, 2, 4, 16 MB
     for (int rows : sizes) {
         const long pf = (long)rows * 32;
         float* X; float* sink;
         CK(hipMalloc(&X, pf * 8 * sizeof(float))); CK(hipMalloc(&sink, 64));
         CK(hipMemset(X, 0, pf * 8 * sizeof(float)));
-        for (int blocks : {2048, 4096, 8192}) {
+        for (int blocks : {4096}) {
             run<0, 4>("plain  4 in flight", X, rows, pf, blocks, sink);
             run<0, 8>("plain  8 in flight", X, rows, pf, blocks, sink);
             run<0, 16>("plain 16 in flight", X, rows, pf, blocks, sink);
