@@ -101,6 +101,34 @@ def selection_gnn_case(name, S2d, dimNodeSignals, nFilterTaps, nSelectedNodes, p
     print(f"selgnn_{name}: N={N} y{tuple(y.shape)} ygnn{tuple(ygnn.shape)} keys={[k for k in out if k.startswith('sd:')]}")
 
 
+def evgf_case(name, S, B, G, F, K, M, Nin=None, bias=True, seed=0):
+    """EdgeVariantGF forward + autograd (graphML.py:2511-2712): full EV (M = N), hybrid (M < N, LSI part + the bias
+    counted twice), Nin < N zero-padding.  The dense weightEV [F,E,K,G,N,N] is stored masked (off-pattern entries are
+    'trash' the reference multiplies by zero, graphML.py:2676) so the fixture compresses."""
+    rng = np.random.RandomState(seed)
+    E, N, _ = S.shape
+    Nin = N if Nin is None else Nin
+    torch.manual_seed(seed)
+    layer = gml.EdgeVariantGF(G, F, K, M, N, E, bias)
+    layer.addGSO(torch.tensor(S))
+    with torch.no_grad():
+        layer.weightEV.mul_(np.sqrt(N))                 # keep the chain products O(1): init std is 1/sqrt(G K N)
+        layer.weightEV.mul_(layer.sparsityPatternFull)  # zero the never-used entries (fixture size only)
+    x = rng.randn(B, G, Nin)
+    dy = rng.randn(B, F, Nin)
+    xt = torch.tensor(x, requires_grad=True)
+    y = layer(xt)
+    y.backward(torch.tensor(dy))
+    out = dict(x=x, dy=dy, y=y.detach().numpy(), dx=xt.grad.numpy(), M=np.array(M), K=np.array(K),
+               weightEV=layer.weightEV.detach().numpy(), dweightEV=layer.weightEV.grad.numpy(), **coo(S))
+    if layer.weightLSI is not None:
+        out.update(weightLSI=layer.weightLSI.detach().numpy(), dweightLSI=layer.weightLSI.grad.numpy())
+    if bias:
+        out.update(bias=layer.bias.detach().numpy(), dbias=layer.bias.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, f"evgf_{name}.npz"), **out)
+    print(f"evgf_{name}: N={N} E={E} M={M} Nin={Nin} B={B} G={G} F={F} K={K} max|y|={np.abs(out['y']).max():.3g}")
+
+
 def main():
     # ---- graphs --------------------------------------------------------------------------
     # directed ring with distinct weights + one chord: maximally asymmetric (catches S vs S^T)
@@ -138,6 +166,15 @@ def main():
     np.savez_compressed(os.path.join(HERE, "graphtools_sbm100.npz"), **gt_out)
     print("graphtools_sbm100:", sorted(gt_out))
 
+    # ---- EVGF / EdgeVariantGF (graphML.py:389-488, 2511-2712) ----------------------------------------------
+    evgf_case("asym37_full", asym37, B=3, G=4, F=6, K=3, M=37)
+    evgf_case("asym37_hybrid", asym37, B=3, G=4, F=6, K=3, M=20)
+    evgf_case("asym37_hybrid_Nin30", asym37, B=2, G=8, F=8, K=4, M=12, Nin=30)
+    evgf_case("asym_E2_hybrid", asym, B=3, G=3, F=5, K=3, M=9)
+    evgf_case("ring_K1_nobias", ring, B=2, G=2, F=3, K=1, M=6, bias=False)
+    evgf_case("sbm100_hybrid", sbm[None], B=4, G=4, F=4, K=3, M=30)
+    if "--evgf-only" in sys.argv:
+        return
     # ---- LSIGF -----------------------------------------------------------------------------
     lsigf_case("ring_dir", ring, B=2, G=2, F=3, K=3)
     lsigf_case("asym_E2", asym, B=3, G=3, F=5, K=4)
