@@ -3,13 +3,14 @@
 Layout mirrors the reference package so that call sites read the same:
     alegnn.utils.graphML.GraphFilter            ->  alegnn_amd.utils.graphML.GraphFilter
     alegnn.utils.graphML.LSIGF                  ->  alegnn_amd.utils.graphML.LSIGF
+    alegnn.utils.graphML.EdgeVariantGF          ->  alegnn_amd.utils.graphML.EdgeVariantGF
     alegnn.modules.architectures.SelectionGNN   ->  alegnn_amd.modules.architectures.SelectionGNN
 `install(reference_gml)` rebinds the reference's own symbols.
 """
-from .functional import LSIGF
-from .gso import SparseGSO
+from .functional import EVGF_edges, LSIGF
+from .gso import EdgePattern, SparseGSO
 
-__all__ = ["LSIGF", "SparseGSO", "install"]
+__all__ = ["LSIGF", "EVGF_edges", "SparseGSO", "EdgePattern", "install"]
 __version__ = "0.1.0"
 
 
@@ -20,4 +21,5 @@ def install(reference_graphML_module):
     from .utils import graphML as amd_gml
     reference_graphML_module.GraphFilter = amd_gml.GraphFilter
     reference_graphML_module.LSIGF = amd_gml.LSIGF
+    reference_graphML_module.EdgeVariantGF = amd_gml.EdgeVariantGF      # architectures.py:1877, 2111
     return reference_graphML_module

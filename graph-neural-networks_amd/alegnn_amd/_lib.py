@@ -33,6 +33,12 @@ _SIGNATURES = {
     "gf_lsigf_forward": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_lsigf_backward": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gf_ev_plan_create": (_c.c_int, [_i32, _i64, _vp, _vp, _c.POINTER(_vp)]),
+    "gf_ev_plan_destroy": (_c.c_int, [_vp]),
+    "gf_ev_plan_info": (_c.c_int, [_vp, _c.POINTER(_i32), _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "gf_evgf_scratch_floats": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "gf_evgf_forward": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gf_evgf_backward": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_time_spmm_hop": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _c.POINTER(_c.c_float)]),
     "gf_tune": (_c.c_int, [_c.c_char_p, _i32]),
 }

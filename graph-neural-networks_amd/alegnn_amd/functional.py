@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .gso import SparseGSO
+from .gso import EdgePattern, SparseGSO
 
 
 def _ptr(t):
@@ -107,3 +107,74 @@ def LSIGF(h, S, x, b=None):
     if late_bias is not None:
         y = y + late_bias[:, : y.shape[2]]
     return y
+
+
+class _EVGFFunction(torch.autograd.Function):
+    """One edge feature of EVGF with per-edge storage: two C-ABI calls (gf_evgf_forward / gf_evgf_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, wdiag, wedge, bias, pattern: EdgePattern):
+        L = _lib.lib()
+        B, G, Nin = x.shape
+        F_, G2, N = wdiag.shape
+        K = wedge.shape[1] + 1
+        x, wdiag, wedge = x.contiguous(), wdiag.contiguous(), wedge.contiguous()
+        bias_c = None if bias is None else bias.contiguous()
+        dev = x.device
+        with torch.cuda.device(dev):
+            plan = pattern.plan(dev)
+            V = torch.empty((K, F_ * G, N, B), dtype=torch.float32, device=dev)
+            scratch = torch.empty(L.gf_evgf_scratch_floats(B, G, F_, N, 0), dtype=torch.float32, device=dev)
+            y = torch.empty((B, F_, Nin), dtype=torch.float32, device=dev)
+            _lib.check(L.gf_evgf_forward(plan, x.data_ptr(), wdiag.data_ptr(), wedge.data_ptr() if K > 1 else None, _ptr(bias_c),
+                                         V.data_ptr(), scratch.data_ptr(), y.data_ptr(), B, G, F_, K, Nin,
+                                         torch.cuda.current_stream().cuda_stream), "gf_evgf_forward")
+        ctx.pattern = pattern
+        ctx.dims = (B, G, F_, K, Nin, N)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, wdiag, wedge, V)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, wdiag, wedge, V = ctx.saved_tensors
+        B, G, F_, K, Nin, N = ctx.dims
+        need_dx, need_dd, need_de = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2] and K > 1
+        need_db = ctx.has_bias and ctx.needs_input_grad[3]
+        dy = dy.contiguous()
+        dev = dy.device
+        with torch.cuda.device(dev):
+            plan = ctx.pattern.plan(dev)
+            scratch = torch.empty(L.gf_evgf_scratch_floats(B, G, F_, N, 1), dtype=torch.float32, device=dev)
+            dx = torch.empty_like(x) if need_dx else None
+            dd = torch.empty_like(wdiag) if need_dd else None
+            de = torch.empty_like(wedge) if need_de else None
+            db = torch.empty((F_, 1), dtype=torch.float32, device=dev) if need_db else None
+            _lib.check(L.gf_evgf_backward(plan, dy.data_ptr(), x.data_ptr(), wdiag.data_ptr(), wedge.data_ptr() if K > 1 else None,
+                                          V.data_ptr(), scratch.data_ptr(), _ptr(dx), _ptr(dd), _ptr(de), _ptr(db), B, G, F_, K, Nin,
+                                          torch.cuda.current_stream().cuda_stream), "gf_evgf_backward")
+        if ctx.needs_input_grad[2] and K == 1:
+            de = torch.zeros_like(wedge)
+        return dx, dd, de, db, None
+
+
+def EVGF_edges(pattern: EdgePattern, wdiag, wedge, x, b=None):
+    """Edge-variant graph filter for one edge feature with per-edge storage (reference: EVGF, graphML.py:389-488, fed
+    with Phi = weightEV * pattern, graphML.py:2676):
+
+        v_0 = diag(wdiag[f,g]) x_g ;  v_k = Phi_k^{fg} v_{k-1}  (Phi_k^{fg} = wedge[f,k-1,g,:] on `pattern`) ;  y_f = sum_{g,k} v_k + b_f
+
+    wdiag [F,G,N], wedge [F,K-1,G,nnzp], x [B,G,Nin<=N] (zero-padded), b [F,1]|None  ->  y [B,F,Nin]."""
+    assert wdiag.dim() == 3 and wedge.dim() == 4 and x.dim() == 3
+    F_, G, N = wdiag.shape
+    assert N == pattern.N
+    assert wedge.shape[0] == F_ and wedge.shape[2] == G and wedge.shape[3] == pattern.nnzp
+    assert x.shape[1] == G                                     # graphML.py:444
+    assert x.shape[2] <= N                                     # graphML.py:445 (== N); < N via EdgeVariantGF padding
+    for name, t in (("x", x), ("wdiag", wdiag), ("wedge", wedge)):
+        _require_f32_cuda(name, t)
+    if b is not None:
+        _require_f32_cuda("b", b)
+        assert b.dim() == 2 and b.shape[0] == F_ and b.shape[1] == 1
+    return _EVGFFunction.apply(x, wdiag, wedge, b, pattern)

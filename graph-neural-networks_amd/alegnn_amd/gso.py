@@ -118,3 +118,58 @@ class SparseGSO:
             for p in raw:
                 L.gf_plan_destroy(p)
         plans.clear()
+
+
+class EdgePattern:
+    """Sparsity pattern of the edge-variant filter taps k >= 1 for ONE edge feature (host CSR of ones, sorted columns)
+    + per-device ``gf_ev_plan`` handles.  Built by ``EdgeVariantGF.addGSO`` following graphML.py:2617-2643:
+    ``(|S_e| + I > zeroTolerance)`` restricted to entries whose row < M or column < M (hybrid mask)."""
+
+    ZERO_TOLERANCE = 1e-9                                       # graphML.py:27
+
+    def __init__(self, pattern: sp.csr_matrix):
+        pattern = sp.csr_matrix(pattern)
+        pattern.sum_duplicates()
+        pattern.sort_indices()
+        self.N = pattern.shape[0]
+        assert pattern.shape == (self.N, self.N)
+        self.indptr = np.ascontiguousarray(pattern.indptr, dtype=np.int32)
+        self.indices = np.ascontiguousarray(pattern.indices, dtype=np.int32)
+        self.nnzp = int(self.indices.shape[0])
+        self.rows = np.repeat(np.arange(self.N, dtype=np.int64), np.diff(self.indptr))
+        self.cols = self.indices.astype(np.int64)
+        self._plans = {}
+        self._finalizer = weakref.finalize(self, EdgePattern._destroy_all, self._plans)
+
+    @classmethod
+    def from_gso(cls, S2d, M: int) -> "EdgePattern":
+        S2d = sp.csr_matrix(S2d)
+        N = S2d.shape[0]
+        P = sp.coo_matrix((abs(S2d) + sp.identity(N, format="csr")) > cls.ZERO_TOLERANCE)
+        keep = ((P.row < M) | (P.col < M)) & (P.data != 0)
+        return cls(sp.csr_matrix((np.ones(int(keep.sum()), dtype=np.float32), (P.row[keep], P.col[keep])), shape=(N, N)))
+
+    def plan(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError(f"alegnn_amd runs on MI355X only (HIP device required), got device '{device}'")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        hit = self._plans.get(idx)
+        if hit is not None:
+            return hit
+        L = _lib.lib()
+        out = ctypes.c_void_p()
+        with torch.cuda.device(idx):
+            _lib.check(L.gf_ev_plan_create(self.N, self.nnzp, self.indptr.ctypes.data, self.indices.ctypes.data,
+                                           ctypes.byref(out)), "gf_ev_plan_create")
+        self._plans[idx] = out.value
+        return out.value
+
+    @staticmethod
+    def _destroy_all(plans):
+        try:
+            L = _lib.lib()
+        except Exception:
+            return
+        for p in plans.values():
+            L.gf_ev_plan_destroy(p)
+        plans.clear()

@@ -3,6 +3,7 @@
 Drop-in for the symbols SelectionGNN binds from alegnn/utils/graphML.py:
     LSIGF          (graphML.py:83-176)     -> alegnn_amd.functional.LSIGF   (HIP)
     GraphFilter    (graphML.py:2036-2155)  -> same ctor, attributes, parameter names/shapes, addGSO/forward/extra_repr
+    EdgeVariantGF  (graphML.py:2511-2712)  -> same ctor / parameters (dense weightEV), or per-edge storage (sparse=True)
     NoPool         (graphML.py:1850-1888)  identity pooling
     MaxPoolLocal   (graphML.py:1890-2028)  alpha-hop neighbourhood max, keep the first nOutputNodes nodes
 Checkpoints are interchangeable with the reference: ``weight [F,E,K,G]``, ``bias [F,1]``; the GSO is a plain attribute
@@ -17,11 +18,11 @@ import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
-from ..functional import LSIGF
-from ..gso import SparseGSO
+from ..functional import EVGF_edges, LSIGF
+from ..gso import EdgePattern, SparseGSO
 from . import graphTools
 
-__all__ = ["LSIGF", "GraphFilter", "NoPool", "MaxPoolLocal"]
+__all__ = ["LSIGF", "GraphFilter", "EdgeVariantGF", "NoPool", "MaxPoolLocal"]
 
 
 class GraphFilter(nn.Module):
@@ -71,6 +72,117 @@ class GraphFilter(nn.Module):
 
     def extra_repr(self):
         reprString = "in_features=%d, out_features=%d, " % (self.G, self.F) + "filter_taps=%d, " % (self.K) + \
+                     "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias is not None)
+        reprString += "GSO stored" if self.S is not None else "no GSO stored"
+        return reprString
+
+
+class EdgeVariantGF(nn.Module):
+    """EdgeVariantGF(in_features, out_features, shift_taps, selected_nodes, number_nodes, edge_features=1, bias=True)
+    -- graphML.py:2574-2597.  Hybrid edge-variant filter: nodes < M get an edge-variant filter, the rest an LSI filter.
+
+    sparse=False (default): parameters exactly as the reference -- ``weightEV [F,E,K,G,N,N]`` (only on-pattern entries are
+    ever used or trained, graphML.py:2676), ``weightLSI [F,E,K,G]`` if M < N, ``bias [F,1]`` -- so checkpoints interchange.
+    The HIP path never multiplies the dense tensor: the on-pattern entries are gathered (a view-like index, autograd
+    scatters the gradient back) and the filter runs on per-edge storage.
+    sparse=True (superset, mandatory when N^2 no longer fits: N = 5e4 is 3e13 bytes dense): the parameters ARE the
+    per-edge storage, ``weightEVdiag [F,E,G,N]`` and ``weightEVedges[e] [F,K-1,G,nnzp_e]``, created by ``addGSO``.
+    """
+
+    def __init__(self, G, F, K, M, N, E=1, bias=True, sparse=False):
+        super().__init__()
+        self.G = G
+        self.F = F
+        self.K = K
+        self.E = E
+        self.M = M                         # number of selected nodes
+        self.N = N                         # total number of nodes
+        self.S = None
+        self.sparse = bool(sparse)
+        self._gso = None
+        self._patterns = None
+        if not self.sparse:
+            self.weightEV = nn.parameter.Parameter(torch.Tensor(F, E, K, G, N, N))
+        else:
+            self.weightEVdiag = nn.parameter.Parameter(torch.Tensor(F, E, G, N))
+            self.weightEVedges = nn.ParameterList()            # filled by addGSO (the pattern sizes them)
+        if self.M < self.N:
+            self.weightLSI = nn.parameter.Parameter(torch.Tensor(F, E, K, G))
+        else:
+            self.register_parameter('weightLSI', None)
+        if bias:
+            self.bias = nn.parameter.Parameter(torch.Tensor(F, 1))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.G * self.K * self.N)          # graphML.py:2599-2606
+        if not self.sparse:
+            self.weightEV.data.uniform_(-stdv, stdv)
+        else:
+            self.weightEVdiag.data.uniform_(-stdv, stdv)
+            for w in self.weightEVedges:
+                w.data.uniform_(-stdv, stdv)
+        if self.weightLSI is not None:
+            self.weightLSI.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        if sp.issparse(S) or isinstance(S, (list, tuple)):
+            S = SparseGSO.from_any(S)
+        assert len(S.shape) == 3                                 # graphML.py:2610
+        assert S.shape[0] == self.E                              # :2612
+        self.N = S.shape[1]
+        assert S.shape[2] == self.N                              # :2614
+        self.S = S
+        self._gso = SparseGSO.from_any(S)
+        # pattern of taps k >= 1: (|S_e| + I > 1e-9) & hybrid mask (:2617-2643); tap 0: identity & mask -> nodes < M (:2653)
+        self._patterns = [EdgePattern.from_gso(m, self.M) for m in self._gso.mats]
+        self._index_cache = {}
+        if self.sparse:
+            dev, dt = self.weightEVdiag.device, self.weightEVdiag.dtype
+            assert self.weightEVdiag.shape[3] == self.N
+            sizes = [tuple(w.shape) for w in self.weightEVedges]
+            want = [(self.F, self.K - 1, self.G, p.nnzp) for p in self._patterns]
+            if sizes != want:                                    # first GSO, or a GSO with a different pattern
+                stdv = 1. / math.sqrt(self.G * self.K * self.N)
+                self.weightEVedges = nn.ParameterList(
+                    [nn.parameter.Parameter(torch.empty(w, device=dev, dtype=dt).uniform_(-stdv, stdv)) for w in want])
+
+    def _indices(self, e, device):
+        key = (e, str(device))
+        hit = self._index_cache.get(key)
+        if hit is None:
+            p = self._patterns[e]
+            hit = (torch.arange(self.N, device=device), torch.from_numpy(p.rows).to(device), torch.from_numpy(p.cols).to(device),
+                   (torch.arange(self.N, device=device) < self.M).to(torch.float32))
+            self._index_cache[key] = hit
+        return hit
+
+    def forward(self, x):
+        assert self._patterns is not None, "EdgeVariantGF.forward called before addGSO"
+        assert x.dim() == 3 and x.shape[2] <= self.N
+        u = None
+        for e in range(self.E):
+            ar, rows, cols, dmask = self._indices(e, x.device)
+            if not self.sparse:
+                w = self.weightEV[:, e]                                            # [F,K,G,N,N]
+                wdiag = w[:, 0][:, :, ar, ar] * dmask                              # Phi_0: identity & hybrid mask
+                wedge = w[:, 1:][:, :, :, rows, cols]                              # Phi_k on the pattern, k >= 1
+            else:
+                wdiag = self.weightEVdiag[:, e] * dmask
+                wedge = self.weightEVedges[e]
+            ue = EVGF_edges(self._patterns[e], wdiag, wedge, x, self.bias if e == 0 else None)   # bias once (:486-487)
+            u = ue if u is None else u + ue
+        if self.M < self.N:
+            u = u + LSIGF(self.weightLSI, self._gso, x, self.bias)                 # bias a second time (:2686)
+        return u
+
+    def extra_repr(self):
+        reprString = "in_features=%d, out_features=%d, " % (self.G, self.F) + "shift_taps=%d, " % (self.K) + \
+                     "selected_nodes=%d, " % (self.M) + "number_nodes=%d, " % (self.N) + \
                      "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias is not None)
         reprString += "GSO stored" if self.S is not None else "no GSO stored"
         return reprString

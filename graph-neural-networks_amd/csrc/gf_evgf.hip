@@ -1,0 +1,432 @@
+// gf_evgf.hip -- edge-variant graph filter with the filter matrices stored PER EDGE.
+// Replaces reference graphML.py:389-488 (EVGF) as called by EdgeVariantGF.forward (graphML.py:2670-2698):
+//     v_0^{fg} = Phi_0^{fg} x_g,   v_k^{fg} = Phi_k^{fg} v_{k-1}^{fg},   y_f = sum_{g,k} v_k^{fg} + b_f     (column convention)
+// The reference materialises Phi = weightEV * pattern as a dense [F,E,K,G,N,N] tensor and runs a broadcast dense
+// matmul per tap (3e13 bytes at N = 5e4); here only on-pattern entries exist: tap 0 is the diagonal wdiag[F,G,N], taps
+// k >= 1 are wedge[F,K-1,G,nnzp] on one shared CSR pattern, and every chain (f,g) is a sparse product.
+//
+// Data layout in HBM: chain state V[c = f*G+g][n][b] -- batch index contiguous -- because the weight of an edge is one
+// scalar for the whole batch: a hop is an axpy over b per pattern entry, the gather of v_{k-1}[col] is one contiguous
+// B-float row, and all loads/stores of a wave are coalesced.  x / dy / y / dx cross the boundary in the reference layout
+// [B,C,N] and are transposed once ([C][N][B] "node-batch" layout) by a tiled kernel.
+//
+// HBM-bound: per tap the algorithmic traffic is the weight stream F*G*nnzp*4 (read once) + the state 2*B*F*G*N*4.
+// Chains are processed chain-major so that the gather panel of the chains in flight (N*B*4 bytes each) is L2-resident.
+// Everything is deterministic: reductions over b use fixed-order wave shuffles, sums over g/k/f are sequential loops.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "gf_common.h"
+
+struct gf_ev_plan {
+    int32_t n = 0;
+    int64_t nnzp = 0;
+    int64_t device_bytes = 0;
+    int32_t* rowptr = nullptr;    // [N+1]   pattern CSR: row i lists its on-pattern columns j (ascending); entry index = p
+    int32_t* col = nullptr;       // [nnzp]
+    int32_t* row = nullptr;       // [nnzp]  COO row of entry p (SDDMM)
+    int32_t* t_rowptr = nullptr;  // [N+1]   transposed pattern: row j lists the entries p with col[p] == j
+    int32_t* t_col = nullptr;     // [nnzp]  = row[p]   (ascending within a transposed row)
+    int32_t* t_vidx = nullptr;    // [nnzp]  = p        (value index into wedge)
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline unsigned grid_for(int64_t work_items) {
+    int64_t blocks = (work_items + kThreads - 1) / kThreads;
+    const int64_t cap = 256 * 64;  // grid-stride beyond this
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// ---- batched transposes between the reference layout and the node-batch layout -------------------------------------
+// src element (c, r, q), r < R, q < Q at src[c*src_cs + r*src_rs + q];  dst element (c, q, r), q < Qpad at
+// dst[c*dst_cs + q*dst_rs + r] = (q < Q ? src : 0).
+__global__ __launch_bounds__(256) void ev_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Q,
+                                                           int Qpad, int64_t src_cs, int64_t src_rs, int64_t dst_cs,
+                                                           int64_t dst_rs) {
+    __shared__ float tile[32][33];
+    const int c = blockIdx.z;
+    const int q0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* s = src + (int64_t)c * src_cs;
+    float* d = dst + (int64_t)c * dst_cs;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, q = q0 + tx;
+        tile[ty + i][tx] = (r < R && q < Q) ? s[(int64_t)r * src_rs + q] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int q = q0 + ty + i, r = r0 + tx;
+        if (q < Qpad && r < R) d[(int64_t)q * dst_rs + r] = tile[tx][ty + i];
+    }
+}
+
+int to_nodebatch(const float* x, float* Xt, int B, int Cn, int Nin, int N, hipStream_t st) {
+    GF_REQUIRE_SHAPE(Cn <= 65535, "gf_evgf: %d feature planes exceed the grid limit", Cn);
+    dim3 grid((N + 31) / 32, (B + 31) / 32, Cn);
+    hipLaunchKernelGGL(ev_transpose_kernel, grid, dim3(256), 0, st, x, Xt, B, Nin, N, (int64_t)Nin, (int64_t)Cn * Nin,
+                       (int64_t)N * B, (int64_t)B);
+    GF_LAUNCH_CHECK("ev_transpose_kernel(to node-batch)");
+    return GF_OK;
+}
+
+int from_nodebatch(const float* Yt, float* y, int B, int Cn, int N, int Nout, hipStream_t st) {
+    GF_REQUIRE_SHAPE(Cn <= 65535, "gf_evgf: %d feature planes exceed the grid limit", Cn);
+    dim3 grid((B + 31) / 32, (Nout + 31) / 32, Cn);
+    hipLaunchKernelGGL(ev_transpose_kernel, grid, dim3(256), 0, st, Yt, y, Nout, B, B, (int64_t)N * B, (int64_t)B,
+                       (int64_t)Nout, (int64_t)Cn * Nout);
+    GF_LAUNCH_CHECK("ev_transpose_kernel(from node-batch)");
+    return GF_OK;
+}
+
+// ---- tap 0: V0[c][n][b] = wdiag[c][n] * Xt[g(c)][n][b]   (Phi_0 is diagonal, graphML.py:2653-2668) -------------------
+__global__ __launch_bounds__(kThreads) void ev_tap0_kernel(const float* __restrict__ wdiag, const float* __restrict__ Xt,
+                                                           float* __restrict__ V0, int G, int64_t NB, int B, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+        const int64_t c = idx / NB, nb = idx - c * NB;
+        const int g = (int)(c % G);
+        V0[idx] = wdiag[c * (NB / B) + nb / B] * Xt[(int64_t)g * NB + nb];
+    }
+}
+
+// ---- one tap of every chain: out[c][i][b] = add[c/add_div][i][b] + sum_{q in row i} W_c[vidx ? vidx[q] : q] * in[c/in_div][col[q]][b]
+// W_c = wedge + ((f*K1 + kidx)*G + g)*nnzp for c = f*G + g.  Forward: (rowptr, col) = pattern, vidx = NULL.
+// Backward: (rowptr, col, vidx) = transposed pattern, add = dy (chain-broadcast via add_div = G).
+__global__ __launch_bounds__(kThreads) void ev_hop_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const int32_t* __restrict__ vidx, const float* __restrict__ wedge,
+                                                          const float* __restrict__ in, const float* __restrict__ add,
+                                                          float* __restrict__ out, int N, int B, int G, int K1, int kidx,
+                                                          int64_t nnzp, int in_div, int add_div, int64_t total) {
+    const int64_t NB = (int64_t)N * B;
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+        const int64_t c = idx / NB;
+        const int64_t nb = idx - c * NB;
+        const int i = (int)(nb / B), b = (int)(nb - (int64_t)i * B);
+        const int f = (int)(c / G), g = (int)(c - (int64_t)f * G);
+        const float* W = wedge + ((int64_t)(f * K1 + kidx) * G + g) * nnzp;
+        const float* vin = in + (c / in_div) * NB + b;
+        float acc = add ? add[(c / add_div) * NB + nb] : 0.f;
+        const int q1 = rowptr[i + 1];
+        for (int q = rowptr[i]; q < q1; ++q) {
+            const int p = vidx ? vidx[q] : q;
+            acc = fmaf(W[p], vin[(int64_t)col[q] * B], acc);
+        }
+        out[idx] = acc;
+    }
+}
+
+// ---- y: Yt[f][n][b] = bias[f] + sum_{k} sum_{g} V[k][f*G+g][n][b]      (graphML.py:481-487) ----------------------------
+__global__ __launch_bounds__(kThreads) void ev_sum_kernel(const float* __restrict__ V, const float* __restrict__ bias,
+                                                          float* __restrict__ Yt, int G, int K, int64_t NB, int64_t CNB,
+                                                          int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+        const int64_t f = idx / NB, nb = idx - f * NB;
+        float acc = bias ? bias[f] : 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float* v = V + (int64_t)k * CNB + f * G * NB + nb;
+            for (int g = 0; g < G; ++g) acc += v[(int64_t)g * NB];
+        }
+        Yt[idx] = acc;
+    }
+}
+
+// ---- reductions over the batch: LB lanes (power of two <= 64) per output, fixed-order xor tree ------------------------
+template <int LB>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LB / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// dW_c[p] = sum_b U[c/u_div][row[p]][b] * V[c][col[p]][b]        (SDDMM on the pattern: dPhi_k = u_k v_{k-1}^T)
+template <int LB>
+__global__ __launch_bounds__(kThreads) void ev_sddmm_kernel(const int32_t* __restrict__ row, const int32_t* __restrict__ col,
+                                                            const float* __restrict__ U, const float* __restrict__ V,
+                                                            float* __restrict__ dwedge, int N, int B, int G, int K1, int kidx,
+                                                            int64_t nnzp, int u_div, int64_t groups) {
+    const int64_t NB = (int64_t)N * B;
+    const int lane = threadIdx.x % LB;
+    const int64_t g0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LB;
+    const int64_t gstep = (int64_t)gridDim.x * kThreads / LB;
+    for (int64_t grp = g0; grp < groups; grp += gstep) {  // whole LB-lane groups leave the loop together
+        const int64_t c = grp / nnzp, p = grp - c * nnzp;
+        const float* u = U + (c / u_div) * NB + (int64_t)row[p] * B;
+        const float* v = V + c * NB + (int64_t)col[p] * B;
+        float acc = 0.f;
+        for (int b = lane; b < B; b += LB) acc = fmaf(u[b], v[b], acc);
+        acc = group_sum<LB>(acc);
+        if (lane == 0) {
+            const int f = (int)(c / G), g = (int)(c - (int64_t)f * G);
+            dwedge[((int64_t)(f * K1 + kidx) * G + g) * nnzp + p] = acc;
+        }
+    }
+}
+
+// dwdiag[c][n] = sum_b U0[c/u_div][n][b] * Xt[g(c)][n][b]
+template <int LB>
+__global__ __launch_bounds__(kThreads) void ev_dwdiag_kernel(const float* __restrict__ U0, const float* __restrict__ Xt,
+                                                             float* __restrict__ dwdiag, int N, int B, int G, int u_div,
+                                                             int64_t groups) {
+    const int64_t NB = (int64_t)N * B;
+    const int lane = threadIdx.x % LB;
+    const int64_t g0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LB;
+    const int64_t gstep = (int64_t)gridDim.x * kThreads / LB;
+    for (int64_t grp = g0; grp < groups; grp += gstep) {
+        const int64_t c = grp / N, n = grp - c * N;
+        const float* u = U0 + (c / u_div) * NB + n * B;
+        const float* x = Xt + (c % G) * NB + n * B;
+        float acc = 0.f;
+        for (int b = lane; b < B; b += LB) acc = fmaf(u[b], x[b], acc);
+        acc = group_sum<LB>(acc);
+        if (lane == 0) dwdiag[grp] = acc;
+    }
+}
+
+// dXt[g][n][b] = sum_f wdiag[f*G+g][n] * U0[(f*G+g)/u_div][n][b]
+__global__ __launch_bounds__(kThreads) void ev_dxt_kernel(const float* __restrict__ wdiag, const float* __restrict__ U0,
+                                                          float* __restrict__ dXt, int N, int B, int G, int F, int u_div,
+                                                          int64_t total) {
+    const int64_t NB = (int64_t)N * B;
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+        const int64_t g = idx / NB, nb = idx - g * NB;
+        const int64_t n = nb / B;
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const int64_t c = (int64_t)f * G + g;
+            acc = fmaf(wdiag[c * N + n], U0[(c / u_div) * NB + nb], acc);
+        }
+        dXt[idx] = acc;
+    }
+}
+
+// dbias[f] = sum_{n,b} Dyt[f][n][b]: one workgroup per f, strided partial sums + fixed LDS tree (deterministic)
+__global__ __launch_bounds__(kThreads) void ev_dbias_kernel(const float* __restrict__ Dyt, float* __restrict__ dbias, int64_t NB) {
+    __shared__ float part[kThreads];
+    const float* d = Dyt + (int64_t)blockIdx.x * NB;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < NB; i += kThreads) acc += d[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dbias[blockIdx.x] = part[0];
+}
+
+int lanes_for_batch(int B) {
+    int lb = 1;
+    while (lb < B && lb < 64) lb <<= 1;
+    return lb;
+}
+
+template <class T>
+int upload_vec(const std::vector<T>& h, T** d, int64_t& bytes) {
+    const size_t nb = std::max<size_t>(h.size(), 1) * sizeof(T);
+    GF_HIP(hipMalloc((void**)d, nb));
+    if (!h.empty()) GF_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    bytes += (int64_t)nb;
+    return GF_OK;
+}
+
+struct EvDims {
+    int N;
+    int64_t NB, CNB;
+    int C;
+};
+
+int check_common(const char* who, const gf_ev_plan* plan, int B, int G, int F, int K, int Nin) {
+    GF_REQUIRE_ARG(plan != nullptr, "%s: plan is NULL", who);
+    GF_REQUIRE_SHAPE(B > 0 && G > 0 && F > 0 && K > 0 && Nin > 0, "%s: bad shape B=%d G=%d F=%d K=%d Nin=%d", who, B, G, F, K, Nin);
+    GF_REQUIRE_SHAPE(Nin <= plan->n, "%s: signal has %d nodes, pattern has %d", who, Nin, plan->n);  // graphML.py:2678 only pads
+    GF_REQUIRE_SHAPE((int64_t)F * G < (int64_t)INT32_MAX / 2, "%s: F*G too large", who);
+    return GF_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int gf_ev_plan_create(int32_t n, int64_t nnzp, const int32_t* rowptr, const int32_t* colidx, gf_ev_plan** out) {
+    GF_REQUIRE_ARG(out != nullptr, "gf_ev_plan_create: out_plan is NULL");
+    *out = nullptr;
+    GF_REQUIRE_ARG(rowptr && (nnzp == 0 || colidx), "gf_ev_plan_create: NULL CSR array");
+    GF_REQUIRE_SHAPE(n > 0, "gf_ev_plan_create: n_nodes = %d must be positive", n);
+    GF_REQUIRE_SHAPE(nnzp >= 0 && nnzp < (int64_t)INT32_MAX, "gf_ev_plan_create: nnzp = %lld outside [0, 2^31)", (long long)nnzp);
+    GF_REQUIRE_SHAPE(rowptr[0] == 0 && rowptr[n] == nnzp, "gf_ev_plan_create: rowptr[0] = %d, rowptr[N] = %d, nnzp = %lld",
+                     rowptr[0], rowptr[n], (long long)nnzp);
+    for (int32_t i = 0; i < n; ++i) {
+        GF_REQUIRE_SHAPE(rowptr[i] <= rowptr[i + 1], "gf_ev_plan_create: rowptr not monotone at row %d", i);
+        for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+            GF_REQUIRE_SHAPE(colidx[q] >= 0 && colidx[q] < n, "gf_ev_plan_create: column %d at %d outside [0, %d)", colidx[q], q, n);
+            GF_REQUIRE_SHAPE(q == rowptr[i] || colidx[q] > colidx[q - 1],
+                             "gf_ev_plan_create: row %d is not strictly ascending (entry order defines the value index)", i);
+        }
+    }
+    gf_ev_plan* pl = new (std::nothrow) gf_ev_plan();
+    if (!pl) {
+        gf_set_error("gf_ev_plan_create: out of host memory");
+        return GF_ERR_NOMEM;
+    }
+    int rc = GF_OK;
+    try {
+        std::vector<int32_t> rp(rowptr, rowptr + n + 1), ci(colidx, colidx + nnzp), row(nnzp);
+        for (int32_t i = 0; i < n; ++i)
+            for (int32_t q = rp[i]; q < rp[i + 1]; ++q) row[q] = i;
+        std::vector<int32_t> trp(n + 1, 0), tci(nnzp), tvi(nnzp);
+        for (int64_t q = 0; q < nnzp; ++q) trp[ci[q] + 1]++;
+        for (int32_t i = 0; i < n; ++i) trp[i + 1] += trp[i];
+        std::vector<int32_t> cur(trp.begin(), trp.end() - 1);
+        for (int64_t q = 0; q < nnzp; ++q) {  // ascending p => ascending original row within each transposed row
+            const int32_t t = cur[ci[q]]++;
+            tci[t] = row[q];
+            tvi[t] = (int32_t)q;
+        }
+        pl->n = n;
+        pl->nnzp = nnzp;
+        if ((rc = upload_vec(rp, &pl->rowptr, pl->device_bytes)) == GF_OK && (rc = upload_vec(ci, &pl->col, pl->device_bytes)) == GF_OK &&
+            (rc = upload_vec(row, &pl->row, pl->device_bytes)) == GF_OK && (rc = upload_vec(trp, &pl->t_rowptr, pl->device_bytes)) == GF_OK &&
+            (rc = upload_vec(tci, &pl->t_col, pl->device_bytes)) == GF_OK)
+            rc = upload_vec(tvi, &pl->t_vidx, pl->device_bytes);
+    } catch (const std::bad_alloc&) {
+        gf_set_error("gf_ev_plan_create: out of host memory");
+        rc = GF_ERR_NOMEM;
+    }
+    if (rc != GF_OK) {
+        gf_ev_plan_destroy(pl);
+        return rc;
+    }
+    *out = pl;
+    return GF_OK;
+}
+
+extern "C" int gf_ev_plan_destroy(gf_ev_plan* pl) {
+    if (!pl) return GF_OK;
+    for (int32_t* p : {pl->rowptr, pl->col, pl->row, pl->t_rowptr, pl->t_col, pl->t_vidx})
+        if (p) (void)hipFree(p);
+    delete pl;
+    return GF_OK;
+}
+
+extern "C" int gf_ev_plan_info(const gf_ev_plan* pl, int32_t* n, int64_t* nnzp, int64_t* device_bytes) {
+    GF_REQUIRE_ARG(pl != nullptr, "gf_ev_plan_info: plan is NULL");
+    if (n) *n = pl->n;
+    if (nnzp) *nnzp = pl->nnzp;
+    if (device_bytes) *device_bytes = pl->device_bytes;
+    return GF_OK;
+}
+
+extern "C" size_t gf_evgf_scratch_floats(int32_t B, int32_t G, int32_t F, int32_t N, int32_t backward) {
+    if (B <= 0 || G <= 0 || F <= 0 || N <= 0) return 0;
+    const size_t NB = (size_t)N * B;
+    return backward ? NB * ((size_t)2 * G + F + (size_t)2 * F * G) : NB * ((size_t)G + F);
+}
+
+extern "C" int gf_evgf_forward(const gf_ev_plan* plan, const float* x, const float* wdiag, const float* wedge, const float* bias,
+                               float* V, float* scratch, float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin,
+                               void* stream) {
+    int rc = check_common("gf_evgf_forward", plan, B, G, F, K, Nin);
+    if (rc != GF_OK) return rc;
+    GF_REQUIRE_ARG(x && wdiag && V && scratch && y && (K == 1 || wedge), "gf_evgf_forward: NULL tensor");
+    const int N = plan->n, C = F * G;
+    const int64_t NB = (int64_t)N * B, CNB = (int64_t)C * NB;
+    hipStream_t st = gf_stream(stream);
+    float* Xt = scratch;
+    float* Yt = scratch + (int64_t)G * NB;
+    if ((rc = to_nodebatch(x, Xt, B, G, Nin, N, st)) != GF_OK) return rc;
+    hipLaunchKernelGGL(ev_tap0_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, wdiag, Xt, V, G, NB, B, CNB);
+    GF_LAUNCH_CHECK("ev_tap0_kernel");
+    for (int k = 1; k < K; ++k) {
+        hipLaunchKernelGGL(ev_hop_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, plan->rowptr, plan->col, (const int32_t*)nullptr,
+                           wedge, V + (int64_t)(k - 1) * CNB, (const float*)nullptr, V + (int64_t)k * CNB, N, B, G, K - 1, k - 1,
+                           plan->nnzp, 1, 1, CNB);
+        GF_LAUNCH_CHECK("ev_hop_kernel");
+    }
+    const int64_t FNB = (int64_t)F * NB;
+    hipLaunchKernelGGL(ev_sum_kernel, dim3(grid_for(FNB)), dim3(kThreads), 0, st, V, bias, Yt, G, K, NB, CNB, FNB);
+    GF_LAUNCH_CHECK("ev_sum_kernel");
+    return from_nodebatch(Yt, y, B, F, N, Nin, st);
+}
+
+extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const float* x, const float* wdiag, const float* wedge,
+                                const float* V, float* scratch, float* dx, float* dwdiag, float* dwedge, float* dbias, int32_t B,
+                                int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
+    int rc = check_common("gf_evgf_backward", plan, B, G, F, K, Nin);
+    if (rc != GF_OK) return rc;
+    GF_REQUIRE_ARG(dy && x && wdiag && V && scratch && (K == 1 || wedge), "gf_evgf_backward: NULL tensor");
+    const int N = plan->n, C = F * G;
+    const int64_t NB = (int64_t)N * B, CNB = (int64_t)C * NB;
+    hipStream_t st = gf_stream(stream);
+    float* Xt = scratch;
+    float* dXt = Xt + (int64_t)G * NB;
+    float* Dyt = dXt + (int64_t)G * NB;
+    float* Ubuf[2] = {Dyt + (int64_t)F * NB, Dyt + (int64_t)F * NB + CNB};
+    if ((rc = to_nodebatch(x, Xt, B, G, Nin, N, st)) != GF_OK) return rc;
+    if ((rc = to_nodebatch(dy, Dyt, B, F, Nin, N, st)) != GF_OK) return rc;
+    if (dbias) {
+        hipLaunchKernelGGL(ev_dbias_kernel, dim3(F), dim3(kThreads), 0, st, Dyt, dbias, NB);
+        GF_LAUNCH_CHECK("ev_dbias_kernel");
+    }
+    // u_{K-1}^{fg} = dy_f : read Dyt through the chain divisor G instead of materialising the broadcast
+    const float* Ucur = Dyt;
+    int udiv = G, pp = 0;
+    const int lb = lanes_for_batch(B);
+    for (int k = K - 1; k >= 1; --k) {
+        if (dwedge) {
+            const int64_t groups = (int64_t)C * plan->nnzp;
+            const unsigned grid = grid_for(groups * lb);
+#define GF_SDDMM(LBV)                                                                                                         \
+    hipLaunchKernelGGL((ev_sddmm_kernel<LBV>), dim3(grid), dim3(kThreads), 0, st, plan->row, plan->col, Ucur,                  \
+                       V + (int64_t)(k - 1) * CNB, dwedge, N, B, G, K - 1, k - 1, plan->nnzp, udiv, groups)
+            switch (lb) {
+                case 1: GF_SDDMM(1); break;
+                case 2: GF_SDDMM(2); break;
+                case 4: GF_SDDMM(4); break;
+                case 8: GF_SDDMM(8); break;
+                case 16: GF_SDDMM(16); break;
+                case 32: GF_SDDMM(32); break;
+                default: GF_SDDMM(64); break;
+            }
+#undef GF_SDDMM
+            GF_LAUNCH_CHECK("ev_sddmm_kernel");
+        }
+        if (k > 1 || dwdiag || dx) {  // u_{k-1} = Phi_k^T u_k + dy_f
+            hipLaunchKernelGGL(ev_hop_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, plan->t_rowptr, plan->t_col, plan->t_vidx,
+                               wedge, Ucur, Dyt, Ubuf[pp], N, B, G, K - 1, k - 1, plan->nnzp, udiv, G, CNB);
+            GF_LAUNCH_CHECK("ev_hop_kernel(transposed)");
+            Ucur = Ubuf[pp];
+            udiv = 1;
+            pp ^= 1;
+        }
+    }
+    if (dwdiag) {
+        const int64_t groups = (int64_t)C * N;
+        const unsigned grid = grid_for(groups * lb);
+#define GF_DWD(LBV) \
+    hipLaunchKernelGGL((ev_dwdiag_kernel<LBV>), dim3(grid), dim3(kThreads), 0, st, Ucur, Xt, dwdiag, N, B, G, udiv, groups)
+        switch (lb) {
+            case 1: GF_DWD(1); break;
+            case 2: GF_DWD(2); break;
+            case 4: GF_DWD(4); break;
+            case 8: GF_DWD(8); break;
+            case 16: GF_DWD(16); break;
+            case 32: GF_DWD(32); break;
+            default: GF_DWD(64); break;
+        }
+#undef GF_DWD
+        GF_LAUNCH_CHECK("ev_dwdiag_kernel");
+    }
+    if (dx) {
+        const int64_t GNB = (int64_t)G * NB;
+        hipLaunchKernelGGL(ev_dxt_kernel, dim3(grid_for(GNB)), dim3(kThreads), 0, st, wdiag, Ucur, dXt, N, B, G, F, udiv, GNB);
+        GF_LAUNCH_CHECK("ev_dxt_kernel");
+        rc = from_nodebatch(dXt, dx, B, G, N, Nin, st);
+    }
+    return rc;
+}

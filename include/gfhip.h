@@ -106,6 +106,29 @@ int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const float* dy, c
                       float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
                       int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
 
+/* ---- edge-variant graph filter, per-edge storage: EVGF (graphML.py:389-488) as called by EdgeVariantGF.forward
+ * (graphML.py:2670-2698).  ONE edge feature per call (the host sums over e; EVGF is linear in e).  The reference holds
+ * Phi = weightEV * sparsityPatternFull as a dense [F,E,K,G,N,N] tensor; here only the entries its mask keeps exist:
+ *   wdiag [F,G,N]         = Phi[:, e, 0, :, n, n]        tap 0 is diagonal (identity & hybrid mask, graphML.py:2653-2668)
+ *   wedge [F,K-1,G,nnzp]  = Phi[:, e, 1:, :, i_p, j_p]   taps k >= 1 on the pattern (|S|+I > 1e-9 & hybrid mask, :2617-2643)
+ * gf_ev_plan: device image of the pattern CSR (HOST arrays; row i lists its columns j strictly ascending; the entry
+ * order defines the value index p) and of its transpose.  Column convention v_k = Phi_k v_{k-1} (graphML.py:464, 475).
+ *   forward : x [B,G,Nin] (zero-padded to N, :2678-2680) -> y [B,F,Nin] = sum_{g,k} v_k^{fg} + bias[f];
+ *             V [K, F*G, N, B] receives every chain state (save it for backward).
+ *   backward: dy [B,F,Nin], x, V -> dx [B,G,Nin], dwdiag [F,G,N], dwedge [F,K-1,G,nnzp], dbias [F]   (each nullable = skip)
+ * scratch: gf_evgf_scratch_floats(B, G, F, N, backward) floats of device memory. */
+typedef struct gf_ev_plan gf_ev_plan; /* opaque */
+int gf_ev_plan_create(int32_t n_nodes, int64_t nnzp, const int32_t* rowptr_host, const int32_t* colidx_host,
+                      gf_ev_plan** out_plan);
+int gf_ev_plan_destroy(gf_ev_plan* plan);
+int gf_ev_plan_info(const gf_ev_plan* plan, int32_t* n_nodes, int64_t* nnzp, int64_t* device_bytes);
+size_t gf_evgf_scratch_floats(int32_t B, int32_t G, int32_t F, int32_t N, int32_t backward);
+int gf_evgf_forward(const gf_ev_plan* plan, const float* x, const float* wdiag, const float* wedge, const float* bias, float* V,
+                    float* scratch, float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
+int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const float* x, const float* wdiag, const float* wedge,
+                     const float* V, float* scratch, float* dx, float* dwdiag, float* dwedge, float* dbias, int32_t B, int32_t G,
+                     int32_t F, int32_t K, int32_t Nin, void* stream);
+
 /* ---- measurement hook: run ONE hop `iters` times on `stream` bracketed by HIP events on that stream and return
  * the average milliseconds per launch (bench.py's roofline leg; hipEvents see the launch stream, torch events may not). */
 int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* X_out, int32_t B, int32_t W,

@@ -15,9 +15,10 @@ import scipy.sparse as sp
 import torch
 
 from _util import FWD_RTOL, GOLDEN, GRAD_RTOL, case_id, golden_files, load, relerr
+from oracle import evgf_oracle as evo
 from oracle import lsigf_oracle as orc
 
-from alegnn_amd import LSIGF, SparseGSO, _lib, graphgen
+from alegnn_amd import EVGF_edges, EdgePattern, LSIGF, SparseGSO, _lib, graphgen
 from alegnn_amd.modules.architectures import SelectionGNN
 from alegnn_amd.utils import graphML as gml
 
@@ -341,3 +342,99 @@ def test_error_conventions_on_device():
     y = layer(torch.zeros(2, 4, 6, device=DEV))
     assert tuple(y.shape) == (2, 8, 6)
     assert torch.allclose(y, layer.bias.detach().reshape(1, 8, 1).expand(2, 8, 6))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# EVGF / EdgeVariantGF
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files("evgf"), ids=case_id)
+def test_edge_variant_gf_matches_reference_golden(path):
+    """The reference's own EdgeVariantGF outputs and autograd gradients (full EV, hybrid with the bias counted twice,
+    E = 2, Nin < N, K = 1, no bias), with the reference's dense parameter layout."""
+    d = load(path)
+    F, E, K, G, N, _ = d["weightEV"].shape
+    M = int(d["M"])
+    has_bias = "bias" in d
+    layer = gml.EdgeVariantGF(G, F, K, M, N, E, has_bias)
+    sd = {"weightEV": torch.tensor(d["weightEV"])}
+    if "weightLSI" in d:
+        sd["weightLSI"] = torch.tensor(d["weightLSI"])
+    if has_bias:
+        sd["bias"] = torch.tensor(d["bias"])
+    layer.load_state_dict(sd)
+    layer.addGSO(torch.tensor(d["S"]))
+    layer = layer.float().to(DEV)
+    x = cu(d["x"], True)
+    y = layer(x)
+    assert tuple(y.shape) == d["y"].shape
+    y.backward(cu(d["dy"]))
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    assert relerr(layer.weightEV.grad.cpu().numpy(), d["dweightEV"]) < GRAD_RTOL
+    if "weightLSI" in d:
+        assert relerr(layer.weightLSI.grad.cpu().numpy(), d["dweightLSI"]) < GRAD_RTOL
+    if has_bias:
+        assert relerr(layer.bias.grad.cpu().numpy(), d["dbias"]) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=700, B=16, G=8, F=8, K=3, M=700, directed=True),
+    dict(N=500, B=5, G=4, F=12, K=4, M=200, directed=True),         # odd batch, hybrid pattern
+    dict(N=300, B=70, G=3, F=5, K=2, M=300, directed=False),        # batch > one wavefront
+    dict(N=2000, B=16, G=32, F=32, K=3, M=2000, directed=False),    # config-5 widths
+], ids=lambda c: "_".join(f"{k}{v}" for k, v in c.items()))
+def test_evgf_per_edge_storage_vs_oracle(cfg):
+    N, B, G, F, K, M = (cfg[k] for k in "NBGFKM")
+    A = graphgen.sbm(N, seed=5, directed=cfg["directed"])
+    pat = EdgePattern.from_gso(A, M)
+    P = evo.ev_pattern(A, M)
+    assert np.array_equal(pat.indices, P.indices)
+    rng = np.random.RandomState(3)
+    scale = 1.0 / np.sqrt(G * K)
+    wdiag = (rng.uniform(-1, 1, (F, G, N)) * (np.arange(N) < M)).astype(np.float32)
+    wedge = (rng.uniform(-1, 1, (F, K - 1, G, pat.nnzp)) * 0.3).astype(np.float32)
+    x = rng.randn(B, G, N).astype(np.float32)
+    b = rng.uniform(-1, 1, (F, 1)).astype(np.float32)
+    dy = (rng.randn(B, F, N) * scale).astype(np.float32)
+    wd, we, xt, bt = cu(wdiag, True), cu(wedge, True), cu(x, True), cu(b, True)
+    y = EVGF_edges(pat, wd, we, xt, bt)
+    y.backward(cu(dy))
+    want = evo.evgf_sparse(P, wdiag, wedge, x, b)
+    dx, dwd, dwe, db = evo.evgf_sparse_grads(P, wdiag, wedge, x, dy)
+    assert relerr(y.detach().cpu().numpy(), want) < FWD_RTOL
+    assert relerr(xt.grad.cpu().numpy(), dx) < GRAD_RTOL
+    assert relerr(wd.grad.cpu().numpy(), dwd) < GRAD_RTOL
+    assert relerr(we.grad.cpu().numpy(), dwe) < GRAD_RTOL
+    assert relerr(bt.grad.cpu().numpy(), db) < GRAD_RTOL
+    # bitwise run-to-run determinism (no float atomics anywhere)
+    wd2, we2, xt2, bt2 = cu(wdiag, True), cu(wedge, True), cu(x, True), cu(b, True)
+    y2 = EVGF_edges(pat, wd2, we2, xt2, bt2)
+    y2.backward(cu(dy))
+    assert torch.equal(y, y2) and torch.equal(we.grad, we2.grad) and torch.equal(xt.grad, xt2.grad)
+
+
+def test_edge_variant_gf_sparse_parameters_config5_shape():
+    """sparse=True parameter storage at config-5 widths (N scaled down so the oracle finishes): same function of the
+    same numbers as the dense-parameter module, linear in x, zero-padding honoured."""
+    N, B, G, F, K, M = 1500, 8, 32, 32, 3, 1500
+    A = graphgen.sbm(N, seed=9)
+    layer = gml.EdgeVariantGF(G, F, K, M, N, 1, True, sparse=True)
+    layer.addGSO(A)
+    layer.to(DEV)
+    with torch.no_grad():
+        layer.weightEVdiag.mul_(np.sqrt(N))
+        layer.weightEVedges[0].mul_(np.sqrt(N) * 0.5)
+    torch.manual_seed(0)
+    x = torch.randn(B, G, N, device=DEV)
+    y = layer(x)
+    P = evo.ev_pattern(A, M)
+    want = evo.evgf_sparse(P, layer.weightEVdiag[:, 0].detach().cpu().numpy(), layer.weightEVedges[0].detach().cpu().numpy(),
+                           x.cpu().numpy(), layer.bias.detach().cpu().numpy())
+    assert relerr(y.detach().cpu().numpy(), want) < FWD_RTOL
+    y2 = layer(2.0 * x)
+    lin = (y2 - layer.bias) - 2.0 * (y - layer.bias)
+    assert float(lin.abs().max()) <= 1e-5 * float(y.abs().max())
+    ypad = layer(x[:, :, :1000])
+    xz = x.clone()
+    xz[:, :, 1000:] = 0
+    assert torch.equal(ypad, layer(xz)[:, :, :1000])

@@ -197,3 +197,58 @@ def test_max_pool_local_semantics():
     nbh = gt.computeNeighborhood(S, 2, 10, 100, "list")
     want = torch.stack([x[:, :, nb].max(dim=2).values for nb in nbh], dim=2)
     assert torch.equal(v, want) and "neighborhood" not in pool.state_dict()
+
+
+# ---- EdgeVariantGF host logic (pattern construction, parameter surface) -------------------------------------------
+def test_edge_pattern_matches_reference_mask():
+    """EdgePattern.from_gso == the oracle's pattern == the support of the reference's masked weights / gradients."""
+    from alegnn_amd import EdgePattern
+    from oracle import evgf_oracle as evo
+    for name in ("evgf_asym37_hybrid", "evgf_asym_E2_hybrid", "evgf_asym37_full"):
+        d = load(os.path.join(GOLDEN, name + ".npz"))
+        S, M = d["S"], int(d["M"])
+        for e in range(S.shape[0]):
+            p = EdgePattern.from_gso(S[e], M)
+            want = evo.ev_pattern(S[e], M)
+            assert np.array_equal(p.indptr, want.indptr) and np.array_equal(p.indices, want.indices)
+            support = np.any(d["dweightEV"][:, e, 1:] != 0, axis=(0, 1, 2))      # entries the reference trains
+            mine = np.zeros_like(support)
+            mine[p.rows, p.cols] = True
+            assert not np.any(support & ~mine), "the reference trains an entry outside our pattern"
+    L = _lib.lib()
+    out = ctypes.c_void_p()
+    rowptr = np.array([0, 2, 3], dtype=np.int32)
+    col = np.array([1, 0, 1], dtype=np.int32)               # row 0 not ascending
+    assert L.gf_ev_plan_create(2, 3, rowptr.ctypes.data, col.ctypes.data, ctypes.byref(out)) == _lib.GF_ERR_SHAPE
+    assert b"ascending" in L.gf_last_error()
+    assert L.gf_evgf_scratch_floats(16, 32, 32, 50000, 1) == 50000 * 16 * (64 + 32 + 2 * 1024)
+
+
+def test_edge_variant_gf_surface_matches_reference():
+    d = load(os.path.join(GOLDEN, "evgf_asym37_hybrid.npz"))
+    F, E, K, G, N, _ = d["weightEV"].shape
+    M = int(d["M"])
+    layer = gml.EdgeVariantGF(G, F, K, M, N, E, True)
+    assert {k: tuple(v.shape) for k, v in layer.state_dict().items()} == {
+        "weightEV": (F, E, K, G, N, N), "weightLSI": (F, E, K, G), "bias": (F, 1)}    # graphML.py:2585-2595
+    full = gml.EdgeVariantGF(G, F, K, N, N, E, False)
+    assert full.weightLSI is None and full.bias is None
+    assert "GSO stored" not in repr(layer).replace("no GSO stored", "")
+    layer.addGSO(torch.tensor(d["S"]))
+    assert "selected_nodes=%d" % M in repr(layer) and repr(layer).endswith("GSO stored)")
+    with pytest.raises(AssertionError):
+        layer.addGSO(torch.zeros(E + 1, N, N))              # graphML.py:2612
+    # per-edge gather of the dense parameter == what the oracle extracts == what the reference's mask keeps
+    from oracle import evgf_oracle as evo
+    layer.load_state_dict({"weightEV": torch.tensor(d["weightEV"]), "weightLSI": torch.tensor(d["weightLSI"]),
+                           "bias": torch.tensor(d["bias"])})
+    ar, rows, cols, dmask = layer._indices(0, torch.device("cpu"))
+    w = layer.weightEV[:, 0]
+    wdiag, wedge = evo.ev_split_dense_weight(d["weightEV"][:, 0], evo.ev_pattern(d["S"][0], M), M)
+    assert np.array_equal((w[:, 0][:, :, ar, ar] * dmask).detach().numpy(), wdiag.astype(np.float32))
+    assert np.array_equal(w[:, 1:][:, :, :, rows, cols].detach().numpy(), wedge.astype(np.float32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.zeros(2, G, N))
+    sparse = gml.EdgeVariantGF(G, F, K, M, N, E, True, sparse=True)
+    sparse.addGSO(torch.tensor(d["S"]))
+    assert tuple(sparse.weightEVedges[0].shape) == (F, K - 1, G, layer._patterns[0].nnzp)
