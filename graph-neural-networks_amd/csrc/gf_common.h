@@ -65,7 +65,23 @@ struct gf_csr_dev {
     int2* sell_ent = nullptr;       // [sell_kptr[n_slices] * 8]
     int32_t* sell_rowid = nullptr;  // [n_slices * 8]  stored position -> original row, -1 past the last row
     int64_t sell_pad_entries = 0;   // padding entries (wasted gathers), for diagnostics
+    // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes: rows in NATURAL order (stores stay coalesced, no
+    // node permutation anywhere), slices of 64 consecutive rows = one wavefront, lane = row.  Step k of slice s holds the
+    // entries of the rows with more than k neighbours, compacted in lane order:
+    //   entry of (slice s, step k, lane l) = pn_slice[s].x + sum_{k' < k} active(k') + rank of l among the active lanes.
+    // Columns are 16-bit (N <= 65536), values fp32 in a separate stream; pn_uniform: every stored value equals pn_uval
+    // (adjacency / lambda_max of an unweighted graph) and the value stream is not read at all.
+    int32_t pn_slices = 0;          // 0 = no panel image
+    int2* pn_slice = nullptr;       // [pn_slices]  {entry offset, width = longest row of the slice}
+    uint16_t* pn_deg = nullptr;     // [pn_slices * 64]  neighbours per row (0 past the last row)
+    uint16_t* pn_col = nullptr;     // [nnz]
+    float* pn_val = nullptr;        // [nnz]
+    int32_t pn_uniform = 0;
+    float pn_uval = 0.f;
+    double pn_conflict = 0.0;       // expected LDS cycles per ds_read_b128 step after the bank-aware ordering (diagnostic)
 };
+constexpr int32_t kPanelMaxNodes = 10240;   // 16 bytes per node in 160 KiB of LDS
+constexpr int32_t kPanelMaxDeg = 65535;
 
 struct gf_plan {
     int32_t n = 0;
@@ -87,13 +103,23 @@ struct gf_tuning {
     int spmm_algo = 0;          // 0 = SELL-8 persistent wave kernel, 1 = CSR workgroup-staged kernel (first version)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
     int spmm_ucap = 0;          // 0/16 = up to 16 gathers in flight per lane, 8 = up to 8 (fewer registers, more waves)
-    int spmm_pf = 0;            // workgroups per tile that prefetch the next tile's gather panel into L2 (0 = off)
+    int spmm_pf = -1;           // workgroups per tile that prefetch the next tile's gather panel into L2 (-1 = heuristic, 0 = off)
     int spmm_load = 0;          // gather loads: 0 = plain, 1 = non-temporal
-    int spmm_store = 1;         // output rows: 0 = plain stores, 1 = write-through (sc1), 2 = non-temporal
+    int spmm_store = 2;         // output rows: 0 = plain stores, 1 = write-through (sc1), 2 = non-temporal
     int contract_generic = 0;   // 1 = force the generic contraction kernel
+    int pipeline = 0;           // 0 = auto, 1 = node-major (gather through L2), 2 = column panels through LDS (needs N <= 10240, G%8 == F%8 == 0)
+    int panel_uniform = 1;      // 1 = use the value-free stream when the plan detected uniform values
+    int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
+    int panel_compute_waves = 8;  // of the 16 waves of a panel workgroup; the rest prefetch the next panel
 };
 extern gf_tuning g_tune;
 
 // internal launchers shared between translation units
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
                        int F, int E, int K, int transpose_bank, hipStream_t st);
+// column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)
+bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F);
+int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st);
+int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st);
+int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
+                             int F, int E, int K, int transpose_bank, hipStream_t st);

@@ -375,11 +375,12 @@ __global__ __launch_bounds__(kThreads) void spmm_hop_generic_kernel(const int32_
 // ------------------------------------------------------------------------------------------------------------------
 int pick_bt(int N, int W, int B, int bl) {
     if (g_tune.spmm_bt == 1 || g_tune.spmm_bt == 2 || g_tune.spmm_bt == 4) return g_tune.spmm_bt;
-    // Two consecutive batch tiles are live in an XCD's L2 while its waves cross a tile boundary: keep 2 gather panels
-    // (N*W*4 bytes per batch entry each) inside ~3 of the 4 MiB.
+    // Measured (profiles/r01_g_evgf_and_prefetch/sweep.log): while the gather panel of a tile (N*W*4*bl*bt bytes) plus the
+    // prefetched next one fit the XCD's 4 MiB L2, two batch entries per lane amortise the (col, val) stream best;
+    // a panel larger than L2 (N = 1e5: 12.8 MB) wants the smallest tile.
     const int64_t panel = (int64_t)N * W * 4 * bl;
     int bt = 1;
-    if (panel * 2 * 2 <= (3 << 20) && B >= 16 * bl) bt = 2;
+    if (panel * 2 <= (3 << 20) && B >= 16 * bl) bt = 2;
     if (panel * 4 * 2 <= (3 << 20) && B >= 32 * bl) bt = 4;
     return bt;
 }
@@ -400,9 +401,13 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     // structure (every XCD works on the same tile).
     const int lanes = !g_tune.spmm_xcd ? 1 : (nBTiles >= 8 ? 8 : nBTiles);
     const int parts = 8 / lanes;
-    const int spw = (g_tune.spmm_spw == 1 || g_tune.spmm_spw == 2 || g_tune.spmm_spw == 4) ? g_tune.spmm_spw : 2;
+    const int64_t tileBytes = (int64_t)N * W * 4 * BL * bt;
+    const bool l2_resident = tileBytes * 2 <= (6 << 20);  // this tile's panel + the prefetched next one
+    const int spw = (g_tune.spmm_spw == 1 || g_tune.spmm_spw == 2 || g_tune.spmm_spw == 4) ? g_tune.spmm_spw : (l2_resident ? 1 : 2);
     const int sliceShare = (m.n_slices + parts - 1) / parts;
-    const int pf = (g_tune.spmm_pf >= 0 && tilesPerLaneOf(nBTiles, lanes) > 1) ? g_tune.spmm_pf : 0;
+    // spmm_pf: -1 = heuristic (24 prefetch workgroups per tile while panels are L2-resident, none otherwise), >= 0 = forced
+    const int pf_want = g_tune.spmm_pf >= 0 ? g_tune.spmm_pf : (l2_resident ? 24 : 0);
+    const int pf = tilesPerLaneOf(nBTiles, lanes) > 1 ? pf_want : 0;
     const int blocksPerTile = (sliceShare + 4 * spw - 1) / (4 * spw) + pf;
     const int tilesPerLane = (nBTiles + lanes - 1) / lanes;
     const int64_t nblk = (int64_t)8 * tilesPerLane * blocksPerTile;

@@ -37,7 +37,7 @@ for name in (sys.argv[1:] or ["cfg2", "cfg4"]):
     for bt, spw, store, pf, ucap in itertools.product((1, 2), (1, 2), (1, 2), (0, 6, 10, 16, 24), (8, 16)):
         tune(spmm_algo=0, spmm_bt=bt, spmm_spw=spw, spmm_xcd=1, spmm_store=store, spmm_load=0, spmm_ucap=ucap, spmm_pf=pf)
         rows.append((time_hop(plans[0], X0, X1, B, W), f"algo=sell bt={bt} spw={spw} store={store} pf={pf} ucap={ucap}"))
-    tune(spmm_algo=0, spmm_bt=0, spmm_spw=0, spmm_xcd=1, spmm_store=1, spmm_load=0, spmm_ucap=0, spmm_pf=0)
+    tune(spmm_algo=0, spmm_bt=0, spmm_spw=0, spmm_xcd=1, spmm_store=2, spmm_load=0, spmm_ucap=0, spmm_pf=-1)
     rows.append((time_hop(plans[0], X0, X1, B, W), "DEFAULT (heuristics)"))
     for ms, label in sorted(rows):
         print(f"  {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s  {100*nbytes/ms/1e6/8000:5.1f}%  {label}")
