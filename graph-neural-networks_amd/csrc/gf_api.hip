@@ -7,7 +7,45 @@
 // The backward data path uses  dx = sum_{e,k} (dY H_{e,k}^T) (S_e^T)^k = sum_{e,k} ((S_e)^k-hop of dY) H_{e,k}^T :
 // hopping the F-wide dY and contracting once costs 2(K-1)+K+1 signal passes instead of the K+3(K-1) of the
 // Horner form on dZ, and reuses the forward kernels unchanged.
+//
+// Two interchangeable pipelines produce bit-for-bit the same interface (x, dy, y, dx in the reference layout; Z / P opaque):
+//   node-major  Z[T][B][N][G]        gathers served by L2            (gf_spmm.hip)     any N, any widths
+//   panels      Z[T][B*G/4][N][4]    gathers served by LDS           (gf_panel.hip)    N <= 10239, G % 8 == F % 8 == 0
+// gf_lsigf_pipeline() tells which one a (plans, G, F) combination runs; forward and backward always agree because the rule
+// depends only on those arguments (and the process-global tuning knob "pipeline").
 #include "gf_common.h"
+
+namespace {
+
+int pick_pipeline(const gf_plan* const* plans, int E, int G, int F) {  // 1 = node-major, 2 = panels, < 0 = error
+    const bool ok = gf_panel_supported(plans, E, G, F);
+    if (g_tune.pipeline == 2 && !ok) {
+        gf_set_error("pipeline 2 (column panels) forced but unsupported here: needs N in [8, %d], G %% 8 == F %% 8 == 0, widths <= 128",
+                     kPanelMaxNodes);
+        return GF_ERR_UNSUPPORTED;
+    }
+    if (g_tune.pipeline == 1) return 1;
+    return ok ? 2 : 1;
+}
+
+int khop_panel(const gf_plan* const* plans, int E, int op, float* Zp, int B, int W, int K, hipStream_t st) {
+    const int64_t tap = (int64_t)B * plans[0]->n * W;
+    for (int e = 0; e < E; ++e)
+        for (int k = 1; k < K; ++k) {
+            const float* src = (k == 1) ? Zp : Zp + (int64_t)(1 + e * (K - 1) + (k - 2)) * tap;
+            float* dst = Zp + (int64_t)(1 + e * (K - 1) + (k - 1)) * tap;
+            const int rc = gf_spmm_panel_launch(plans[e], op, src, dst, B * (W / 4), st);
+            if (rc != GF_OK) return rc;
+        }
+    return GF_OK;
+}
+
+}  // namespace
+
+extern "C" int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t G, int32_t F) {
+    GF_REQUIRE_ARG(plans && E > 0 && plans[0], "gf_lsigf_pipeline: NULL plans");
+    return pick_pipeline(plans, E, G, F);
+}
 
 extern "C" int gf_lsigf_forward(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias,
                                 float* Z, float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
@@ -17,6 +55,19 @@ extern "C" int gf_lsigf_forward(const gf_plan* const* plans, int32_t E, const fl
     GF_REQUIRE_ARG(plans[0] != nullptr, "gf_lsigf_forward: plan 0 is NULL");
     const int N = plans[0]->n;
     GF_REQUIRE_SHAPE(Nin <= N, "gf_lsigf_forward: input has %d nodes, GSO has %d", Nin, N);  // graphML.py:2131 only pads
+    for (int e = 0; e < E; ++e) {
+        GF_REQUIRE_ARG(plans[e] != nullptr, "gf_lsigf_forward: plan %d is NULL", e);
+        GF_REQUIRE_SHAPE(plans[e]->n == N, "gf_lsigf_forward: plan %d has %d nodes, plan 0 has %d", e, plans[e]->n, N);
+    }
+    const int pipe = pick_pipeline(plans, E, G, F);
+    if (pipe < 0) return pipe;
+    if (pipe == 2) {
+        int rc = gf_pack_panels_launch(x, Z, B, G, Nin, N, gf_stream(stream));
+        if (rc != GF_OK) return rc;
+        rc = khop_panel(plans, E, GF_OP_FWD, Z, B, G, K, gf_stream(stream));
+        if (rc != GF_OK) return rc;
+        return gf_contract_panel_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank=*/0, gf_stream(stream));
+    }
     int rc = gf_layout_bgn_to_bng(x, Z, B, G, Nin, N, stream);
     if (rc != GF_OK) return rc;
     rc = gf_khop(plans, E, GF_OP_FWD, Z, B, G, K, stream);
@@ -33,6 +84,27 @@ extern "C" int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const f
     GF_REQUIRE_ARG(plans[0] != nullptr, "gf_lsigf_backward: plan 0 is NULL");
     const int N = plans[0]->n;
     GF_REQUIRE_SHAPE(Nin <= N, "gf_lsigf_backward: gradient has %d nodes, GSO has %d", Nin, N);
+    for (int e = 0; e < E; ++e) {
+        GF_REQUIRE_ARG(plans[e] != nullptr, "gf_lsigf_backward: plan %d is NULL", e);
+        GF_REQUIRE_SHAPE(plans[e]->n == N, "gf_lsigf_backward: plan %d has %d nodes, plan 0 has %d", e, plans[e]->n, N);
+    }
+    const int pipe = pick_pipeline(plans, E, G, F);
+    if (pipe < 0) return pipe;
+    if (pipe == 2) {
+        int rc = gf_pack_panels_launch(dy, P, B, F, Nin, N, gf_stream(stream));  // P[0] = dy as panels, rows >= Nin zero
+        if (rc != GF_OK) return rc;
+        if (dh || dbias) {
+            GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
+            rc = gf_grad_taps_panel(Z, P, dh, dbias, workspace, workspace_bytes, B, N, G, F, E, K, stream);
+            if (rc != GF_OK) return rc;
+        }
+        if (dx) {
+            rc = khop_panel(plans, E, GF_OP_BWD, P, B, F, K, gf_stream(stream));
+            if (rc != GF_OK) return rc;
+            rc = gf_contract_panel_launch(P, h, nullptr, dx, B, N, Nin, G, F, E, K, /*transpose_bank=*/1, gf_stream(stream));
+        }
+        return rc;
+    }
     int rc = gf_layout_bgn_to_bng(dy, P, B, F, Nin, N, stream);  // P[0] = dy, node-major, rows >= Nin zero
     if (rc != GF_OK) return rc;
     if (dh || dbias) {

@@ -66,21 +66,24 @@ struct gf_csr_dev {
     int32_t* sell_rowid = nullptr;  // [n_slices * 8]  stored position -> original row, -1 past the last row
     int64_t sell_pad_entries = 0;   // padding entries (wasted gathers), for diagnostics
     // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes: rows in NATURAL order (stores stay coalesced, no
-    // node permutation anywhere), slices of 64 consecutive rows = one wavefront, lane = row.  Step k of slice s holds the
-    // entries of the rows with more than k neighbours, compacted in lane order:
-    //   entry of (slice s, step k, lane l) = pn_slice[s].x + sum_{k' < k} active(k') + rank of l among the active lanes.
-    // Columns are 16-bit (N <= 65536), values fp32 in a separate stream; pn_uniform: every stored value equals pn_uval
-    // (adjacency / lambda_max of an unweighted graph) and the value stream is not read at all.
+    // node permutation anywhere), slices of 64 consecutive rows = one wavefront, lane = row.  Entries are stored in GROUPS of
+    // 4 steps: group j of a lane = its neighbours 4j .. 4j+3 (4 x 16-bit columns = 8 bytes, 4 x fp32 values = 16 bytes,
+    // slots past the row's end = {column N, value 0}).  Group-step j of slice s holds the groups of the lanes that still
+    // have a neighbour at step 4j, compacted in lane order:
+    //   group of (slice s, group-step j, lane l) = pn_slice[s].x + sum_{j' < j} active(j') + rank of l among the active lanes.
+    // pn_uniform: every stored value equals pn_uval (adjacency / lambda_max of an unweighted graph): the value stream is not read.
     int32_t pn_slices = 0;          // 0 = no panel image
-    int2* pn_slice = nullptr;       // [pn_slices]  {entry offset, width = longest row of the slice}
+    int2* pn_slice = nullptr;       // [pn_slices]  {group offset, group-steps = ceil(longest row / 4)}
     uint16_t* pn_deg = nullptr;     // [pn_slices * 64]  neighbours per row (0 past the last row)
-    uint16_t* pn_col = nullptr;     // [nnz]
-    float* pn_val = nullptr;        // [nnz]
+    int32_t* pn_row = nullptr;      // [pn_slices * 64]  row handled by (slice, lane); -1 = none
+    uint2* pn_col4 = nullptr;       // [groups + 1]
+    float4* pn_val4 = nullptr;      // [groups + 1]
+    int32_t pn_sentinel = 0;        // index of the sentinel group {columns N, values 0} that follows the last real group
     int32_t pn_uniform = 0;
     float pn_uval = 0.f;
     double pn_conflict = 0.0;       // expected LDS cycles per ds_read_b128 step after the bank-aware ordering (diagnostic)
 };
-constexpr int32_t kPanelMaxNodes = 10240;   // 16 bytes per node in 160 KiB of LDS
+constexpr int32_t kPanelMaxNodes = 10239;   // 16 bytes per node + one zero slot in 160 KiB of LDS
 constexpr int32_t kPanelMaxDeg = 65535;
 
 struct gf_plan {
@@ -107,10 +110,11 @@ struct gf_tuning {
     int spmm_load = 0;          // gather loads: 0 = plain, 1 = non-temporal
     int spmm_store = 2;         // output rows: 0 = plain stores, 1 = write-through (sc1), 2 = non-temporal
     int contract_generic = 0;   // 1 = force the generic contraction kernel
-    int pipeline = 0;           // 0 = auto, 1 = node-major (gather through L2), 2 = column panels through LDS (needs N <= 10240, G%8 == F%8 == 0)
+    int pipeline = 0;           // 0 = auto, 1 = node-major (gather through L2), 2 = column panels through LDS (needs N <= 10239, G%8 == F%8 == 0)
     int panel_uniform = 1;      // 1 = use the value-free stream when the plan detected uniform values
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
-    int panel_compute_waves = 8;  // of the 16 waves of a panel workgroup; the rest prefetch the next panel
+    int panel_sort = 0;         // 1 = panel image processes rows in descending-degree order (set BEFORE gf_plan_create)
+    int panel_pace = 4;         // HBM loads a panel loader wave keeps in flight: 1 | 2 | 4 | 8 | 0 = unpaced (all 20)
 };
 extern gf_tuning g_tune;
 

@@ -173,6 +173,134 @@ void launch_stage1(const Geo& g, const float* Z, const float* P0, float* ws, int
                        ws + g.off_partial_b, g.R, G, F, g.numGI, g.numCT, g.numFT, g.passes, g.rowsPerWave);
 }
 
+
+// ---- column-panel variant of stage 1: Z is Zp[T][B][G/4][N][4], P0 is P0p[B][F/4][N][4] (gf_panel.hip).  Same strips, same
+// accumulators, same partial layout (stages 2/3 are shared); only the operand addresses change: lane l31 = g (or f) reads
+// component g % 4 of panel g / 4, so the 32 lanes of a half wave cover 8 panels x 16 bytes of one node and the four steps
+// of an 8-row round walk each panel's 128-byte line once (L1-resident between the four loads).
+template <int CTP>
+__global__ __launch_bounds__(kThreads) void grad_taps_panel_kernel(const float* __restrict__ Zp, const float* __restrict__ P0p,
+                                                                   float* __restrict__ partial, float* __restrict__ partial_b,
+                                                                   int R, int N, int B, int G, int F, int numGI, int numCT, int numFT,
+                                                                   int passes, int rowsPerWave) {
+    const int pass = blockIdx.y;
+    const int ft = pass % numFT, cpass = pass / numFT;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wg = blockIdx.x * kWaves + wave;
+    const int r_begin = wg * rowsPerWave;  // R < 2^31 (checked by the launcher)
+    const int r_end = min(R, r_begin + rowsPerWave);
+    const int QG = G / 4, QF = F / 4;
+    const int64_t N4 = (int64_t)N * 4;
+
+    const int f = ft * 32 + l31;
+    const bool fvalid = f < F;
+    const float* pp = P0p + (fvalid ? (int64_t)(f >> 2) * N4 + (f & 3) : 0);
+    const float* zp[CTP];
+    bool gvalid[CTP];
+#pragma unroll
+    for (int j = 0; j < CTP; ++j) {
+        const int ct = cpass * CTP + j;
+        const int t = ct / numGI, gi = ct - t * numGI;
+        const int g = gi * 32 + l31;
+        gvalid[j] = (ct < numCT) && (g < G);
+        zp[j] = Zp + (gvalid[j] ? ((int64_t)t * B * QG + (g >> 2)) * N4 + (g & 3) : 0);
+    }
+    f32x16 acc[CTP];
+#pragma unroll
+    for (int j = 0; j < CTP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum = 0.f;
+
+    for (int r0 = r_begin; r0 < r_begin + rowsPerWave; r0 += 8) {
+        float p[4], a[4][CTP];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = r0 + 2 * s + half;
+            const bool rv = r < r_end;
+            const int b = rv ? r / N : 0;
+            const int n = rv ? r - b * N : 0;
+            const int64_t zoff = (int64_t)b * QG * N4 + (int64_t)n * 4;
+            const int64_t poff = (int64_t)b * QF * N4 + (int64_t)n * 4;
+            p[s] = (rv && fvalid) ? pp[poff] : 0.f;
+#pragma unroll
+            for (int j = 0; j < CTP; ++j) a[s][j] = (rv && gvalid[j]) ? zp[j][zoff] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bsum += p[s];
+#pragma unroll
+            for (int j = 0; j < CTP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][j], p[s], acc[j], 0, 0, 0);
+        }
+    }
+
+    float* pt = partial + ((int64_t)wg * passes + pass) * CTP * 1024;
+#pragma unroll
+    for (int j = 0; j < CTP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            pt[j * 1024 + i * 32 + l31] = acc[j][r];
+        }
+    if (cpass == 0) {
+        const float other = __shfl_xor(bsum, 32, 64);
+        if (half == 0) partial_b[((int64_t)wg * numFT + ft) * 32 + l31] = bsum + other;
+    }
+}
+
+template <int CTP>
+void launch_stage1_panel(const Geo& g, const float* Zp, const float* P0p, float* ws, int N, int B, int G, int F, hipStream_t st) {
+    hipLaunchKernelGGL((grad_taps_panel_kernel<CTP>), dim3(g.strips, g.passes), dim3(kThreads), 0, st, Zp, P0p, ws,
+                       ws + g.off_partial_b, (int)g.R, N, B, G, F, g.numGI, g.numCT, g.numFT, g.passes, g.rowsPerWave);
+}
+
+int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, int E, int K, hipStream_t st) {
+    const int wavesPadded = g.strips * kWaves;
+    const int slices = wavesPadded < kSlices ? wavesPadded : kSlices;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((g.tileOutputs + kThreads - 1) / kThreads), slices), dim3(kThreads), 0,
+                       st, ws, ws + g.off_mid, wavesPadded, g.tileOutputs, slices);
+    GF_LAUNCH_CHECK("reduce_rows_kernel(taps)");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((g.biasOutputs + kThreads - 1) / kThreads), slices), dim3(kThreads), 0,
+                       st, ws + g.off_partial_b, ws + g.off_mid_b, wavesPadded, g.biasOutputs, slices);
+    GF_LAUNCH_CHECK("reduce_rows_kernel(bias)");
+    const int64_t tot = g.tileOutputs + g.biasOutputs;
+    hipLaunchKernelGGL(finalize_taps_kernel, dim3((unsigned)((tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                       ws + g.off_mid, ws + g.off_mid_b, dh, dbias, g.tileOutputs, (int)g.biasOutputs, slices, G, F, E, K,
+                       g.numGI, g.numCT, g.numFT, g.ctp);
+    GF_LAUNCH_CHECK("finalize_taps_kernel");
+    return GF_OK;
+}
+
+}  // namespace
+
+extern "C" int gf_grad_taps_panel(const float* Zp, const float* P0p, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
+                                  int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K, void* stream) {
+    GF_REQUIRE_ARG(Zp && P0p && workspace, "gf_grad_taps_panel: NULL tensor");
+    GF_REQUIRE_ARG(dh || dbias, "gf_grad_taps_panel: nothing to compute (dh and dbias both NULL)");
+    GF_REQUIRE_SHAPE(B > 0 && N > 0 && G > 0 && F > 0 && E > 0 && K > 0 && G % 4 == 0 && F % 4 == 0,
+                     "gf_grad_taps_panel: bad shape B=%d N=%d G=%d F=%d E=%d K=%d (G, F multiples of 4)", B, N, G, F, E, K);
+    const Geo g = make_geo(B, N, G, F, E, K);
+    GF_REQUIRE_SHAPE(g.R < (int64_t)INT32_MAX - 4096, "gf_grad_taps_panel: B*N = %lld too large", (long long)g.R);
+    GF_REQUIRE_ARG(workspace_bytes >= g.bytes, "gf_grad_taps_panel: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
+    GF_REQUIRE_SHAPE(g.passes <= 65535, "gf_grad_taps_panel: %d passes exceed the grid limit", g.passes);
+    hipStream_t st = gf_stream(stream);
+    float* ws = (float*)workspace;
+    switch (g.ctp) {
+        case 1: launch_stage1_panel<1>(g, Zp, P0p, ws, N, B, G, F, st); break;
+        case 2: launch_stage1_panel<2>(g, Zp, P0p, ws, N, B, G, F, st); break;
+        case 3: launch_stage1_panel<3>(g, Zp, P0p, ws, N, B, G, F, st); break;
+        case 4: launch_stage1_panel<4>(g, Zp, P0p, ws, N, B, G, F, st); break;
+        case 5: launch_stage1_panel<5>(g, Zp, P0p, ws, N, B, G, F, st); break;
+        case 6: launch_stage1_panel<6>(g, Zp, P0p, ws, N, B, G, F, st); break;
+        case 7: launch_stage1_panel<7>(g, Zp, P0p, ws, N, B, G, F, st); break;
+        default: launch_stage1_panel<8>(g, Zp, P0p, ws, N, B, G, F, st); break;
+    }
+    GF_LAUNCH_CHECK("grad_taps_panel_kernel");
+    return finish_taps(g, ws, dh, dbias, G, F, E, K, st);
+}
+
+namespace {
 }  // namespace
 
 extern "C" size_t gf_grad_taps_workspace_bytes(int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K) {
@@ -202,18 +330,5 @@ extern "C" int gf_grad_taps(const float* Z, const float* P0, float* dh, float* d
         default: launch_stage1<8>(g, Z, P0, ws, G, F, st); break;
     }
     GF_LAUNCH_CHECK("grad_taps_kernel");
-    const int wavesPadded = g.strips * kWaves;
-    const int slices = wavesPadded < kSlices ? wavesPadded : kSlices;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((g.tileOutputs + kThreads - 1) / kThreads), slices), dim3(kThreads), 0,
-                       st, ws, ws + g.off_mid, wavesPadded, g.tileOutputs, slices);
-    GF_LAUNCH_CHECK("reduce_rows_kernel(taps)");
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((g.biasOutputs + kThreads - 1) / kThreads), slices), dim3(kThreads), 0,
-                       st, ws + g.off_partial_b, ws + g.off_mid_b, wavesPadded, g.biasOutputs, slices);
-    GF_LAUNCH_CHECK("reduce_rows_kernel(bias)");
-    const int64_t tot = g.tileOutputs + g.biasOutputs;
-    hipLaunchKernelGGL(finalize_taps_kernel, dim3((unsigned)((tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-                       ws + g.off_mid, ws + g.off_mid_b, dh, dbias, g.tileOutputs, (int)g.biasOutputs, slices, G, F, E, K,
-                       g.numGI, g.numCT, g.numFT, g.ctp);
-    GF_LAUNCH_CHECK("finalize_taps_kernel");
-    return GF_OK;
+    return finish_taps(g, ws, dh, dbias, G, F, E, K, st);
 }

@@ -36,6 +36,11 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_pf")) g_tune.spmm_pf = value;
     else if (!strcmp(key, "spmm_ucap")) g_tune.spmm_ucap = value;
     else if (!strcmp(key, "contract_generic")) g_tune.contract_generic = value;
+    else if (!strcmp(key, "pipeline")) g_tune.pipeline = value;
+    else if (!strcmp(key, "panel_uniform")) g_tune.panel_uniform = value;
+    else if (!strcmp(key, "panel_order")) g_tune.panel_order = value;
+    else if (!strcmp(key, "panel_pace")) g_tune.panel_pace = value;
+    else if (!strcmp(key, "panel_sort")) g_tune.panel_sort = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);
         return GF_ERR_ARG;
@@ -139,6 +144,8 @@ int upload(const std::vector<T>& h, T** d, int64_t& bytes) {
     return GF_OK;
 }
 
+int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes);
+
 int upload_csr(int32_t n, const HostCsr& a, bool sorted, gf_csr_dev& d, int64_t& bytes) {
     HostCsr s;
     std::vector<int32_t> rowid;
@@ -173,6 +180,136 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, gf_csr_dev& d, int64_t&
     if ((rc = upload(kptr, &d.sell_kptr, bytes))) return rc;
     if ((rc = upload(ent, &d.sell_ent, bytes))) return rc;
     if ((rc = upload(rid, &d.sell_rowid, bytes))) return rc;
+    return upload_panel(n, a, d, bytes);
+}
+
+// ---- panel (LDS) image: natural row order, slices of 64 rows, steps compacted (see gf_common.h) -------------------------
+// ds_read_b128 is serviced in four 16-lane groups; within a group, lanes whose 16-byte slots fall on the same bank quad
+// (column mod 16) with different addresses serialise.  The order in which a row visits its neighbours is free (it only
+// fixes the summation order), so step by step each lane picks, among its remaining neighbours, one whose quad is still
+// unused in its group (or an address another lane already reads: broadcast).  Greedy, most-constrained lanes first.
+const int kB128Group[64] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
+                            2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3};
+
+int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
+    if (n > kPanelMaxNodes) return GF_OK;
+    for (int32_t i = 0; i < n; ++i)
+        if (a.rowptr[i + 1] - a.rowptr[i] > kPanelMaxDeg) return GF_OK;  // hub row longer than a 16-bit count: no panel image
+    const int32_t ns = (n + 63) / 64;
+    std::vector<int2> slice(ns);
+    std::vector<uint16_t> deg((size_t)ns * 64, 0);
+    // processing order of the rows: natural (lane = row: coalesced 1 KiB stores, ~1.85x issue-slot padding on Poisson
+    // degrees) or sorted by descending degree (slices of near-equal rows; each lane stores its own 16 bytes)
+    std::vector<int32_t> prow((size_t)ns * 64, -1);
+    for (int32_t i = 0; i < n; ++i) prow[i] = i;
+    if (g_tune.panel_sort)
+        std::stable_sort(prow.begin(), prow.begin() + n, [&](int32_t x, int32_t y) {
+            return (a.rowptr[x + 1] - a.rowptr[x]) > (a.rowptr[y + 1] - a.rowptr[y]);
+        });
+    std::vector<uint2> col4;   // 4 x 16-bit columns per (lane, group of 4 steps)
+    std::vector<float4> val4;
+    col4.reserve(a.col.size() / 3);
+    val4.reserve(a.val.size() / 3);
+    const bool reorder = g_tune.panel_order != 0;
+    double cycles = 0.0;
+    int64_t steps = 0;
+    std::vector<std::vector<int32_t>> rest(64);  // remaining entry indices (into a.col / a.val) per lane
+    std::vector<int32_t> picks;                  // [step][lane] chosen entry (-1 = row exhausted)
+    for (int32_t sl = 0; sl < ns; ++sl) {
+        int32_t w = 0;
+        for (int l = 0; l < 64; ++l) {
+            rest[l].clear();
+            const int32_t r = prow[(size_t)sl * 64 + l];
+            if (r >= 0) {
+                for (int32_t q = a.rowptr[r]; q < a.rowptr[r + 1]; ++q) rest[l].push_back(q);
+                deg[(size_t)sl * 64 + l] = (uint16_t)rest[l].size();
+                w = std::max<int32_t>(w, (int32_t)rest[l].size());
+            }
+        }
+        const int32_t gmax = (w + 3) / 4;
+        slice[sl] = make_int2((int32_t)col4.size(), gmax);
+        picks.assign((size_t)gmax * 4 * 64, -1);
+        for (int32_t k = 0; k < w; ++k) {
+            int quadCols[4][16][4];  // per service group, per bank quad: distinct columns already read (up to 4 tracked)
+            int quadCnt[4][16];
+            for (int g = 0; g < 4; ++g)
+                for (int qd = 0; qd < 16; ++qd) quadCnt[g][qd] = 0;
+            int order[64], no = 0;
+            for (int l = 0; l < 64; ++l)
+                if (!rest[l].empty()) order[no++] = l;
+            if (reorder)  // most-constrained first: lanes with the fewest remaining neighbours choose first
+                std::stable_sort(order, order + no, [&](int x, int y) { return rest[x].size() < rest[y].size(); });
+            for (int oi = 0; oi < no; ++oi) {
+                const int l = order[oi], g = kB128Group[l];
+                size_t best = 0;
+                if (reorder) {
+                    int bestCost = 1 << 30;
+                    for (size_t j = 0; j < rest[l].size(); ++j) {
+                        const int c = a.col[rest[l][j]], qd = c & 15;
+                        int cost = quadCnt[g][qd];
+                        for (int t = 0; t < quadCnt[g][qd] && t < 4; ++t)
+                            if (quadCols[g][qd][t] == c) cost = 0;  // same address: broadcast
+                        if (cost < bestCost) {
+                            bestCost = cost;
+                            best = j;
+                            if (cost == 0) break;
+                        }
+                    }
+                }
+                const int32_t q = rest[l][best];
+                rest[l].erase(rest[l].begin() + best);
+                picks[(size_t)k * 64 + l] = q;
+                const int c = a.col[q], qd = c & 15;
+                bool seen = false;
+                for (int t = 0; t < quadCnt[g][qd] && t < 4; ++t) seen = seen || quadCols[g][qd][t] == c;
+                if (!seen) {
+                    if (quadCnt[g][qd] < 4) quadCols[g][qd][quadCnt[g][qd]] = c;
+                    quadCnt[g][qd]++;
+                }
+            }
+            for (int g = 0; g < 4; ++g) {
+                int mx = 1;
+                for (int qd = 0; qd < 16; ++qd) mx = std::max(mx, quadCnt[g][qd]);
+                cycles += mx;
+            }
+            steps++;
+        }
+        // emit: group j (steps 4j .. 4j+3) of every lane that still has a neighbour at step 4j, in lane order (the kernel's
+        // ballot + mbcnt rank); slots past the end of a row hold {column N = the LDS zero slot, value 0}
+        for (int32_t j = 0; j < gmax; ++j)
+            for (int l = 0; l < 64; ++l) {
+                if ((int32_t)deg[(size_t)sl * 64 + l] <= 4 * j) continue;
+                uint16_t c[4];
+                float v[4];
+                for (int i = 0; i < 4; ++i) {
+                    const int32_t q = picks[(size_t)(4 * j + i) * 64 + l];
+                    c[i] = q >= 0 ? (uint16_t)a.col[q] : (uint16_t)n;
+                    v[i] = q >= 0 ? a.val[q] : 0.f;
+                }
+                col4.push_back(make_uint2((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)c[2] | ((uint32_t)c[3] << 16)));
+                val4.push_back(make_float4(v[0], v[1], v[2], v[3]));
+            }
+    }
+    d.pn_uniform = 0;
+    d.pn_uval = 0.f;
+    if (!a.val.empty()) {
+        bool uni = true;
+        for (size_t i = 1; i < a.val.size() && uni; ++i) uni = std::memcmp(&a.val[i], &a.val[0], 4) == 0;
+        d.pn_uniform = uni ? 1 : 0;
+        d.pn_uval = a.val[0];
+    }
+    d.pn_conflict = steps ? cycles / (double)steps : 0.0;
+    d.pn_sentinel = (int32_t)col4.size();  // exhausted lanes read this group: columns N (the LDS zero slot), values 0
+    const uint32_t nn = (uint32_t)n | ((uint32_t)n << 16);
+    col4.push_back(make_uint2(nn, nn));
+    val4.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    int rc;
+    if ((rc = upload(slice, &d.pn_slice, bytes))) return rc;
+    if ((rc = upload(deg, &d.pn_deg, bytes))) return rc;
+    if ((rc = upload(prow, &d.pn_row, bytes))) return rc;
+    if ((rc = upload(col4, &d.pn_col4, bytes))) return rc;
+    if ((rc = upload(val4, &d.pn_val4, bytes))) return rc;
+    d.pn_slices = ns;
     return GF_OK;
 }
 
@@ -184,6 +321,11 @@ void free_csr(gf_csr_dev& d) {
     if (d.sell_kptr) (void)hipFree(d.sell_kptr);
     if (d.sell_ent) (void)hipFree(d.sell_ent);
     if (d.sell_rowid) (void)hipFree(d.sell_rowid);
+    if (d.pn_slice) (void)hipFree(d.pn_slice);
+    if (d.pn_deg) (void)hipFree(d.pn_deg);
+    if (d.pn_row) (void)hipFree(d.pn_row);
+    if (d.pn_col4) (void)hipFree(d.pn_col4);
+    if (d.pn_val4) (void)hipFree(d.pn_val4);
     d = gf_csr_dev{};
 }
 
@@ -236,6 +378,15 @@ extern "C" int gf_plan_destroy(gf_plan* pl) {
     free_csr(pl->mat[0]);
     free_csr(pl->mat[1]);
     delete pl;
+    return GF_OK;
+}
+
+extern "C" int gf_plan_panel_info(const gf_plan* pl, int32_t op, int32_t* n_slices, int32_t* uniform, double* lds_cycles_per_step) {
+    GF_REQUIRE_ARG(pl != nullptr && (op == GF_OP_FWD || op == GF_OP_BWD), "gf_plan_panel_info: bad plan / op");
+    const gf_csr_dev& m = pl->mat[op];
+    if (n_slices) *n_slices = m.pn_slices;
+    if (uniform) *uniform = m.pn_uniform;
+    if (lds_cycles_per_step) *lds_cycles_per_step = m.pn_conflict;
     return GF_OK;
 }
 

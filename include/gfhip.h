@@ -106,6 +106,29 @@ int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const float* dy, c
                       float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
                       int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
 
+/* ---- column-panel pipeline: the same hot path with the gathers served from LDS (N <= 10239 nodes; widths multiple of 8).
+ * Layout: Xp[P][N][4], P = B*C/4 panels of 4 consecutive signal columns (b, c..c+3): 16 bytes per node, one panel fills
+ * at most 160 KiB = one CU's LDS.  Tap stack Zp[T][B*C/4][N][4] (same size as the node-major stack).
+ * gf_lsigf_forward / _backward pick this pipeline by themselves (gf_lsigf_pipeline tells which: 1 node-major, 2 panels);
+ * the entry points below expose its stages for tests and profiling. */
+int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t G, int32_t F);
+/* x [B,C,Nin] -> Xp [B*C/4][N][4], nodes n >= Nin zero (GraphFilter.forward's padding, graphML.py:2131-2135); C % 4 == 0 */
+int gf_pack_panels(const float* x, float* Xp, int32_t B, int32_t C, int32_t Nin, int32_t N, void* stream);
+/* Xp [B*C/4][N][4] -> x [B,C,Nout], nodes n < Nout (graphML.py:2142-2143) */
+int gf_unpack_panels(const float* Xp, float* x, int32_t B, int32_t C, int32_t N, int32_t Nout, void* stream);
+/* one hop on n_panels panels: Xout[p] = op(S) Xin[p]   (replaces torch.matmul, graphML.py:159) */
+int gf_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, float* Xout, int32_t n_panels, void* stream);
+int gf_time_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, float* Xout, int32_t n_panels, int32_t iters,
+                           void* stream, float* avg_ms);
+/* as gf_contract / gf_grad_taps with Z (and P0) in panel layout */
+int gf_contract_panel(const float* Zp, const float* h, const float* bias, float* out, int32_t B, int32_t N, int32_t Nout,
+                      int32_t G, int32_t F, int32_t E, int32_t K, int32_t transpose_bank, void* stream);
+int gf_grad_taps_panel(const float* Zp, const float* P0p, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
+                       int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K, void* stream);
+/* panel image of the plan: slices of 64 rows (0 = none, N too large), whether all stored values are equal (value-free
+ * stream), and the modelled LDS cycles per ds_read_b128 step after the bank-aware neighbour ordering (4.0 = conflict-free) */
+int gf_plan_panel_info(const gf_plan* plan, int32_t op, int32_t* n_slices, int32_t* uniform, double* lds_cycles_per_step);
+
 /* ---- edge-variant graph filter, per-edge storage: EVGF (graphML.py:389-488) as called by EdgeVariantGF.forward
  * (graphML.py:2670-2698).  ONE edge feature per call (the host sums over e; EVGF is linear in e).  The reference holds
  * Phi = weightEV * sparsityPatternFull as a dense [F,E,K,G,N,N] tensor; here only the entries its mask keeps exist:
@@ -138,7 +161,9 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * "spmm_bt" (0 = heuristic | 1 | 2 | 4), "spmm_spw" (0 = default | 1 | 2 | 4 slices per wave), "spmm_generic" (0/1),
  * "spmm_algo" (0 = SELL-8 wave kernel | 1 = CSR workgroup kernel), "spmm_xcd" (0/1),
  * "spmm_pf" (workgroups per tile prefetching the next gather panel, -1 = heuristic, 0 = off), "spmm_ucap" (0 | 8 | 16 gathers in flight per lane), "spmm_load" (0 = plain | 1 = non-temporal gather loads),
- * "spmm_store" (0 = plain | 1 = write-through sc1 | 2 = non-temporal output stores), "contract_generic" (0/1).  Process-global, not thread-safe: for benchmarks and tests only. */
+ * "spmm_store" (0 = plain | 1 = write-through sc1 | 2 = non-temporal output stores), "contract_generic" (0/1),
+ * "pipeline" (0 = auto | 1 = node-major | 2 = column panels), "panel_uniform" (0/1 use the value-free stream),
+ * "panel_order" (0/1 bank-aware neighbour order; read by gf_plan_create), "panel_pace" (HBM loads in flight per panel loader wave: 1 | 2 | 4 | 8 | 0 = all).  Process-global, not thread-safe: for benchmarks and tests only. */
 int gf_tune(const char* key, int32_t value);
 
 #ifdef __cplusplus

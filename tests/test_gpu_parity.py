@@ -438,3 +438,178 @@ def test_edge_variant_gf_sparse_parameters_config5_shape():
     xz = x.clone()
     xz[:, :, 1000:] = 0
     assert torch.equal(ypad, layer(xz)[:, :, :1000])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# column-panel pipeline (gathers served from LDS): every stage against numpy, then the whole layer under both pipelines
+# ---------------------------------------------------------------------------------------------------------------
+def tune(**kw):
+    L = _lib.lib()
+    for k, v in kw.items():
+        _lib.check(L.gf_tune(k.encode(), int(v)), "gf_tune " + k)
+
+
+@pytest.fixture
+def pipeline_knob():
+    yield tune
+    tune(pipeline=0, panel_uniform=1, panel_order=1)
+
+
+def to_panels(x, N):
+    """numpy mirror of gf_pack_panels: x [B,C,Nin] -> [B*C/4, N, 4]"""
+    B, C, Nin = x.shape
+    xp = np.zeros((B, C, N), dtype=x.dtype)
+    xp[:, :, :Nin] = x
+    return np.ascontiguousarray(xp.reshape(B, C // 4, 4, N).transpose(0, 1, 3, 2).reshape(B * C // 4, N, 4))
+
+
+@pytest.mark.parametrize("B,C,Nin,N", [(3, 32, 100, 100), (2, 8, 37, 64), (5, 4, 10, 45), (1, 64, 33, 70)])
+def test_pack_unpack_panels(B, C, Nin, N):
+    L = _lib.lib()
+    rng = np.random.RandomState(0)
+    x = rng.randn(B, C, Nin).astype(np.float32)
+    xt = cu(x)
+    Xp = torch.full((B * C // 4, N, 4), float("nan"), device=DEV)
+    _lib.check(L.gf_pack_panels(xt.data_ptr(), Xp.data_ptr(), B, C, Nin, N, stream()))
+    assert np.array_equal(Xp.cpu().numpy(), to_panels(x, N))
+    back = torch.empty((B, C, Nin), device=DEV)
+    _lib.check(L.gf_unpack_panels(Xp.data_ptr(), back.data_ptr(), B, C, N, Nin, stream()))
+    assert np.array_equal(back.cpu().numpy(), x)
+
+
+@pytest.mark.parametrize("N,P,kind", [
+    (100, 3, "weighted"), (1000, 40, "weighted"), (1000, 40, "uniform"), (2561, 64, "weighted"), (5000, 300, "uniform"),
+    (5121, 700, "weighted"), (10000, 520, "uniform"), (10239, 300, "weighted"), (64, 2, "weighted"), (63, 5, "uniform"),
+], ids=lambda v: str(v))
+def test_spmm_hop_panel_against_scipy(N, P, kind, pipeline_knob):
+    """One LDS-panel hop, both operators, against scipy: workgroup sizes 256 / 512 / 1024, more panels than workgroups,
+    empty rows, rows longer than one 8-step round, a hub row, value-free (uniform) and weighted streams."""
+    L = _lib.lib()
+    rng = np.random.RandomState(N + P)
+    A = sp.random(N, N, density=min(0.5, 9.0 / N), format="lil", random_state=rng, data_rvs=rng.randn)
+    A[N // 2, :] = 0                                        # empty row
+    A[:, N // 3] = 0                                        # empty column
+    hub = rng.choice(N, size=min(N, 300), replace=False)    # one long row and one long column
+    A[1, hub] = rng.randn(len(hub))
+    A[hub, 2] = rng.randn(len(hub))
+    A = sp.csr_matrix(A)
+    if kind == "uniform":
+        A.data[:] = 0.37
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    ns, uni, cyc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+    _lib.check(L.gf_plan_panel_info(plans[0], 0, ctypes.byref(ns), ctypes.byref(uni), ctypes.byref(cyc)))
+    assert ns.value == (N + 63) // 64 and uni.value == (1 if kind == "uniform" else 0) and 4.0 <= cyc.value <= 64.0
+    X = rng.randn(P, N, 4).astype(np.float32)
+    Xt = cu(X)
+    for use_uniform in ((1, 0) if kind == "uniform" else (1,)):
+        pipeline_knob(panel_uniform=use_uniform)
+        for op, M in ((0, A.T.tocsr()), (1, A)):
+            out = torch.full((P, N, 4), float("nan"), device=DEV)
+            _lib.check(L.gf_spmm_hop_panel(plans[0], op, Xt.data_ptr(), out.data_ptr(), P, stream()))
+            want = np.stack([M.astype(np.float64) @ X[p].astype(np.float64) for p in range(P)])
+            assert relerr(out.cpu().numpy(), want) < 2e-6, (op, use_uniform)
+            out2 = torch.empty_like(out)
+            _lib.check(L.gf_spmm_hop_panel(plans[0], op, Xt.data_ptr(), out2.data_ptr(), P, stream()))
+            assert torch.equal(out, out2)                    # bitwise deterministic
+
+
+def test_spmm_hop_panel_does_not_spread_nonfinite_values():
+    """A NaN in one node's signal reaches exactly its out-neighbours (rows exhausted early gather from a zero slot, never
+    from real data)."""
+    L = _lib.lib()
+    N, P = 500, 8
+    A = graphgen.sbm(N, seed=3, directed=True)
+    gso = SparseGSO([A])                                   # owns the device plans: keep it alive while they are used
+    plans = gso.plans(DEV)
+    X = np.random.RandomState(0).randn(P, N, 4).astype(np.float32)
+    X[:, 0, :] = np.nan
+    out = torch.empty((P, N, 4), device=DEV)
+    Xt = cu(X)
+    _lib.check(L.gf_spmm_hop_panel(plans[0], 1, Xt.data_ptr(), out.data_ptr(), P, stream()))
+    bad = np.isnan(out.cpu().numpy()).any(axis=(0, 2))
+    assert np.array_equal(bad, np.asarray((A[:, 0] != 0).todense()).ravel())
+
+
+@pytest.mark.parametrize("shape", [(3, 100, 100, 32, 32, 1, 5), (2, 70, 33, 8, 16, 2, 3), (1, 234, 234, 64, 32, 1, 5),
+                                   (4, 45, 45, 16, 64, 1, 1), (2, 1000, 999, 32, 128, 1, 4)], ids=str)
+@pytest.mark.parametrize("transpose", [0, 1])
+def test_contract_and_grad_taps_panel_against_einsum(shape, transpose):
+    L = _lib.lib()
+    B, N, Nout, G, F, E, K = shape
+    T = 1 + E * (K - 1)
+    Cin = F if transpose else G
+    rng = np.random.RandomState(5)
+    Zn = rng.randn(T, B, Cin, N).astype(np.float32)                       # taps in the reference orientation [B,C,N]
+    Zp = np.stack([to_panels(Zn[t], N) for t in range(T)])
+    h = (rng.uniform(-1, 1, (F, E, K, G)) / np.sqrt(G * K)).astype(np.float32)
+    bias = rng.uniform(-1, 1, (F,)).astype(np.float32)
+    Cout = G if transpose else F
+    out = torch.full((B, Cout, Nout), float("nan"), device=DEV)
+    Zt, ht, bt = cu(Zp), cu(h), cu(bias)                                  # keep the device buffers alive across the calls
+    _lib.check(L.gf_contract_panel(Zt.data_ptr(), ht.data_ptr(), None if transpose else bt.data_ptr(),
+                                   out.data_ptr(), B, N, Nout, G, F, E, K, transpose, stream()))
+    hb = _bank(h.astype(np.float64), transpose)                           # [T, Cin, Cout]
+    want = np.einsum("tbcn,tco->bon", Zn.astype(np.float64), hb)[:, :, :Nout]
+    if not transpose:
+        want = want + bias.astype(np.float64)[None, :, None]
+    assert relerr(out.cpu().numpy(), want) < 5e-6
+    if transpose:
+        return
+    # grad_taps: dh[f,e,k,g] = sum_{b,n} Z[t(e,k),b,g,n] dY[b,f,n]
+    dY = rng.randn(B, F, N).astype(np.float32)
+    nb = L.gf_grad_taps_workspace_bytes(B, N, G, F, E, K)
+    ws = torch.empty(nb // 4 + 1, device=DEV)
+    dh = torch.full((F, E, K, G), float("nan"), device=DEV)
+    db = torch.full((F,), float("nan"), device=DEV)
+    dYt = cu(to_panels(dY, N))
+    _lib.check(L.gf_grad_taps_panel(Zt.data_ptr(), dYt.data_ptr(), dh.data_ptr(), db.data_ptr(),
+                                    ws.data_ptr(), nb, B, N, G, F, E, K, stream()))
+    full = np.einsum("tbgn,bfn->tfg", Zn.astype(np.float64), dY.astype(np.float64))
+    want_dh = np.zeros((F, E, K, G))
+    for e in range(E):
+        want_dh[:, e, 0] = full[0]
+        for k in range(1, K):
+            want_dh[:, e, k] = full[1 + e * (K - 1) + (k - 1)]
+    assert relerr(dh.cpu().numpy(), want_dh) < 5e-6
+    assert relerr(db.cpu().numpy(), dY.astype(np.float64).sum(axis=(0, 2))) < 5e-6
+
+
+@pytest.mark.parametrize("pipe", [1, 2])
+@pytest.mark.parametrize("path", [p for p in golden_files("lsigf") if any(k in p for k in ("asym37_G32", "fbego_G32", "fbego_G64_F32", "sbm100_G32", "asym37_nobias"))], ids=case_id)
+def test_lsigf_golden_under_both_pipelines(path, pipe, pipeline_knob):
+    """The same reference outputs through the node-major (L2 gather) and the column-panel (LDS gather) pipelines."""
+    d = load(path)
+    pipeline_knob(pipeline=pipe)
+    gso = SparseGSO.from_any(d["S"])
+    F, E, K, G = d["h"].shape
+    assert _lib.lib().gf_lsigf_pipeline(gso.plans(DEV), E, G, F) == pipe
+    h, x = cu(d["h"], True), cu(d["x"], True)
+    b = cu(d["b"], True) if "b" in d else None
+    y = LSIGF(h, gso, x, b)
+    y.backward(cu(d["dy"]))
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    assert relerr(h.grad.cpu().numpy(), d["dh"]) < GRAD_RTOL
+    if b is not None:
+        assert relerr(b.grad.cpu().numpy(), d["db"]) < GRAD_RTOL
+
+
+def test_pipelines_agree_at_full_size(cfg2, pipeline_knob):
+    """BASELINE configs[1] at full size: forward and all gradients of the two pipelines agree to fp32 round-off, and the
+    panel pipeline is what the layer runs by default there."""
+    layer, x = cfg2["layer"], cfg2["x"]
+    dy = torch.randn(x.shape[0], layer.F, x.shape[2], device=DEV)
+    res = {}
+    for pipe in (1, 2):
+        pipeline_knob(pipeline=pipe)
+        xx = x.detach().clone().requires_grad_(True)
+        for p_ in layer.parameters():
+            p_.grad = None
+        y = layer(xx)
+        y.backward(dy)
+        res[pipe] = (y.detach().clone(), xx.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone())
+    pipeline_knob(pipeline=0)
+    assert _lib.lib().gf_lsigf_pipeline(layer._gso.plans(DEV), 1, layer.G, layer.F) == 2
+    for a, b_ in zip(res[1], res[2]):
+        assert float((a - b_).abs().max()) <= 2e-6 * float(a.abs().max())

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round-10 GPU call: panel pipeline parity + timing
+cd "$(dirname "$0")/.."; mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/r10; rm -rf $O; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "panel or pipelines" > $O/pytest_panel.log 2>&1; echo "pytest exit $?" >> $O/pytest_panel.log
+tail -25 $O/pytest_panel.log
+timeout 300 python tools/panel_sweep.py > $O/panel_sweep.log 2>&1; cat $O/panel_sweep.log
