@@ -113,6 +113,9 @@ struct gf_tuning {
     int pipeline = 0;           // 0 = auto, 1 = node-major (gather through L2), 2 = column panels through LDS (needs N <= 10239, G%8 == F%8 == 0)
     int panel_uniform = 1;      // 1 = use the value-free stream when the plan detected uniform values
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
+    int panel_stagger = 1;      // unified mode: start delay step between workgroup phases, in ~2 us units (0 = start together)
+    int panel_debug = 0;        // timing experiments only: 1 = skip the compute phase, 2 = skip the panel load (WRONG RESULTS)
+    int panel_mode = 0;         // 0 = unified (all waves load, then all compute), 1 = loader / compute wave roles
     int panel_sort = 0;         // 1 = panel image processes rows in descending-degree order (set BEFORE gf_plan_create)
     int panel_pace = 4;         // HBM loads a panel loader wave keeps in flight: 1 | 2 | 4 | 8 | 0 = unpaced (all 20)
 };

@@ -32,20 +32,22 @@ constexpr int kNV = 20;  // float4 per loader lane: 64 * kNV * 16 B per loader w
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-template <int UNIFORM, int PACE>
+template <int UNIFORM, int PACE, int UNIFIED>
 __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict__ slice, const uint16_t* __restrict__ degs, const int32_t* __restrict__ rows,
                                                           const uint2* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
-                                                          int N, int nSlices, int nPanels, int sentinel, int store_mode) {
+                                                          int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug, int stagger) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int CW = (int)(blockDim.x >> 7);  // compute waves = loader waves = half the workgroup
+    // UNIFIED: every wave loads its share of the panel, then every wave computes (load and compute phases alternate per CU;
+    // other CUs are in other phases).  Otherwise: half the waves are loaders that prefetch the next panel (see above).
+    const int CW = UNIFIED ? (int)(blockDim.x >> 6) : (int)(blockDim.x >> 7);
     const int64_t pstride = (int64_t)N * 4;  // floats per panel
     int p = blockIdx.x;
     if (p >= nPanels) return;  // whole workgroup
 
-    if (wave >= CW) {
+    if (!UNIFIED && wave >= CW) {
         // ------------------------------------------------------------------ loader waves
         const int lt = (wave - CW) * 64 + lane, nl = CW * 64;
         // every lane always loads kNV rows (index clamped into the panel: unconditional loads keep pre[] in registers)
@@ -111,9 +113,29 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
         }
     };
 
+    if (UNIFIED && tid == 0) reinterpret_cast<f32x4*>(panel)[N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slot
+    if (UNIFIED) {
+        // De-synchronise the workgroups once: every CU alternates an HBM-bound load phase and an LDS/issue-bound compute phase;
+        // started together they stay in lock step (HBM idle while everyone computes: measured 224 us = 53 load + 138 compute
+        // + 33 lost), started spread over one period the phases of different CUs interleave.
+        const int phase = (int)((blockIdx.x >> 3) & 7);   // workgroups b, b+8, ... share an XCD: spread within each XCD
+        for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(64);  // 64 * 64 cycles ~ 2 us each
+    }
     for (;;) {
+        if (UNIFIED && debug != 2) {
+            constexpr int kNVU = 10;  // N <= 10 * blockDim.x
+            const f32x4* src = reinterpret_cast<const f32x4*>(Xin + (int64_t)p * pstride);
+            f32x4* dst = reinterpret_cast<f32x4*>(panel);
+            f32x4 tmp[kNVU];
+            const int nthr = (int)blockDim.x;
+#pragma unroll
+            for (int j = 0; j < kNVU; ++j) tmp[j] = src[min(tid + j * nthr, N - 1)];
+#pragma unroll
+            for (int j = 0; j < kNVU; ++j)
+                if (tid + j * nthr < N) dst[tid + j * nthr] = tmp[j];
+        }
         __syncthreads();  // B1
-        if (wave < nSlices) {
+        if (wave < nSlices && debug != 1) {
             float* outp = Xout + (int64_t)p * pstride;
             int s = wave;                       // slice in hand
             int2 si = slice[s];                 // {group offset, group-steps}
@@ -163,7 +185,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                     j0 += kGC;
                     return false;
                 }
-                const int row = rows[s * 64 + lane];
+                const int row = rows ? rows[s * 64 + lane] : (s * 64 + lane < N ? s * 64 + lane : -1);
                 if (row >= 0) {
                     f32x4 acc = acc0 + acc1;
                     if (UNIFORM) acc *= uval;
@@ -281,18 +303,20 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     int64_t grid = (int64_t)num_cus() * wgPerCU;
     if (grid > nPanels) grid = nPanels;
     const bool uniform = m.pn_uniform && g_tune.panel_uniform;
-    typedef void (*kern_t)(const int2*, const uint16_t*, const int32_t*, const uint2*, const float4*, float, const float*, float*, int, int, int, int, int);
+    typedef void (*kern_t)(const int2*, const uint16_t*, const int32_t*, const uint2*, const float4*, float, const float*, float*, int, int, int, int, int, int, int);
     kern_t kern;
-    switch (g_tune.panel_pace) {
-        case 1: kern = uniform ? spmm_panel_kernel<1, 1> : spmm_panel_kernel<0, 1>; break;
-        case 2: kern = uniform ? spmm_panel_kernel<1, 2> : spmm_panel_kernel<0, 2>; break;
-        case 8: kern = uniform ? spmm_panel_kernel<1, 8> : spmm_panel_kernel<0, 8>; break;
-        case 0: kern = uniform ? spmm_panel_kernel<1, 0> : spmm_panel_kernel<0, 0>; break;
-        default: kern = uniform ? spmm_panel_kernel<1, 4> : spmm_panel_kernel<0, 4>; break;
+    if (g_tune.panel_mode == 0) {
+        kern = uniform ? spmm_panel_kernel<1, 0, 1> : spmm_panel_kernel<0, 0, 1>;
+    } else {
+        switch (g_tune.panel_pace) {
+            case 1: kern = uniform ? spmm_panel_kernel<1, 1, 0> : spmm_panel_kernel<0, 1, 0>; break;
+            case 0: kern = uniform ? spmm_panel_kernel<1, 0, 0> : spmm_panel_kernel<0, 0, 0>; break;
+            default: kern = uniform ? spmm_panel_kernel<1, 4, 0> : spmm_panel_kernel<0, 4, 0>; break;
+        }
     }
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_deg, m.pn_row, m.pn_col4, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_deg, g_tune.panel_sort ? m.pn_row : nullptr, m.pn_col4, m.pn_val4, m.pn_uval, Xin,
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, g_tune.panel_stagger);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }

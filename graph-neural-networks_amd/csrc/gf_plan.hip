@@ -41,6 +41,9 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_order")) g_tune.panel_order = value;
     else if (!strcmp(key, "panel_pace")) g_tune.panel_pace = value;
     else if (!strcmp(key, "panel_sort")) g_tune.panel_sort = value;
+    else if (!strcmp(key, "panel_mode")) g_tune.panel_mode = value;
+    else if (!strcmp(key, "panel_debug")) g_tune.panel_debug = value;
+    else if (!strcmp(key, "panel_stagger")) g_tune.panel_stagger = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);
         return GF_ERR_ARG;
