@@ -40,7 +40,7 @@ _SIGNATURES = {
     "gf_time_spmm_hop_panel": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _c.POINTER(_c.c_float)]),
     "gf_contract_panel": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_grad_taps_panel": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "gf_plan_panel_info": (_c.c_int, [_vp, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _c.POINTER(_c.c_double)]),
+    "gf_plan_panel_info": (_c.c_int, [_vp, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "gf_ev_plan_create": (_c.c_int, [_i32, _i64, _vp, _vp, _c.POINTER(_vp)]),
     "gf_ev_plan_destroy": (_c.c_int, [_vp]),
     "gf_ev_plan_info": (_c.c_int, [_vp, _c.POINTER(_i32), _c.POINTER(_i64), _c.POINTER(_i64)]),

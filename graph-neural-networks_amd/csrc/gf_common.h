@@ -65,20 +65,21 @@ struct gf_csr_dev {
     int2* sell_ent = nullptr;       // [sell_kptr[n_slices] * 8]
     int32_t* sell_rowid = nullptr;  // [n_slices * 8]  stored position -> original row, -1 past the last row
     int64_t sell_pad_entries = 0;   // padding entries (wasted gathers), for diagnostics
-    // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes: rows in NATURAL order (stores stay coalesced, no
-    // node permutation anywhere), slices of 64 consecutive rows = one wavefront, lane = row.  Entries are stored in GROUPS of
-    // 4 steps: group j of a lane = its neighbours 4j .. 4j+3 (4 x 16-bit columns = 8 bytes, 4 x fp32 values = 16 bytes,
-    // slots past the row's end = {column N, value 0}).  Group-step j of slice s holds the groups of the lanes that still
-    // have a neighbour at step 4j, compacted in lane order:
-    //   group of (slice s, group-step j, lane l) = pn_slice[s].x + sum_{j' < j} active(j') + rank of l among the active lanes.
+    // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes.  Work unit = OCTET (8 consecutive rows = one 128-byte
+    // line of a column panel); octets are sorted by their longest row and a slice = 8 octets = one wavefront (lane l handles
+    // row pn_oct[8s + l/8] * 8 + l%8), so the rows a wave walks together have similar lengths and every octet still stores a
+    // full line.  Entries are an ELL block per slice: group-row j (steps 4j .. 4j+3) x 64 lanes, one 8-byte word of
+    // 4 x 16-bit columns and one 16-byte word of 4 fp32 values per lane; empty slots = {column N = the LDS zero slot, 0}.
+    //   address of (slice s, group-row j, lane l) = (pn_slice[s].x + j) * 64 + l      -- no per-lane bookkeeping at all.
     // pn_uniform: every stored value equals pn_uval (adjacency / lambda_max of an unweighted graph): the value stream is not read.
     int32_t pn_slices = 0;          // 0 = no panel image
-    int2* pn_slice = nullptr;       // [pn_slices]  {group offset, group-steps = ceil(longest row / 4)}
-    uint16_t* pn_deg = nullptr;     // [pn_slices * 64]  neighbours per row (0 past the last row)
-    int32_t* pn_row = nullptr;      // [pn_slices * 64]  row handled by (slice, lane); -1 = none
-    uint2* pn_col4 = nullptr;       // [groups + 1]
-    float4* pn_val4 = nullptr;      // [groups + 1]
-    int32_t pn_sentinel = 0;        // index of the sentinel group {columns N, values 0} that follows the last real group
+    int2* pn_slice = nullptr;       // [pn_slices]  {group-row offset, group-rows = ceil(longest row / 4)}
+    int32_t* pn_oct = nullptr;      // [pn_slices * (64 >> pn_ushift)]  unit handled by lanes (i << ushift) .. of the slice (-1 = none)
+    int32_t pn_ushift = 3;          // log2(rows per unit): 3 = octets (full 128-byte lines), 2 = quads (64 bytes), 1 = pairs
+    uint2* pn_col4 = nullptr;       // [(group-rows + 2) * 64]
+    float4* pn_val4 = nullptr;      // [(group-rows + 2) * 64]
+    int32_t pn_sentinel = 0;        // group-row index of two all-sentinel group-rows after the last real one
+    double pn_fill = 1.0;           // real entries / ELL slots (diagnostic)
     int32_t pn_uniform = 0;
     float pn_uval = 0.f;
     double pn_conflict = 0.0;       // expected LDS cycles per ds_read_b128 step after the bank-aware ordering (diagnostic)
@@ -115,9 +116,8 @@ struct gf_tuning {
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
     int panel_stagger = 1;      // unified mode: start delay step between workgroup phases, in ~2 us units (0 = start together)
     int panel_debug = 0;        // timing experiments only: 1 = skip the compute phase, 2 = skip the panel load (WRONG RESULTS)
-    int panel_mode = 0;         // 0 = unified (all waves load, then all compute), 1 = loader / compute wave roles
-    int panel_sort = 0;         // 1 = panel image processes rows in descending-degree order (set BEFORE gf_plan_create)
-    int panel_pace = 4;         // HBM loads a panel loader wave keeps in flight: 1 | 2 | 4 | 8 | 0 = unpaced (all 20)
+    int panel_unit = 8;         // rows per work unit of the panel image: 8 | 4 | 2 (set BEFORE gf_plan_create)
+    int panel_sort = 1;         // 1 = octets sorted by their longest row (set BEFORE gf_plan_create)
 };
 extern gf_tuning g_tune;
 

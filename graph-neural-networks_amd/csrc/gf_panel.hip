@@ -5,21 +5,26 @@
 //                   16 bytes per node, N*16 bytes per panel -- at most 160 KiB, i.e. ONE panel fits a CU's LDS.
 //
 // Why: a hop gathers nnz*B*C*4 bytes (each node's row once per neighbour, ~10x the algorithmic read).  Served from L2
-// that stream is capped by the L2 itself (34 TB/s peak for 8 TB/s of HBM: <= 85 % of the HBM roofline even at 100 % hits,
-// 39 % measured, profiles/r01_g_*).  Here a workgroup stages one panel in LDS (one coalesced read of its N*16 bytes =
-// exactly the algorithmic X read), every gather becomes a ds_read_b128, and the only thing streamed per panel besides
-// the panel itself is the (column, value) list -- 2 or 6 bytes per edge, coalesced, L2-resident.
+// that stream goes through the CU's L1 miss path (~64 lines in flight x 128 B / ~250 cycles ~ 33 B/clk/CU: the node-major
+// kernel sits at 39 % of the HBM roofline and every variant of it clustered there, profiles/r01_b..g).  Here a workgroup
+// stages one panel in LDS (one coalesced read of its N*16 bytes = exactly the algorithmic X read), every gather is a
+// ds_read_b128, and the only thing streamed per panel besides the panel itself is the (column, value) list -- 2 or 6 bytes
+// per edge, coalesced, L2-resident.
 //
-// Kernel (persistent, one workgroup per LDS-full; 16 / 8 / 4 waves by N):
-//   * waves are specialised: the first half compute, the second half are loaders.  A wave's vector-memory results
-//     return in issue order, so a wave that had the next panel's HBM loads in flight would stall its L2-latency entry
-//     loads behind them; the loader waves hold the next panel in registers (20 x 16 B per lane), sleep on it, and copy
-//     it into LDS between two workgroup barriers once the compute waves are done with the current panel.
-//   * compute: lane = row, wave = slice of 64 consecutive rows in NATURAL order (the output store of a slice is one
-//     contiguous 1 KiB, no node permutation exists anywhere).  A lane's neighbours come in groups of 4 (one 8-byte
-//     column load + one 16-byte value load per 4 gathers); rows of a slice differ in length: group-step j holds only the
-//     lanes that still have neighbours, compacted (ballot + mbcnt give a lane its slot), so at most 3 padding entries per
-//     row are read; the groups of the next 8 steps -- across slice boundaries -- are requested before the current 8 are gathered.
+// Kernel (persistent; 16 / 8 / 4 waves per workgroup by N, as many workgroups per CU as LDS allows):
+//   * per panel: every wave loads its share of the panel into LDS (HBM-bound phase), barrier, every wave computes its slices
+//     (LDS / issue-bound phase), barrier.  Workgroups start staggered so that the phases of different CUs interleave and
+//     HBM stays busy (measured at N = 1e4: 224 us in lock step = 53 load + 138 compute + 33 lost, 189 us staggered).
+//     (A variant with dedicated loader waves prefetching the next panel into registers overlapped perfectly but left only
+//     2 compute waves per SIMD: 255 us.  A wave's vector-memory results return in issue order, so a computing wave cannot
+//     keep HBM loads in flight without stalling its own L2-latency entry loads behind them.)
+//   * compute: work unit = octet (8 consecutive rows = one 128-byte output line); the plan sorts octets by their longest row,
+//     a slice = 8 octets = one wave, lane = row.  A lane's neighbours come in groups of 4 (one 8-byte load of 4 x 16-bit
+//     columns + one 16-byte load of 4 values per 4 gathers) laid out as an ELL block per slice: the address of a group is
+//     base + j*64 + lane -- no per-lane bookkeeping; empty slots point at a zero slot of the panel.  Two register sets
+//     ping-pong so that the groups of the next 8 steps -- across slice boundaries -- are in flight while the current 8 steps
+//     gather; every path issues the same number of requests (a skipped request would make the in-order vmcnt bookkeeping
+//     of the other set unknowable and force vmcnt(0) waits).
 //   * plan-time neighbour order (gf_plan.hip) spreads the 16 lanes of each ds_read_b128 service group over distinct
 //     16-byte bank quads, cutting the random-access LDS conflicts.
 //   * per-row sums run in the plan's fixed neighbour order: bitwise run-to-run deterministic, no atomics.
@@ -28,143 +33,91 @@
 namespace {
 
 constexpr int kGC = 2;   // entry groups (of 4 neighbours) per lane gathered per round
-constexpr int kNV = 20;  // float4 per loader lane: 64 * kNV * 16 B per loader wave
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-
-template <int UNIFORM, int PACE, int UNIFIED>
-__global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict__ slice, const uint16_t* __restrict__ degs, const int32_t* __restrict__ rows,
+template <int UNIFORM>
+__global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict__ slice, const int32_t* __restrict__ octs,
                                                           const uint2* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
-                                                          int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug, int stagger) {
+                                                          int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug,
+                                                          int stagger, int ush) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // UNIFIED: every wave loads its share of the panel, then every wave computes (load and compute phases alternate per CU;
-    // other CUs are in other phases).  Otherwise: half the waves are loaders that prefetch the next panel (see above).
-    const int CW = UNIFIED ? (int)(blockDim.x >> 6) : (int)(blockDim.x >> 7);
+    const int CW = (int)(blockDim.x >> 6);
     const int64_t pstride = (int64_t)N * 4;  // floats per panel
     int p = blockIdx.x;
     if (p >= nPanels) return;  // whole workgroup
+    f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
+    const u32x2* col4 = reinterpret_cast<const u32x2*>(cols) + lane;
+    const f32x4* val4 = reinterpret_cast<const f32x4*>(vals) + lane;
 
-    if (!UNIFIED && wave >= CW) {
-        // ------------------------------------------------------------------ loader waves
-        const int lt = (wave - CW) * 64 + lane, nl = CW * 64;
-        // every lane always loads kNV rows (index clamped into the panel: unconditional loads keep pre[] in registers)
-        f32x4 pre[kNV];
-        int idxs[kNV];
-#pragma unroll
-        for (int j = 0; j < kNV; ++j) idxs[j] = min(lt + j * nl, N - 1);
-        {
-            const f32x4* src = reinterpret_cast<const f32x4*>(Xin + (int64_t)p * pstride);
-#pragma unroll
-            for (int j = 0; j < kNV; ++j) pre[j] = src[idxs[j]];
-        }
-        f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
-        if (lt == 0) lds4[N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slot exhausted rows gather from
-        for (;;) {
-#pragma unroll
-            for (int j = 0; j < kNV; ++j)
-                if (lt + j * nl < N) lds4[idxs[j]] = pre[j];
-            __syncthreads();  // B1: panel p is in LDS
-            const int pn = p + (int)gridDim.x;
-            const bool more = pn < nPanels;
-            const f32x4* src = reinterpret_cast<const f32x4*>(Xin + (int64_t)(more ? pn : p) * pstride);
-            // The next panel streams in while the compute waves work on panel p.  PACE bounds the HBM loads a loader wave
-            // keeps in flight: dumped all at once, the 160 KiB fill the CU's L1 miss queue and the compute waves' L2-resident
-            // entry loads wait behind them (measured: hop 265 us unpaced).
-#pragma unroll
-            for (int j = 0; j < kNV; ++j) {
-                pre[j] = src[idxs[j]];
-                if (PACE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (PACE == 2 && (j & 1) == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                if (PACE == 4 && (j & 1) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                if (PACE == 8 && (j & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            }
-            __syncthreads();  // B2: compute waves are done reading panel p
-            if (!more) break;
-            p = pn;
-        }
-        return;
+    if (tid == 0) lds4[N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slot empty ELL slots gather from
+    {
+        // De-synchronise the workgroups once (see the header comment).
+        const int phase = (int)((blockIdx.x >> 3) & 7);  // workgroups b, b+8, ... share an XCD: spread within each XCD
+        for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(64);  // 64 * 64 cycles ~ 2 us each
     }
 
-    // ---------------------------------------------------------------------- compute waves
-    // Two register sets (A, B) ping-pong: while the gathers of the set in hand run, the other set is being filled with the
-    // NEXT chunk's entry groups -- across slice boundaries.  No register copies between the sets (a copy would read the
-    // freshly requested registers and force a full vmcnt(0) at the loop's back edge), and every request is issued on every
-    // path: a skipped load would make the in-order vmcnt bookkeeping of the other set unknowable (again vmcnt(0)).
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const f32x4* lds4 = reinterpret_cast<const f32x4*>(panel);
-    const u32x2* col4 = reinterpret_cast<const u32x2*>(cols);
-    const f32x4* val4 = reinterpret_cast<const f32x4*>(vals);
-
-    // request group-steps [jj, jj + kGC) for a lane that owns gl groups; pb = offset of group-step jj's first group.
-    // Lanes without a group at a step read the sentinel group {columns N = the panel's zero slot, values 0}.
-    auto load_chunk = [&](u32x2 (&cc)[kGC], f32x4 (&vv)[kGC], int gl, int jj, int& pb) {
+    // request group-rows [g0, g0 + kGC) of an ELL block (g0 = absolute group-row index)
+    auto load_chunk = [&](u32x2 (&cc)[kGC], f32x4 (&vv)[kGC], int g0) {
 #pragma unroll
         for (int g = 0; g < kGC; ++g) {
-            const bool act = (jj + g) < gl;
-            const unsigned long long m = __ballot(act);
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            const int e = act ? pb + rank : sentinel;
-            cc[g] = col4[e];
-            if (!UNIFORM) vv[g] = val4[e];
-            pb += __popcll(m);
+            cc[g] = col4[(int64_t)(g0 + g) * 64];
+            if (!UNIFORM) vv[g] = val4[(int64_t)(g0 + g) * 64];
         }
     };
 
-    if (UNIFIED && tid == 0) reinterpret_cast<f32x4*>(panel)[N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slot
-    if (UNIFIED) {
-        // De-synchronise the workgroups once: every CU alternates an HBM-bound load phase and an LDS/issue-bound compute phase;
-        // started together they stay in lock step (HBM idle while everyone computes: measured 224 us = 53 load + 138 compute
-        // + 33 lost), started spread over one period the phases of different CUs interleave.
-        const int phase = (int)((blockIdx.x >> 3) & 7);   // workgroups b, b+8, ... share an XCD: spread within each XCD
-        for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(64);  // 64 * 64 cycles ~ 2 us each
-    }
     for (;;) {
-        if (UNIFIED && debug != 2) {
-            constexpr int kNVU = 10;  // N <= 10 * blockDim.x
+        if (debug != 2) {
+            // HBM-bound phase: every wave loads its share of the panel (N <= kNVU * blockDim.x rows of 16 bytes).
+            // (Requesting the NEXT panel from inside the compute phase instead -- registers, one HBM-latency stall per wave
+            // and panel -- was measured and gave nothing: 184 vs 181 us; a CU pulls at most ~22 GB/s from HBM and the
+            // entry streams compete for the same L1 miss queue.)
+            constexpr int kNVU = 10;
             const f32x4* src = reinterpret_cast<const f32x4*>(Xin + (int64_t)p * pstride);
-            f32x4* dst = reinterpret_cast<f32x4*>(panel);
             f32x4 tmp[kNVU];
             const int nthr = (int)blockDim.x;
 #pragma unroll
             for (int j = 0; j < kNVU; ++j) tmp[j] = src[min(tid + j * nthr, N - 1)];
 #pragma unroll
             for (int j = 0; j < kNVU; ++j)
-                if (tid + j * nthr < N) dst[tid + j * nthr] = tmp[j];
+                if (tid + j * nthr < N) lds4[tid + j * nthr] = tmp[j];
         }
-        __syncthreads();  // B1
+        __syncthreads();  // B1: panel p is in LDS
         if (wave < nSlices && debug != 1) {
             float* outp = Xout + (int64_t)p * pstride;
             int s = wave;                       // slice in hand
-            int2 si = slice[s];                 // {group offset, group-steps}
-            int gl = ((int)degs[s * 64 + lane] + 3) >> 2;   // this lane's groups
+            int2 si = slice[s];                 // {group-row offset, group-rows}
+            int oc = octs[(s << (6 - ush)) + (lane >> ush)];
             int sn = s + CW;                    // next slice of this wave (its header is fetched one slice ahead)
-            int2 sin = make_int2(0, 0);
-            int gln = 0;
+            int2 sin = make_int2(sentinel, 0);
+            int ocn = -1;
             if (sn < nSlices) {
                 sin = slice[sn];
-                gln = ((int)degs[sn * 64 + lane] + 3) >> 2;
+                ocn = octs[(sn << (6 - ush)) + (lane >> ush)];
             }
-            int pb = si.x;                      // group offset up to which requests have been issued
             int j0 = 0;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             u32x2 cA[kGC], cB[kGC];
             f32x4 vA[kGC], vB[kGC];
-            load_chunk(cA, vA, gl, 0, pb);
+            load_chunk(cA, vA, si.y > 0 ? si.x : sentinel);
 
-            // gathers + FMAs of the chunk held in (cc, vv) = group-steps [j0, j0 + kGC) of slice s, after requesting the
+            // gathers + FMAs of the chunk held in (cc, vv) = group-rows [j0, j0 + kGC) of slice s, after requesting the
             // following chunk into (cn, vn).  Returns true when the wave has no slice left.
             auto process = [&](u32x2 (&cc)[kGC], f32x4 (&vv)[kGC], u32x2 (&cn)[kGC], f32x4 (&vn)[kGC]) -> bool {
                 const bool same = (j0 + kGC) < si.y;  // wave-uniform: the next chunk belongs to the same slice
-                const int gn = same ? gl : gln;       // gln = 0 when the wave has no further slice: all-sentinel requests
-                const int jn = same ? j0 + kGC : 0;
-                pb = same ? pb : sin.x;
-                load_chunk(cn, vn, gn, jn, pb);
+                // next chunk: same slice, or the head of the next slice (the sentinel rows when it is empty / absent).
+                // A chunk may run one group-row past its slice's block: it then reads the following block's (or the
+                // sentinel's) first row, whose gathers the exhausted-row test below discards.
+                const int gnext = same ? si.x + j0 + kGC : (sin.y > 0 ? sin.x : sentinel);
+                load_chunk(cn, vn, gnext);
 #pragma unroll
                 for (int g = 0; g < kGC; ++g) {
-                    const unsigned c01 = cc[g].x, c23 = cc[g].y;
+                    const bool live = (j0 + g) < si.y;  // wave-uniform: group-row belongs to this slice
+                    const unsigned c01 = live ? cc[g].x : ((unsigned)N | ((unsigned)N << 16));
+                    const unsigned c23 = live ? cc[g].y : ((unsigned)N | ((unsigned)N << 16));
                     const f32x4 x0 = lds4[c01 & 0xffffu];
                     const f32x4 x1 = lds4[c01 >> 16];
                     const f32x4 x2 = lds4[c23 & 0xffffu];
@@ -185,8 +138,8 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                     j0 += kGC;
                     return false;
                 }
-                const int row = rows ? rows[s * 64 + lane] : (s * 64 + lane < N ? s * 64 + lane : -1);
-                if (row >= 0) {
+                const int row = (oc << ush) + (lane & ((1 << ush) - 1));
+                if (oc >= 0 && row < N) {
                     f32x4 acc = acc0 + acc1;
                     if (UNIFORM) acc *= uval;
                     f32x4* dst = reinterpret_cast<f32x4*>(outp + (int64_t)row * 4);
@@ -200,13 +153,14 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 s = sn;
                 if (s >= nSlices) return true;
                 si = sin;
-                gl = gln;
+                oc = ocn;
                 j0 = 0;
                 sn = s + CW;
-                gln = 0;
+                sin = make_int2(sentinel, 0);
+                ocn = -1;
                 if (sn < nSlices) {
                     sin = slice[sn];
-                    gln = ((int)degs[sn * 64 + lane] + 3) >> 2;
+                    ocn = octs[(sn << (6 - ush)) + (lane >> ush)];
                 }
                 return false;
             };
@@ -215,7 +169,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 if (process(cB, vB, cA, vA)) break;
             }
         }
-        __syncthreads();  // B2
+        __syncthreads();  // B2: every wave is done reading panel p
         p += (int)gridDim.x;
         if (p >= nPanels) break;
     }
@@ -303,20 +257,10 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     int64_t grid = (int64_t)num_cus() * wgPerCU;
     if (grid > nPanels) grid = nPanels;
     const bool uniform = m.pn_uniform && g_tune.panel_uniform;
-    typedef void (*kern_t)(const int2*, const uint16_t*, const int32_t*, const uint2*, const float4*, float, const float*, float*, int, int, int, int, int, int, int);
-    kern_t kern;
-    if (g_tune.panel_mode == 0) {
-        kern = uniform ? spmm_panel_kernel<1, 0, 1> : spmm_panel_kernel<0, 0, 1>;
-    } else {
-        switch (g_tune.panel_pace) {
-            case 1: kern = uniform ? spmm_panel_kernel<1, 1, 0> : spmm_panel_kernel<0, 1, 0>; break;
-            case 0: kern = uniform ? spmm_panel_kernel<1, 0, 0> : spmm_panel_kernel<0, 0, 0>; break;
-            default: kern = uniform ? spmm_panel_kernel<1, 4, 0> : spmm_panel_kernel<0, 4, 0>; break;
-        }
-    }
+    auto kern = uniform ? spmm_panel_kernel<1> : spmm_panel_kernel<0>;
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_deg, g_tune.panel_sort ? m.pn_row : nullptr, m.pn_col4, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, g_tune.panel_stagger);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_oct, m.pn_col4, m.pn_val4, m.pn_uval, Xin,
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }

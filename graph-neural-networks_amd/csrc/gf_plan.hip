@@ -39,9 +39,8 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "pipeline")) g_tune.pipeline = value;
     else if (!strcmp(key, "panel_uniform")) g_tune.panel_uniform = value;
     else if (!strcmp(key, "panel_order")) g_tune.panel_order = value;
-    else if (!strcmp(key, "panel_pace")) g_tune.panel_pace = value;
     else if (!strcmp(key, "panel_sort")) g_tune.panel_sort = value;
-    else if (!strcmp(key, "panel_mode")) g_tune.panel_mode = value;
+    else if (!strcmp(key, "panel_unit")) g_tune.panel_unit = value;
     else if (!strcmp(key, "panel_debug")) g_tune.panel_debug = value;
     else if (!strcmp(key, "panel_stagger")) g_tune.panel_stagger = value;
     else {
@@ -198,39 +197,42 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     if (n > kPanelMaxNodes) return GF_OK;
     for (int32_t i = 0; i < n; ++i)
         if (a.rowptr[i + 1] - a.rowptr[i] > kPanelMaxDeg) return GF_OK;  // hub row longer than a 16-bit count: no panel image
-    const int32_t ns = (n + 63) / 64;
-    std::vector<int2> slice(ns);
-    std::vector<uint16_t> deg((size_t)ns * 64, 0);
-    // processing order of the rows: natural (lane = row: coalesced 1 KiB stores, ~1.85x issue-slot padding on Poisson
-    // degrees) or sorted by descending degree (slices of near-equal rows; each lane stores its own 16 bytes)
-    std::vector<int32_t> prow((size_t)ns * 64, -1);
-    for (int32_t i = 0; i < n; ++i) prow[i] = i;
+    auto rdeg = [&](int32_t r) { return r < n ? a.rowptr[r + 1] - a.rowptr[r] : 0; };
+    // Octets (8 consecutive rows = one 128-byte line of a panel) are the unit of work assignment: sorted by their longest
+    // row, so that the 8 octets of a slice need about the same number of steps, while every octet still stores one full line.
+    const int ush = (g_tune.panel_unit == 4) ? 2 : (g_tune.panel_unit == 2 ? 1 : 3);  // rows per unit = 8 (full line) | 4 | 2
+    const int U = 1 << ush, UPS = 64 >> ush;                                          // rows per unit, units per slice
+    const int32_t noct = (n + U - 1) / U;
+    const int32_t ns = (noct + UPS - 1) / UPS;
+    std::vector<int32_t> oct((size_t)ns * UPS, -1), omax(noct, 0);
+    for (int32_t o = 0; o < noct; ++o) {
+        oct[o] = o;
+        for (int r = 0; r < U; ++r) omax[o] = std::max(omax[o], rdeg(o * U + r));
+    }
     if (g_tune.panel_sort)
-        std::stable_sort(prow.begin(), prow.begin() + n, [&](int32_t x, int32_t y) {
-            return (a.rowptr[x + 1] - a.rowptr[x]) > (a.rowptr[y + 1] - a.rowptr[y]);
-        });
-    std::vector<uint2> col4;   // 4 x 16-bit columns per (lane, group of 4 steps)
+        std::stable_sort(oct.begin(), oct.begin() + noct, [&](int32_t x, int32_t y) { return omax[x] > omax[y]; });
+    std::vector<int2> slice(ns);
+    std::vector<uint2> col4;   // ELL: [slice][group j][lane] -> 4 x 16-bit columns of steps 4j .. 4j+3
     std::vector<float4> val4;
-    col4.reserve(a.col.size() / 3);
-    val4.reserve(a.val.size() / 3);
     const bool reorder = g_tune.panel_order != 0;
     double cycles = 0.0;
-    int64_t steps = 0;
+    int64_t steps = 0, slots = 0;
     std::vector<std::vector<int32_t>> rest(64);  // remaining entry indices (into a.col / a.val) per lane
     std::vector<int32_t> picks;                  // [step][lane] chosen entry (-1 = row exhausted)
+    const uint32_t nn = (uint32_t)n | ((uint32_t)n << 16);
     for (int32_t sl = 0; sl < ns; ++sl) {
         int32_t w = 0;
         for (int l = 0; l < 64; ++l) {
             rest[l].clear();
-            const int32_t r = prow[(size_t)sl * 64 + l];
-            if (r >= 0) {
+            const int32_t o = oct[(size_t)sl * UPS + (l >> ush)];
+            const int32_t r = o >= 0 ? o * U + (l & (U - 1)) : n;
+            if (r < n) {
                 for (int32_t q = a.rowptr[r]; q < a.rowptr[r + 1]; ++q) rest[l].push_back(q);
-                deg[(size_t)sl * 64 + l] = (uint16_t)rest[l].size();
                 w = std::max<int32_t>(w, (int32_t)rest[l].size());
             }
         }
         const int32_t gmax = (w + 3) / 4;
-        slice[sl] = make_int2((int32_t)col4.size(), gmax);
+        slice[sl] = make_int2((int32_t)(col4.size() / 64), gmax);   // group-row offset (x 64 lanes), group-steps
         picks.assign((size_t)gmax * 4 * 64, -1);
         for (int32_t k = 0; k < w; ++k) {
             int quadCols[4][16][4];  // per service group, per bank quad: distinct columns already read (up to 4 tracked)
@@ -277,11 +279,9 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
             }
             steps++;
         }
-        // emit: group j (steps 4j .. 4j+3) of every lane that still has a neighbour at step 4j, in lane order (the kernel's
-        // ballot + mbcnt rank); slots past the end of a row hold {column N = the LDS zero slot, value 0}
+        // emit the slice's ELL block: gmax group-rows of 64 lanes; empty slots = {column N = the LDS zero slot, value 0}
         for (int32_t j = 0; j < gmax; ++j)
             for (int l = 0; l < 64; ++l) {
-                if ((int32_t)deg[(size_t)sl * 64 + l] <= 4 * j) continue;
                 uint16_t c[4];
                 float v[4];
                 for (int i = 0; i < 4; ++i) {
@@ -292,6 +292,7 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
                 col4.push_back(make_uint2((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)c[2] | ((uint32_t)c[3] << 16)));
                 val4.push_back(make_float4(v[0], v[1], v[2], v[3]));
             }
+        slots += (int64_t)gmax * 4 * 64;
     }
     d.pn_uniform = 0;
     d.pn_uval = 0.f;
@@ -302,17 +303,19 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
         d.pn_uval = a.val[0];
     }
     d.pn_conflict = steps ? cycles / (double)steps : 0.0;
-    d.pn_sentinel = (int32_t)col4.size();  // exhausted lanes read this group: columns N (the LDS zero slot), values 0
-    const uint32_t nn = (uint32_t)n | ((uint32_t)n << 16);
-    col4.push_back(make_uint2(nn, nn));
-    val4.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    d.pn_fill = slots ? (double)a.col.size() / (double)slots : 1.0;
+    d.pn_sentinel = (int32_t)(col4.size() / 64);   // two all-sentinel group-rows: what a wave without further work requests
+    for (int i = 0; i < 128; ++i) {
+        col4.push_back(make_uint2(nn, nn));
+        val4.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    }
     int rc;
     if ((rc = upload(slice, &d.pn_slice, bytes))) return rc;
-    if ((rc = upload(deg, &d.pn_deg, bytes))) return rc;
-    if ((rc = upload(prow, &d.pn_row, bytes))) return rc;
+    if ((rc = upload(oct, &d.pn_oct, bytes))) return rc;
     if ((rc = upload(col4, &d.pn_col4, bytes))) return rc;
     if ((rc = upload(val4, &d.pn_val4, bytes))) return rc;
     d.pn_slices = ns;
+    d.pn_ushift = ush;
     return GF_OK;
 }
 
@@ -325,8 +328,7 @@ void free_csr(gf_csr_dev& d) {
     if (d.sell_ent) (void)hipFree(d.sell_ent);
     if (d.sell_rowid) (void)hipFree(d.sell_rowid);
     if (d.pn_slice) (void)hipFree(d.pn_slice);
-    if (d.pn_deg) (void)hipFree(d.pn_deg);
-    if (d.pn_row) (void)hipFree(d.pn_row);
+    if (d.pn_oct) (void)hipFree(d.pn_oct);
     if (d.pn_col4) (void)hipFree(d.pn_col4);
     if (d.pn_val4) (void)hipFree(d.pn_val4);
     d = gf_csr_dev{};
@@ -384,12 +386,13 @@ extern "C" int gf_plan_destroy(gf_plan* pl) {
     return GF_OK;
 }
 
-extern "C" int gf_plan_panel_info(const gf_plan* pl, int32_t op, int32_t* n_slices, int32_t* uniform, double* lds_cycles_per_step) {
+extern "C" int gf_plan_panel_info(const gf_plan* pl, int32_t op, int32_t* n_slices, int32_t* uniform, double* lds_cycles_per_step, double* fill) {
     GF_REQUIRE_ARG(pl != nullptr && (op == GF_OP_FWD || op == GF_OP_BWD), "gf_plan_panel_info: bad plan / op");
     const gf_csr_dev& m = pl->mat[op];
     if (n_slices) *n_slices = m.pn_slices;
     if (uniform) *uniform = m.pn_uniform;
     if (lds_cycles_per_step) *lds_cycles_per_step = m.pn_conflict;
+    if (fill) *fill = m.pn_fill;
     return GF_OK;
 }
 

@@ -127,7 +127,8 @@ int gf_grad_taps_panel(const float* Zp, const float* P0p, float* dh, float* dbia
                        int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K, void* stream);
 /* panel image of the plan: slices of 64 rows (0 = none, N too large), whether all stored values are equal (value-free
  * stream), and the modelled LDS cycles per ds_read_b128 step after the bank-aware neighbour ordering (4.0 = conflict-free) */
-int gf_plan_panel_info(const gf_plan* plan, int32_t op, int32_t* n_slices, int32_t* uniform, double* lds_cycles_per_step);
+int gf_plan_panel_info(const gf_plan* plan, int32_t op, int32_t* n_slices, int32_t* uniform, double* lds_cycles_per_step,
+                       double* fill);
 
 /* ---- edge-variant graph filter, per-edge storage: EVGF (graphML.py:389-488) as called by EdgeVariantGF.forward
  * (graphML.py:2670-2698).  ONE edge feature per call (the host sums over e; EVGF is linear in e).  The reference holds
@@ -163,7 +164,7 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * "spmm_pf" (workgroups per tile prefetching the next gather panel, -1 = heuristic, 0 = off), "spmm_ucap" (0 | 8 | 16 gathers in flight per lane), "spmm_load" (0 = plain | 1 = non-temporal gather loads),
  * "spmm_store" (0 = plain | 1 = write-through sc1 | 2 = non-temporal output stores), "contract_generic" (0/1),
  * "pipeline" (0 = auto | 1 = node-major | 2 = column panels), "panel_uniform" (0/1 use the value-free stream),
- * "panel_order" (0/1 bank-aware neighbour order; read by gf_plan_create), "panel_pace" (HBM loads in flight per panel loader wave: 1 | 2 | 4 | 8 | 0 = all).  Process-global, not thread-safe: for benchmarks and tests only. */
+ * "panel_order" (0/1 bank-aware neighbour order; read by gf_plan_create), "panel_sort" (0/1 octets sorted by longest row; read by gf_plan_create), "panel_stagger" (start delay step between workgroup phases, ~2 us units).  Process-global, not thread-safe: for benchmarks and tests only. */
 int gf_tune(const char* key, int32_t value);
 
 #ifdef __cplusplus

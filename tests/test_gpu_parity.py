@@ -452,7 +452,7 @@ def tune(**kw):
 @pytest.fixture
 def pipeline_knob():
     yield tune
-    tune(pipeline=0, panel_uniform=1, panel_order=1)
+    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1)
 
 
 def to_panels(x, N):
@@ -497,13 +497,18 @@ def test_spmm_hop_panel_against_scipy(N, P, kind, pipeline_knob):
         A.data[:] = 0.37
     gso = SparseGSO([A])
     plans = gso.plans(DEV)
-    ns, uni, cyc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
-    _lib.check(L.gf_plan_panel_info(plans[0], 0, ctypes.byref(ns), ctypes.byref(uni), ctypes.byref(cyc)))
+    ns, uni, cyc, fill = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
+    _lib.check(L.gf_plan_panel_info(plans[0], 0, ctypes.byref(ns), ctypes.byref(uni), ctypes.byref(cyc), ctypes.byref(fill)))
     assert ns.value == (N + 63) // 64 and uni.value == (1 if kind == "uniform" else 0) and 4.0 <= cyc.value <= 64.0
+    assert 0.0 < fill.value <= 1.0
     X = rng.randn(P, N, 4).astype(np.float32)
     Xt = cu(X)
     for use_uniform in ((1, 0) if kind == "uniform" else (1,)):
         pipeline_knob(panel_uniform=use_uniform)
+        if use_uniform == 0:                                 # also the unsorted / unordered plan image
+            pipeline_knob(panel_sort=0, panel_order=0)
+            gso = SparseGSO([A])
+            plans = gso.plans(DEV)
         for op, M in ((0, A.T.tocsr()), (1, A)):
             out = torch.full((P, N, 4), float("nan"), device=DEV)
             _lib.check(L.gf_spmm_hop_panel(plans[0], op, Xt.data_ptr(), out.data_ptr(), P, stream()))

@@ -14,11 +14,11 @@ gso = SparseGSO([graphgen.sbm(N, seed=0)]); plans = gso.plans(dev)
 P = B * W // 4
 X = torch.randn(P, N, 4, device=dev); Y = torch.empty_like(X)
 ms = ctypes.c_float()
-for stag in (0, 1, 2, 3, 4):
-  for dbg, what in ((0, f"full stagger={stag}"),):
+for pf in (1, 0):
+  for stag in (0, 1):
     for uni in (1, 0):
-        tune(panel_debug=dbg, panel_uniform=uni, panel_mode=0, spmm_store=0, panel_stagger=stag)
+        tune(panel_debug=0, panel_uniform=uni, spmm_store=0, panel_stagger=stag, panel_prefetch=pf)
         _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X.data_ptr(), Y.data_ptr(), P, 20, torch.cuda.current_stream().cuda_stream, ctypes.byref(ms)))
-        print(f"{ms.value*1e3:8.1f} us  uniform={uni}  {what}", flush=True)
+        print(f"{ms.value*1e3:8.1f} us  prefetch={pf} stagger={stag} uniform={uni}", flush=True)
 PY
 cat $O/phase.log

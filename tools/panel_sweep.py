@@ -28,17 +28,17 @@ for name in (sys.argv[1:] or ["cfg2", "cfg2w", "mid5k", "n2k"]):
     nbytes = 2 * B * N * W * 4 + A.nnz * 8 + (N + 1) * 4
     print(f"== {name}: N={N} nnz={A.nnz} B={B} W={W} panels={P} algorithmic MB/hop={nbytes/1e6:.1f} roof@8TB/s={nbytes/8e12*1e6:.1f} us", flush=True)
     ms = ctypes.c_float()
-    for order, srt in ((1, 0), (0, 0)):
+    for order, srt in ((1, 1), (0, 1), (1, 0)):
         tune(panel_order=order, panel_sort=srt)
         gso = SparseGSO([A]); plans = gso.plans(dev)   # gso owns the plans
-        ns, uni, cyc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
-        _lib.check(L.gf_plan_panel_info(plans[0], 0, ctypes.byref(ns), ctypes.byref(uni), ctypes.byref(cyc)))
+        ns, uni, cyc, fill = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(L.gf_plan_panel_info(plans[0], 0, ctypes.byref(ns), ctypes.byref(uni), ctypes.byref(cyc), ctypes.byref(fill)))
         for useu in ((1, 0) if uni.value else (0,)):
-            for pace, mode in ((0, 0), (4, 1)):
-                tune(panel_uniform=useu, spmm_store=0, panel_pace=pace, panel_mode=mode)
+            for stag in (0, 1, 2, 3):
+                tune(panel_uniform=useu, spmm_store=0, panel_stagger=stag)
                 _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, Xp.data_ptr(), Yp.data_ptr(), P, 20, st(), ctypes.byref(ms)))
                 print(f"  panel  {ms.value*1e3:8.1f} us  {nbytes/ms.value/1e6:8.1f} GB/s  {100*nbytes/ms.value/1e6/8000:5.1f}%  order={order} "
-                      f"sort={srt} (model {cyc.value:.2f} LDS cyc/step) uniform_stream={useu} mode={mode}", flush=True)
-    tune(panel_order=1, panel_sort=0, panel_uniform=1, spmm_store=2, panel_pace=4, panel_mode=0)
+                      f"sort={srt} (model {cyc.value:.2f} LDS cyc/step, ELL fill {fill.value:.2f}) uniform_stream={useu} stagger={stag}", flush=True)
+    tune(panel_order=1, panel_sort=1, panel_uniform=1, spmm_store=2, panel_stagger=1)
     _lib.check(L.gf_time_spmm_hop(plans[0], 0, Xn.data_ptr(), Yn.data_ptr(), B, W, 20, st(), ctypes.byref(ms)))
     print(f"  L2     {ms.value*1e3:8.1f} us  {nbytes/ms.value/1e6:8.1f} GB/s  {100*nbytes/ms.value/1e6/8000:5.1f}%  node-major gather kernel (defaults)", flush=True)
