@@ -10,10 +10,10 @@ through the C ABI; for N>1 plus the ONE bucketed RCCL all-reduce of the tap/bias
 per-GPU batch fixed).  Inputs are resident in HBM before the timed region.  value = B_global * nnz * K / t_step.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (the K-hop SpMM hop): achieved = algorithmic bytes per launch
-                  (2*B*N*G*4 + nnz*8 + (N+1)*4) / average launch time measured here with HIP events on
-                  the launch stream (gf_time_spmm_hop); peak = 8 TB/s HBM3E; traffic = PMC HBM bytes per launch when a
-                  profiles/*_pmc.json for this workload exists (collected with rocprofv3 --pmc in its own pass), else null.
+  roofline     -- the dominant kernel (one hop of the K-hop SpMM, in the pipeline the layer runs): achieved = algorithmic
+                  bytes per launch (2*B*N*G*4 + nnz*8 + (N+1)*4) / average launch time measured here with
+                  HIP events on the launch stream (gf_time_spmm_hop[_panel]); peak = 8 TB/s HBM3E; traffic = PMC HBM bytes
+                  per launch from profiles/*_pmc.json for this workload and kernel (rocprofv3 --pmc in its own pass), else null.
   cpu_baseline -- the reference's CPU path (oracle restatement of graphML.py:152-175: dense S, torch.matmul loop, cat,
                   permute) timed on this box's host cores on a bounded batch sample; rank 0, N=1 only.
 """
@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=64, help="batch entries of the workload timed on the CPU")
     ap.add_argument("--detail", action="store_true", help="per-kernel timings to stderr")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2], help="0 auto | 1 node-major (L2 gathers) | 2 column panels (LDS gathers)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,6 +75,8 @@ def main():
     from alegnn_amd import _lib, graphgen, parallel
     from alegnn_amd.utils import graphML as gml
 
+    if args.pipeline:
+        _lib.check(_lib.lib().gf_tune(b"pipeline", args.pipeline), "gf_tune pipeline")
     wl = WORKLOADS[args.workload]
     N, B, G, F, K = wl["N"], wl["B"], wl["G"], wl["F"], wl["K"]
     A = (graphgen.sbm if wl["model"] == "sbm" else graphgen.er)(N, avg_degree=wl["deg"], seed=0)
@@ -115,29 +118,38 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = (B * world) * nnz * K / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel: one SpMM hop, HIP events on the launch stream -------------------------
+    # ---- roofline of the dominant kernel: one SpMM hop of the pipeline the layer actually runs, HIP events on the
+    #      launch stream (gf_time_spmm_hop*: hipEventRecord on that stream around `iters` back-to-back launches) -----------
     L = _lib.lib()
     plans = layer._gso.plans(dev)
-    X0 = torch.randn(B, N, G, device=dev)
-    X1 = torch.empty_like(X0)
+    pipe = L.gf_lsigf_pipeline(plans, 1, G, F)
     ms = np.zeros(1, dtype=np.float32)
     stream = torch.cuda.current_stream().cuda_stream
-    _lib.check(L.gf_time_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, G, 20, stream,
-                                  ms.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+    msp = ms.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    if pipe == 2:                                            # column panels, gathers from LDS
+        X0 = torch.randn(B * G // 4, N, 4, device=dev)
+        X1 = torch.empty_like(X0)
+        _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B * G // 4, 20, stream, msp))
+        kname = "spmm_panel_kernel (one hop, op=S^T, column panels through LDS)"
+    else:                                                    # node-major, gathers through L2
+        X0 = torch.randn(B, N, G, device=dev)
+        X1 = torch.empty_like(X0)
+        _lib.check(L.gf_time_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, G, 20, stream, msp))
+        kname = "spmm_sell_kernel (one hop, op=S^T, node-major through L2)"
     hop_ms = float(ms[0])
-    hop_bytes = 2 * B * N * G * 4 + nnz * 8 + (N + 1) * 4
+    hop_bytes = 2 * B * N * G * 4 + nnz * 8 + (N + 1) * 4    # read X once, write X once, read the CSR once
     achieved = hop_bytes / (hop_ms * 1e-3) / 1e9
     traffic = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             pm = json.load(open(f))
-            if pm.get("workload") == args.workload and pm.get("kernel", "").startswith("spmm_hop"):
+            if pm.get("workload") == args.workload and pm.get("kernel", "").split("<")[0] == kname.split(" ")[0]:
                 traffic = pm.get("hbm_bytes_per_launch")
         except Exception:
             pass
-    roofline = dict(bound="hbm", kernel="spmm_hop_vec_kernel (one hop, op=S^T)", achieved=round(achieved, 1),
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    algorithmic_bytes=hop_bytes, launch_ms=round(hop_ms, 5))
+                    algorithmic_bytes=hop_bytes, launch_ms=round(hop_ms, 5), pipeline=int(pipe))
 
     detail = None
     if args.detail and rank == 0:
@@ -177,7 +189,26 @@ def kernel_breakdown(L, layer, plans, x, dy, B, N, G, F, K, dev):
     ws = torch.empty(nb // 4 + 1, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     w, b = layer.weight.detach(), layer.bias.detach()
-    calls = {
+    if L.gf_lsigf_pipeline(plans, 1, G, F) == 2:
+        def khop(buf, op, width):
+            tap = B * N * width
+            for k in range(1, K):
+                rc = L.gf_spmm_hop_panel(plans[0], op, buf.data_ptr() + 4 * tap * (k - 1), buf.data_ptr() + 4 * tap * k,
+                                         B * width // 4, st)
+                if rc:
+                    return rc
+            return 0
+        calls = {
+            "pack_x": lambda: L.gf_pack_panels(x.data_ptr(), Z.data_ptr(), B, G, N, N, st),
+            "khop_fwd(K-1 panel hops)": lambda: khop(Z, 0, G),
+            "contract_fwd": lambda: L.gf_contract_panel(Z.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, N, N, G, F, 1, K, 0, st),
+            "pack_dy": lambda: L.gf_pack_panels(dy.data_ptr(), P.data_ptr(), B, F, N, N, st),
+            "grad_taps": lambda: L.gf_grad_taps_panel(Z.data_ptr(), P.data_ptr(), dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, N, G, F, 1, K, st),
+            "khop_bwd(K-1 panel hops)": lambda: khop(P, 1, F),
+            "contract_bwd": lambda: L.gf_contract_panel(P.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, N, N, G, F, 1, K, 1, st),
+        }
+    else:
+      calls = {
         "layout_in": lambda: L.gf_layout_bgn_to_bng(x.data_ptr(), Z.data_ptr(), B, G, N, N, st),
         "khop_fwd(K-1 hops)": lambda: L.gf_khop(plans, 1, 0, Z.data_ptr(), B, G, K, st),
         "contract_fwd": lambda: L.gf_contract(Z.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, N, N, G, F, 1, K, 0, st),
@@ -185,7 +216,7 @@ def kernel_breakdown(L, layer, plans, x, dy, B, N, G, F, K, dev):
         "grad_taps": lambda: L.gf_grad_taps(Z.data_ptr(), P.data_ptr(), dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, N, G, F, 1, K, st),
         "khop_bwd(K-1 hops)": lambda: L.gf_khop(plans, 1, 1, P.data_ptr(), B, F, K, st),
         "contract_bwd": lambda: L.gf_contract(P.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, N, N, G, F, 1, K, 1, st),
-    }
+      }
     out = {}
     for name, fn in calls.items():
         ts = []
