@@ -68,9 +68,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs; there is no CPU fallback"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    distributed = world > 1 or "RANK" in os.environ       # under torch.distributed.run even N = 1 goes through RCCL
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from alegnn_amd import _lib, graphgen, parallel
     from alegnn_amd.utils import graphML as gml
@@ -99,8 +102,8 @@ def main():
         bucket.allreduce_mean()
 
     def sync_all():
-        if world > 1:
-            dist.barrier()
+        if distributed:
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -111,9 +114,9 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # the slowest rank defines the step time
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = (B * world) * nnz * K / (elapsed / args.steps)
@@ -171,7 +174,7 @@ def main():
         if detail:
             out["breakdown_ms"] = detail
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

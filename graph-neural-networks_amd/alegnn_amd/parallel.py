@@ -11,8 +11,13 @@ backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+# GFHIP_FORCE_COLLECTIVES=1: issue the collectives even at world size 1 (exercises the RCCL path on a one-GPU box)
+_FORCE = os.environ.get("GFHIP_FORCE_COLLECTIVES", "0") == "1"
 
 
 class GradBucket:
@@ -43,7 +48,7 @@ class GradBucket:
         an equal share of the batch (nn.CrossEntropyLoss / SmoothL1Loss default reduction, sourceLocGNN.py:167)."""
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(self.group)
-            if world > 1:
+            if world > 1 or _FORCE:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
                 self.flat.div_(world)
         return self.flat
@@ -67,6 +72,6 @@ def shard_batch(indices, rank=None, world=None):
 
 def broadcast_parameters(module, src=0):
     """Make every rank start from rank ``src``'s parameters (replicas must be identical for DP to be exact)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE):
         for p in module.parameters():
             dist.broadcast(p.data, src=src)

@@ -34,7 +34,9 @@ int khop_panel(const gf_plan* const* plans, int E, int op, float* Zp, int B, int
         for (int k = 1; k < K; ++k) {
             const float* src = (k == 1) ? Zp : Zp + (int64_t)(1 + e * (K - 1) + (k - 2)) * tap;
             float* dst = Zp + (int64_t)(1 + e * (K - 1) + (k - 1)) * tap;
-            const int rc = gf_spmm_panel_launch(plans[e], op, src, dst, B * (W / 4), st);
+            // Successive hops walk the panels in opposite directions: hop k reads first what hop k-1 wrote last, i.e. what is
+            // most likely still in the 256 MiB Infinity Cache (a same-direction walk evicts every panel before it is re-read).
+            const int rc = gf_spmm_panel_launch(plans[e], op, src, dst, B * (W / 4), st, g_tune.panel_zigzag ? (k & 1) : 0);
             if (rc != GF_OK) return rc;
         }
     return GF_OK;

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                                                           const uint2* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
                                                           int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug,
-                                                          int stagger, int ush) {
+                                                          int stagger, int ush, int reverse) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
             // and panel -- was measured and gave nothing: 184 vs 181 us; a CU pulls at most ~22 GB/s from HBM and the
             // entry streams compete for the same L1 miss queue.)
             constexpr int kNVU = 10;
-            const f32x4* src = reinterpret_cast<const f32x4*>(Xin + (int64_t)p * pstride);
+            const f32x4* src = reinterpret_cast<const f32x4*>(Xin + (int64_t)(reverse ? nPanels - 1 - p : p) * pstride);
             f32x4 tmp[kNVU];
             const int nthr = (int)blockDim.x;
 #pragma unroll
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
         }
         __syncthreads();  // B1: panel p is in LDS
         if (wave < nSlices && debug != 1) {
-            float* outp = Xout + (int64_t)p * pstride;
+            float* outp = Xout + (int64_t)(reverse ? nPanels - 1 - p : p) * pstride;
             int s = wave;                       // slice in hand
             int2 si = slice[s];                 // {group-row offset, group-rows}
             int oc = octs[(s << (6 - ush)) + (lane >> ush)];
@@ -244,7 +244,7 @@ int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int 
     return GF_OK;
 }
 
-int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st) {
+int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st, int reverse) {
     const gf_csr_dev& m = plan->mat[op];
     const int N = plan->n;
     GF_REQUIRE_ARG(m.pn_slices > 0, "gf_spmm_hop_panel: the plan has no panel image (N = %d > %d?)", N, kPanelMaxNodes);
@@ -260,7 +260,7 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     auto kern = uniform ? spmm_panel_kernel<1> : spmm_panel_kernel<0>;
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_oct, m.pn_col4, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift);
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, reverse);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }
@@ -288,7 +288,7 @@ extern "C" int gf_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* X
     GF_REQUIRE_ARG(Xin != Xout, "gf_spmm_hop_panel: in-place hop is not supported");
     GF_REQUIRE_SHAPE(n_panels > 0, "gf_spmm_hop_panel: n_panels = %d", n_panels);
     GF_REQUIRE_SHAPE(plan->n <= kPanelMaxNodes, "gf_spmm_hop_panel: N = %d exceeds the LDS panel limit %d", plan->n, kPanelMaxNodes);
-    return gf_spmm_panel_launch(plan, op, Xin, Xout, n_panels, gf_stream(stream));
+    return gf_spmm_panel_launch(plan, op, Xin, Xout, n_panels, gf_stream(stream), 0);
 }
 
 extern "C" int gf_time_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, float* Xout, int32_t n_panels, int32_t iters,

@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "
 tail -4 $O/pytest_gpu.log
 timeout 400 python bench.py --detail > $O/bench_cfg2.json 2> $O/bench_cfg2.err; cat $O/bench_cfg2.json
 timeout 400 python bench.py --detail --pipeline 1 --no-cpu-baseline > $O/bench_cfg2_pipe1.json 2> $O/bench_cfg2_pipe1.err; cat $O/bench_cfg2_pipe1.json
-timeout 400 python bench.py --workload cfg4 --steps 10 --warmup 3 --detail --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err; cat $O/bench_cfg4.json
+GFHIP_FORCE_COLLECTIVES=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err; cat $O/bench_torchrun1.json; tail -3 $O/bench_torchrun1.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats_full.csv
 python - <<'PY'
