@@ -114,11 +114,99 @@ __global__ __launch_bounds__(kThreads) void ev_hop_kernel(const int32_t* __restr
         const float* vin = in + (c / in_div) * NB + b;
         float acc = add ? add[(c / add_div) * NB + nb] : 0.f;
         const int q1 = rowptr[i + 1];
-        for (int q = rowptr[i]; q < q1; ++q) {
+        int q = rowptr[i];
+        // 4 entries per round: all index / weight loads first, then the 4 gathers they address, then the FMAs in entry
+        // order (fixed summation order) -- a one-entry loop is a chain of two dependent L2 round trips per entry
+        for (; q + 3 < q1; q += 4) {
+            int cj[4], pj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cj[u] = col[q + u];
+                pj[u] = vidx ? vidx[q + u] : q + u;
+            }
+            float wv[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                wv[u] = W[pj[u]];
+                xv[u] = vin[(int64_t)cj[u] * B];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(wv[u], xv[u], acc);
+        }
+        for (; q < q1; ++q) {
             const int p = vidx ? vidx[q] : q;
             acc = fmaf(W[p], vin[(int64_t)col[q] * B], acc);
         }
         out[idx] = acc;
+    }
+}
+
+// ---- the same tap with the pattern segment of a row block staged in LDS (B <= 64): one workgroup = one chain x kRowsPerWG
+// consecutive rows.  The (column, weight) pairs of those rows are loaded once, coalesced (3 of the 4 global loads per entry
+// and thread of the kernel above were index / weight fetches with 16 useful bytes per wave-instruction), then every thread
+// (row, b) walks its row from LDS and only the gathers of v_{k-1} go to memory, 4 in flight per thread.
+constexpr int kRowsPerWG = 128;
+constexpr int kEvChunk = 2048;  // staged entries per pass (16 KB of LDS)
+
+template <int LB>
+__global__ __launch_bounds__(kThreads) void ev_hop_lds_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                              const int32_t* __restrict__ vidx, const float* __restrict__ wedge,
+                                                              const float* __restrict__ in, const float* __restrict__ add,
+                                                              float* __restrict__ out, int N, int B, int G, int K1, int kidx,
+                                                              int64_t nnzp, int in_div, int add_div, int nRowBlocks) {
+    constexpr int RPP = kThreads / LB;  // rows per pass
+    constexpr int RPW = RPP > kRowsPerWG ? RPP : kRowsPerWG;  // rows per workgroup
+    __shared__ int32_t s_col[kEvChunk];
+    __shared__ float s_w[kEvChunk];
+    const int64_t NB = (int64_t)N * B;
+    const int c = blockIdx.x / nRowBlocks;            // chain-major: the workgroups in flight share a gather panel in L2
+    const int rb = blockIdx.x - c * nRowBlocks;
+    const int r0 = rb * RPW, r1 = min(N, r0 + RPW);
+    const int f = c / G, g = c - f * G;
+    const float* W = wedge + ((int64_t)(f * K1 + kidx) * G + g) * nnzp;
+    const int tid = threadIdx.x, lr = tid / LB, b = tid - lr * LB;
+    const float* vin = in + (int64_t)(c / in_div) * NB + b;
+    const int seg_lo = rowptr[r0], seg_hi = rowptr[r1];
+    float acc[RPW / RPP];
+#pragma unroll
+    for (int j = 0; j < RPW / RPP; ++j) acc[j] = 0.f;
+    for (int base = seg_lo; base < seg_hi; base += kEvChunk) {
+        const int cnt = min(kEvChunk, seg_hi - base);
+        if (base != seg_lo) __syncthreads();
+        for (int i = tid; i < cnt; i += kThreads) {
+            s_col[i] = col[base + i];
+            s_w[i] = W[vidx ? vidx[base + i] : base + i];
+        }
+        __syncthreads();
+        if (b < B) {
+#pragma unroll
+            for (int j = 0; j < RPW / RPP; ++j) {
+                const int r = r0 + j * RPP + lr;
+                if (r >= r1) break;
+                int q = max(rowptr[r], base) - base;
+                const int qe = min(rowptr[r + 1], base + cnt) - base;
+                float a = acc[j];
+                for (; q + 3 < qe; q += 4) {
+                    const float x0 = vin[(int64_t)s_col[q] * B], x1 = vin[(int64_t)s_col[q + 1] * B];
+                    const float x2 = vin[(int64_t)s_col[q + 2] * B], x3 = vin[(int64_t)s_col[q + 3] * B];
+                    a = fmaf(s_w[q], x0, a);
+                    a = fmaf(s_w[q + 1], x1, a);
+                    a = fmaf(s_w[q + 2], x2, a);
+                    a = fmaf(s_w[q + 3], x3, a);
+                }
+                for (; q < qe; ++q) a = fmaf(s_w[q], vin[(int64_t)s_col[q] * B], a);
+                acc[j] = a;
+            }
+        }
+    }
+    if (b < B) {
+#pragma unroll
+        for (int j = 0; j < RPW / RPP; ++j) {
+            const int r = r0 + j * RPP + lr;
+            if (r >= r1) break;
+            const int64_t o = (int64_t)r * B + b;
+            out[(int64_t)c * NB + o] = acc[j] + (add ? add[(int64_t)(c / add_div) * NB + o] : 0.f);
+        }
     }
 }
 
@@ -155,16 +243,40 @@ __global__ __launch_bounds__(kThreads) void ev_sddmm_kernel(const int32_t* __res
     const int lane = threadIdx.x % LB;
     const int64_t g0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LB;
     const int64_t gstep = (int64_t)gridDim.x * kThreads / LB;
+    // EPG consecutive pattern entries of one chain per lane group and round: their (row, col) pairs are loaded first, then
+    // the 2*EPG gathers, then the fixed-order reductions -- one entry per round is three dependent L2 round trips.
+    constexpr int EPG = 4;
+    const int64_t epc = (nnzp + EPG - 1) / EPG;  // entry quads per chain
     for (int64_t grp = g0; grp < groups; grp += gstep) {  // whole LB-lane groups leave the loop together
-        const int64_t c = grp / nnzp, p = grp - c * nnzp;
-        const float* u = U + (c / u_div) * NB + (int64_t)row[p] * B;
-        const float* v = V + c * NB + (int64_t)col[p] * B;
-        float acc = 0.f;
-        for (int b = lane; b < B; b += LB) acc = fmaf(u[b], v[b], acc);
-        acc = group_sum<LB>(acc);
-        if (lane == 0) {
-            const int f = (int)(c / G), g = (int)(c - (int64_t)f * G);
-            dwedge[((int64_t)(f * K1 + kidx) * G + g) * nnzp + p] = acc;
+        const int64_t c = grp / epc, p0 = (grp - c * epc) * EPG;
+        const float* ub = U + (c / u_div) * NB;
+        const float* vb = V + c * NB;
+        int ri[EPG], ci[EPG];
+#pragma unroll
+        for (int e = 0; e < EPG; ++e) {
+            const int64_t p = p0 + e < nnzp ? p0 + e : nnzp - 1;  // clamp: the surplus lanes of the last quad recompute its last entry
+            ri[e] = row[p];
+            ci[e] = col[p];
+        }
+        float acc[EPG];
+#pragma unroll
+        for (int e = 0; e < EPG; ++e) acc[e] = 0.f;
+        for (int b = lane; b < B; b += LB) {
+            float uu[EPG], vv[EPG];
+#pragma unroll
+            for (int e = 0; e < EPG; ++e) {
+                uu[e] = ub[(int64_t)ri[e] * B + b];
+                vv[e] = vb[(int64_t)ci[e] * B + b];
+            }
+#pragma unroll
+            for (int e = 0; e < EPG; ++e) acc[e] = fmaf(uu[e], vv[e], acc[e]);
+        }
+        const int f = (int)(c / G), g = (int)(c - (int64_t)f * G);
+        float* dst = dwedge + ((int64_t)(f * K1 + kidx) * G + g) * nnzp;
+#pragma unroll
+        for (int e = 0; e < EPG; ++e) {
+            const float tot = group_sum<LB>(acc[e]);
+            if (lane == 0 && p0 + e < nnzp) dst[p0 + e] = tot;
         }
     }
 }
@@ -225,6 +337,39 @@ int lanes_for_batch(int B) {
     int lb = 1;
     while (lb < B && lb < 64) lb <<= 1;
     return lb;
+}
+
+
+int launch_ev_hop(const int32_t* rowptr, const int32_t* col, const int32_t* vidx, const float* wedge, const float* in, const float* add,
+                  float* out, int N, int B, int G, int C, int K1, int kidx, int64_t nnzp, int in_div, int add_div, hipStream_t st) {
+    const int64_t NB = (int64_t)N * B, CNB = (int64_t)C * NB;
+    const int lbw = lanes_for_batch(B);
+    const int rpw = std::max(kRowsPerWG, kThreads / lbw);  // rows per workgroup (RPW of ev_hop_lds_kernel)
+    const int nRowBlocks = (N + rpw - 1) / rpw;
+    const int64_t nblk = (int64_t)C * nRowBlocks;
+    static const int env_generic = getenv("GFHIP_EVGF_GENERIC") ? atoi(getenv("GFHIP_EVGF_GENERIC")) : 0;
+    if (B <= 64 && nblk < (int64_t)INT32_MAX && !env_generic) {
+        const int lb = lanes_for_batch(B);
+#define GF_EVHOP(LBV)                                                                                                         \
+    hipLaunchKernelGGL((ev_hop_lds_kernel<LBV>), dim3((unsigned)nblk), dim3(kThreads), 0, st, rowptr, col, vidx, wedge, in, add, out, \
+                       N, B, G, K1, kidx, nnzp, in_div, add_div, nRowBlocks)
+        switch (lb) {
+            case 1: GF_EVHOP(1); break;
+            case 2: GF_EVHOP(2); break;
+            case 4: GF_EVHOP(4); break;
+            case 8: GF_EVHOP(8); break;
+            case 16: GF_EVHOP(16); break;
+            case 32: GF_EVHOP(32); break;
+            default: GF_EVHOP(64); break;
+        }
+#undef GF_EVHOP
+        GF_LAUNCH_CHECK("ev_hop_lds_kernel");
+        return GF_OK;
+    }
+    hipLaunchKernelGGL(ev_hop_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, rowptr, col, vidx, wedge, in, add, out, N, B, G, K1,
+                       kidx, nnzp, in_div, add_div, CNB);
+    GF_LAUNCH_CHECK("ev_hop_kernel");
+    return GF_OK;
 }
 
 template <class T>
@@ -343,10 +488,9 @@ extern "C" int gf_evgf_forward(const gf_ev_plan* plan, const float* x, const flo
     hipLaunchKernelGGL(ev_tap0_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, wdiag, Xt, V, G, NB, B, CNB);
     GF_LAUNCH_CHECK("ev_tap0_kernel");
     for (int k = 1; k < K; ++k) {
-        hipLaunchKernelGGL(ev_hop_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, plan->rowptr, plan->col, (const int32_t*)nullptr,
-                           wedge, V + (int64_t)(k - 1) * CNB, (const float*)nullptr, V + (int64_t)k * CNB, N, B, G, K - 1, k - 1,
-                           plan->nnzp, 1, 1, CNB);
-        GF_LAUNCH_CHECK("ev_hop_kernel");
+        rc = launch_ev_hop(plan->rowptr, plan->col, nullptr, wedge, V + (int64_t)(k - 1) * CNB, nullptr, V + (int64_t)k * CNB, N, B,
+                           G, C, K - 1, k - 1, plan->nnzp, 1, 1, st);
+        if (rc != GF_OK) return rc;
     }
     const int64_t FNB = (int64_t)F * NB;
     hipLaunchKernelGGL(ev_sum_kernel, dim3(grid_for(FNB)), dim3(kThreads), 0, st, V, bias, Yt, G, K, NB, CNB, FNB);
@@ -379,7 +523,7 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
     const int lb = lanes_for_batch(B);
     for (int k = K - 1; k >= 1; --k) {
         if (dwedge) {
-            const int64_t groups = (int64_t)C * plan->nnzp;
+            const int64_t groups = (int64_t)C * ((plan->nnzp + 3) / 4);  // entry quads (EPG = 4 in ev_sddmm_kernel)
             const unsigned grid = grid_for(groups * lb);
 #define GF_SDDMM(LBV)                                                                                                         \
     hipLaunchKernelGGL((ev_sddmm_kernel<LBV>), dim3(grid), dim3(kThreads), 0, st, plan->row, plan->col, Ucur,                  \
@@ -397,9 +541,9 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
             GF_LAUNCH_CHECK("ev_sddmm_kernel");
         }
         if (k > 1 || dwdiag || dx) {  // u_{k-1} = Phi_k^T u_k + dy_f
-            hipLaunchKernelGGL(ev_hop_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, plan->t_rowptr, plan->t_col, plan->t_vidx,
-                               wedge, Ucur, Dyt, Ubuf[pp], N, B, G, K - 1, k - 1, plan->nnzp, udiv, G, CNB);
-            GF_LAUNCH_CHECK("ev_hop_kernel(transposed)");
+            rc = launch_ev_hop(plan->t_rowptr, plan->t_col, plan->t_vidx, wedge, Ucur, Dyt, Ubuf[pp], N, B, G, C, K - 1, k - 1,
+                               plan->nnzp, udiv, G, st);
+            if (rc != GF_OK) return rc;
             Ucur = Ubuf[pp];
             udiv = 1;
             pp ^= 1;

@@ -618,3 +618,41 @@ def test_pipelines_agree_at_full_size(cfg2, pipeline_knob):
     assert _lib.lib().gf_lsigf_pipeline(layer._gso.plans(DEV), 1, layer.G, layer.F) == 2
     for a, b_ in zip(res[1], res[2]):
         assert float((a - b_).abs().max()) <= 2e-6 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=200, B=6, G=16, F=24, K=3, E=2, nin=200, density=0.05),       # two edge features through the panel pipeline
+    dict(N=333, B=3, G=8, F=8, K=1, E=1, nin=333, density=0.03),         # K = 1: no hop at all
+    dict(N=500, B=5, G=32, F=16, K=4, E=1, nin=123, density=0.02),       # Nin < N: zero padding + kept nodes
+    dict(N=64, B=2, G=8, F=8, K=3, E=1, nin=64, density=0.0),            # empty GSO: y = h_0 x + b
+    dict(N=5200, B=9, G=8, F=8, K=3, E=1, nin=5200, density=0.002),      # 1024-thread panel workgroups, ragged last slice
+], ids=lambda c: "N%d_G%d_F%d_K%d_E%d_Nin%d" % (c["N"], c["G"], c["F"], c["K"], c["E"], c["nin"]))
+@pytest.mark.parametrize("pipe", [1, 2])
+def test_lsigf_edge_cases_under_both_pipelines(cfg, pipe, pipeline_knob):
+    N, B, G, F, K, E, nin = (cfg[k] for k in ("N", "B", "G", "F", "K", "E", "nin"))
+    rng = np.random.RandomState(N + K)
+    mats = []
+    for e in range(E):
+        A = sp.random(N, N, density=cfg["density"], format="csr", random_state=rng, data_rvs=rng.randn)
+        mats.append(A * (0.5 / max(1.0, abs(A).sum(axis=1).max())) if A.nnz else A)
+    pipeline_knob(pipeline=pipe)
+    gso = SparseGSO(mats)
+    assert _lib.lib().gf_lsigf_pipeline(gso.plans(DEV), E, G, F) == pipe
+    h = (rng.uniform(-1, 1, (F, E, K, G)) / np.sqrt(G * K)).astype(np.float32)
+    x = rng.randn(B, G, nin).astype(np.float32)
+    b = rng.uniform(-1, 1, (F, 1)).astype(np.float32)
+    dy = rng.randn(B, F, nin).astype(np.float32)
+    ht, xt, bt = cu(h, True), cu(x, True), cu(b, True)
+    y = LSIGF(ht, gso, xt, bt)
+    assert tuple(y.shape) == (B, F, nin)
+    y.backward(cu(dy))
+    xp = np.zeros((B, G, N), dtype=np.float32)
+    xp[:, :, :nin] = x
+    dyp = np.zeros((B, F, N), dtype=np.float32)
+    dyp[:, :, :nin] = dy
+    want = orc.lsigf_sparse(h, mats, xp, b)[:, :, :nin]
+    dx, dh, db = orc.lsigf_sparse_grads(h, mats, xp, b, dyp)
+    assert relerr(y.detach().cpu().numpy(), want) < FWD_RTOL
+    assert relerr(xt.grad.cpu().numpy(), dx[:, :, :nin]) < GRAD_RTOL
+    assert relerr(ht.grad.cpu().numpy(), dh) < GRAD_RTOL
+    assert relerr(bt.grad.cpu().numpy(), db) < GRAD_RTOL
