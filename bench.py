@@ -193,7 +193,7 @@ def kernel_breakdown(L, layer, plans, x, dy, B, N, G, F, K, dev):
     st = torch.cuda.current_stream().cuda_stream
     w, b = layer.weight.detach(), layer.bias.detach()
     if L.gf_lsigf_pipeline(plans, 1, G, F) == 2:
-        def khop(buf, op, width):
+        def khop(buf, op, width):                            # as separate launches (the layer fuses the K-1 hops of a chain)
             tap = B * N * width
             for k in range(1, K):
                 rc = L.gf_spmm_hop_panel(plans[0], op, buf.data_ptr() + 4 * tap * (k - 1), buf.data_ptr() + 4 * tap * k,

@@ -10,7 +10,7 @@
 //
 // Two interchangeable pipelines produce bit-for-bit the same interface (x, dy, y, dx in the reference layout; Z / P opaque):
 //   node-major  Z[T][B][N][G]        gathers served by L2            (gf_spmm.hip)     any N, any widths
-//   panels      Z[T][B*G/4][N][4]    gathers served by LDS           (gf_panel.hip)    N <= 10239, G % 8 == F % 8 == 0
+//   panels      Z[T][B*G/4][N][4]    gathers served by LDS           (gf_panel.hip)    N <= 10239, G and F in {8,16,32,64,128}
 // gf_lsigf_pipeline() tells which one a (plans, G, F) combination runs; forward and backward always agree because the rule
 // depends only on those arguments (and the process-global tuning knob "pipeline").
 #include "gf_common.h"
@@ -20,7 +20,7 @@ namespace {
 int pick_pipeline(const gf_plan* const* plans, int E, int G, int F) {  // 1 = node-major, 2 = panels, < 0 = error
     const bool ok = gf_panel_supported(plans, E, G, F);
     if (g_tune.pipeline == 2 && !ok) {
-        gf_set_error("pipeline 2 (column panels) forced but unsupported here: needs N in [8, %d], G %% 8 == F %% 8 == 0, widths <= 128",
+        gf_set_error("pipeline 2 (column panels) forced but unsupported here: needs N in [8, %d], G and F in {8, 16, 32, 64, 128}",
                      kPanelMaxNodes);
         return GF_ERR_UNSUPPORTED;
     }
@@ -30,15 +30,21 @@ int pick_pipeline(const gf_plan* const* plans, int E, int G, int F) {  // 1 = no
 
 int khop_panel(const gf_plan* const* plans, int E, int op, float* Zp, int B, int W, int K, hipStream_t st) {
     const int64_t tap = (int64_t)B * plans[0]->n * W;
-    for (int e = 0; e < E; ++e)
+    const int nPanels = B * (W / 4);
+    if (K < 2) return GF_OK;
+    for (int e = 0; e < E; ++e) {
+        float* first = Zp + (int64_t)(1 + e * (K - 1)) * tap;  // taps 1 + e(K-1) ... of this edge feature are consecutive
+        if (g_tune.panel_fuse_hops) {  // one launch: every workgroup walks its panels through all K-1 hops (zigzag-free, cache-hot reloads)
+            const int rc = gf_spmm_panel_launch(plans[e], op, Zp, first, nPanels, st, K - 1, tap);
+            if (rc != GF_OK) return rc;
+            continue;
+        }
         for (int k = 1; k < K; ++k) {
-            const float* src = (k == 1) ? Zp : Zp + (int64_t)(1 + e * (K - 1) + (k - 2)) * tap;
-            float* dst = Zp + (int64_t)(1 + e * (K - 1) + (k - 1)) * tap;
-            // Successive hops walk the panels in opposite directions: hop k reads first what hop k-1 wrote last, i.e. what is
-            // most likely still in the 256 MiB Infinity Cache (a same-direction walk evicts every panel before it is re-read).
-            const int rc = gf_spmm_panel_launch(plans[e], op, src, dst, B * (W / 4), st, g_tune.panel_zigzag ? (k & 1) : 0);
+            const float* src = (k == 1) ? Zp : first + (int64_t)(k - 2) * tap;
+            const int rc = gf_spmm_panel_launch(plans[e], op, src, first + (int64_t)(k - 1) * tap, nPanels, st, 1, 0);
             if (rc != GF_OK) return rc;
         }
+    }
     return GF_OK;
 }
 

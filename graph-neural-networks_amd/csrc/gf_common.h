@@ -114,7 +114,7 @@ struct gf_tuning {
     int pipeline = 0;           // 0 = auto, 1 = node-major (gather through L2), 2 = column panels through LDS (needs N <= 10239, G%8 == F%8 == 0)
     int panel_uniform = 1;      // 1 = use the value-free stream when the plan detected uniform values
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
-    int panel_zigzag = 0;       // 1 = successive hops walk the panels in alternating order (measured: no effect, 2.85 ms/step either way)
+    int panel_fuse_hops = 0;    // 1 = the K-1 hops of a chain are one launch (each workgroup walks its panels through all hops); measured: no gain
     int panel_stagger = 1;      // unified mode: start delay step between workgroup phases, in ~2 us units (0 = start together)
     int panel_debug = 0;        // timing experiments only: 1 = skip the compute phase, 2 = skip the panel load (WRONG RESULTS)
     int panel_unit = 8;         // rows per work unit of the panel image: 8 | 4 | 2 (set BEFORE gf_plan_create)
@@ -128,6 +128,7 @@ int gf_contract_launch(const float* Z, const float* h, const float* bias, float*
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)
 bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F);
 int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st);
-int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st, int reverse);
+int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st, int nHops,
+                         int64_t tapStride);
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
                              int F, int E, int K, int transpose_bank, hipStream_t st);

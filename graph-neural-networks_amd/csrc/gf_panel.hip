@@ -41,7 +41,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                                                           const uint2* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
                                                           int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug,
-                                                          int stagger, int ush, int reverse) {
+                                                          int stagger, int ush, int nHops, int64_t tapStride) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,13 +70,19 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     };
 
     for (;;) {
+      // nHops successive hops of the SAME panel (hops of different panels are independent): hop h reads what hop h-1 of this
+      // workgroup just stored (tap stride tapStride), i.e. from L2 / Infinity Cache instead of an HBM-latency-bound reload,
+      // and the K-1 hops of a chain are one launch.
+      for (int h = 0; h < nHops; ++h) {
+        const float* srcp = (h == 0 ? Xin : Xout + (int64_t)(h - 1) * tapStride) + (int64_t)p * pstride;
+        float* outp = Xout + (int64_t)h * tapStride + (int64_t)p * pstride;
         if (debug != 2) {
             // HBM-bound phase: every wave loads its share of the panel (N <= kNVU * blockDim.x rows of 16 bytes).
             // (Requesting the NEXT panel from inside the compute phase instead -- registers, one HBM-latency stall per wave
             // and panel -- was measured and gave nothing: 184 vs 181 us; a CU pulls at most ~22 GB/s from HBM and the
             // entry streams compete for the same L1 miss queue.)
             constexpr int kNVU = 10;
-            const f32x4* src = reinterpret_cast<const f32x4*>(Xin + (int64_t)(reverse ? nPanels - 1 - p : p) * pstride);
+            const f32x4* src = reinterpret_cast<const f32x4*>(srcp);
             f32x4 tmp[kNVU];
             const int nthr = (int)blockDim.x;
 #pragma unroll
@@ -87,7 +93,6 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
         }
         __syncthreads();  // B1: panel p is in LDS
         if (wave < nSlices && debug != 1) {
-            float* outp = Xout + (int64_t)(reverse ? nPanels - 1 - p : p) * pstride;
             int s = wave;                       // slice in hand
             int2 si = slice[s];                 // {group-row offset, group-rows}
             int oc = octs[(s << (6 - ush)) + (lane >> ush)];
@@ -169,7 +174,9 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 if (process(cB, vB, cA, vA)) break;
             }
         }
+        if (nHops > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows have reached L2 before anyone reloads them
         __syncthreads();  // B2: every wave is done reading panel p
+      }
         p += (int)gridDim.x;
         if (p >= nPanels) break;
     }
@@ -229,7 +236,8 @@ unsigned grid_for(int64_t items) {
 }  // namespace
 
 bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F) {
-    if (G % 8 != 0 || F % 8 != 0 || G > 128 || F > 128) return false;  // hop width % 4 and the MFMA contraction's Cin % 8
+    auto ok = [](int w) { return w == 8 || w == 16 || w == 32 || w == 64 || w == 128; };  // the MFMA contraction's Cin tiles
+    if (!ok(G) || !ok(F)) return false;
     for (int e = 0; e < E; ++e) {
         if (!plans[e] || plans[e]->n > kPanelMaxNodes || plans[e]->n < 8) return false;
         if (plans[e]->mat[0].pn_slices == 0 || plans[e]->mat[1].pn_slices == 0) return false;
@@ -244,7 +252,8 @@ int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int 
     return GF_OK;
 }
 
-int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st, int reverse) {
+int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st, int nHops,
+                         int64_t tapStride) {
     const gf_csr_dev& m = plan->mat[op];
     const int N = plan->n;
     GF_REQUIRE_ARG(m.pn_slices > 0, "gf_spmm_hop_panel: the plan has no panel image (N = %d > %d?)", N, kPanelMaxNodes);
@@ -260,7 +269,7 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     auto kern = uniform ? spmm_panel_kernel<1> : spmm_panel_kernel<0>;
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_oct, m.pn_col4, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, reverse);
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }
@@ -288,7 +297,7 @@ extern "C" int gf_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* X
     GF_REQUIRE_ARG(Xin != Xout, "gf_spmm_hop_panel: in-place hop is not supported");
     GF_REQUIRE_SHAPE(n_panels > 0, "gf_spmm_hop_panel: n_panels = %d", n_panels);
     GF_REQUIRE_SHAPE(plan->n <= kPanelMaxNodes, "gf_spmm_hop_panel: N = %d exceeds the LDS panel limit %d", plan->n, kPanelMaxNodes);
-    return gf_spmm_panel_launch(plan, op, Xin, Xout, n_panels, gf_stream(stream), 0);
+    return gf_spmm_panel_launch(plan, op, Xin, Xout, n_panels, gf_stream(stream), 1, 0);
 }
 
 extern "C" int gf_time_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, float* Xout, int32_t n_panels, int32_t iters,

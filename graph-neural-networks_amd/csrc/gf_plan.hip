@@ -43,7 +43,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_unit")) g_tune.panel_unit = value;
     else if (!strcmp(key, "panel_debug")) g_tune.panel_debug = value;
     else if (!strcmp(key, "panel_stagger")) g_tune.panel_stagger = value;
-    else if (!strcmp(key, "panel_zigzag")) g_tune.panel_zigzag = value;
+    else if (!strcmp(key, "panel_fuse_hops")) g_tune.panel_fuse_hops = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);
         return GF_ERR_ARG;

@@ -106,7 +106,7 @@ int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const float* dy, c
                       float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
                       int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
 
-/* ---- column-panel pipeline: the same hot path with the gathers served from LDS (N <= 10239 nodes; widths multiple of 8).
+/* ---- column-panel pipeline: the same hot path with the gathers served from LDS (N <= 10239 nodes; G and F in {8, 16, 32, 64, 128}).
  * Layout: Xp[P][N][4], P = B*C/4 panels of 4 consecutive signal columns (b, c..c+3): 16 bytes per node, one panel fills
  * at most 160 KiB = one CU's LDS.  Tap stack Zp[T][B*C/4][N][4] (same size as the node-major stack).
  * gf_lsigf_forward / _backward pick this pipeline by themselves (gf_lsigf_pipeline tells which: 1 node-major, 2 panels);

@@ -452,7 +452,7 @@ def tune(**kw):
 @pytest.fixture
 def pipeline_knob():
     yield tune
-    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1)
+    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_fuse_hops=0)
 
 
 def to_panels(x, N):
@@ -606,22 +606,24 @@ def test_pipelines_agree_at_full_size(cfg2, pipeline_knob):
     layer, x = cfg2["layer"], cfg2["x"]
     dy = torch.randn(x.shape[0], layer.F, x.shape[2], device=DEV)
     res = {}
-    for pipe in (1, 2):
-        pipeline_knob(pipeline=pipe)
+    for pipe in (1, 2, 3):                                  # 3 = panels with the K-1 hops of a chain fused into one launch
+        pipeline_knob(pipeline=min(pipe, 2), panel_fuse_hops=int(pipe == 3))
         xx = x.detach().clone().requires_grad_(True)
         for p_ in layer.parameters():
             p_.grad = None
         y = layer(xx)
         y.backward(dy)
         res[pipe] = (y.detach().clone(), xx.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone())
-    pipeline_knob(pipeline=0)
+    pipeline_knob(pipeline=0, panel_fuse_hops=0)
     assert _lib.lib().gf_lsigf_pipeline(layer._gso.plans(DEV), 1, layer.G, layer.F) == 2
     for a, b_ in zip(res[1], res[2]):
         assert float((a - b_).abs().max()) <= 2e-6 * float(a.abs().max())
+    for a, b_ in zip(res[2], res[3]):
+        assert torch.equal(a, b_)                            # same kernel, same order: bitwise
 
 
 @pytest.mark.parametrize("cfg", [
-    dict(N=200, B=6, G=16, F=24, K=3, E=2, nin=200, density=0.05),       # two edge features through the panel pipeline
+    dict(N=200, B=6, G=16, F=64, K=3, E=2, nin=200, density=0.05),       # two edge features through the panel pipeline
     dict(N=333, B=3, G=8, F=8, K=1, E=1, nin=333, density=0.03),         # K = 1: no hop at all
     dict(N=500, B=5, G=32, F=16, K=4, E=1, nin=123, density=0.02),       # Nin < N: zero padding + kept nodes
     dict(N=64, B=2, G=8, F=8, K=3, E=1, nin=64, density=0.0),            # empty GSO: y = h_0 x + b

@@ -16,11 +16,11 @@ def step():
     x.grad = None; layer.zero_grad()
     y = layer(x); y.backward(dy)
 for zz in (1, 0, 1, 0):
-    assert L.gf_tune(b"panel_zigzag", zz) == 0
+    assert L.gf_tune(b"panel_fuse_hops", zz) == 0
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(30): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
-    print(f"zigzag={zz}: {dt*1e3:.3f} ms/step", flush=True)
+    print(f"fuse_hops={zz}: {dt*1e3:.3f} ms/step", flush=True)
 PY
-cat $O/zigzag.log
+cat $O/zigzag.log; timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "lsigf or pipelines or graph_filter or selection or full_size" 2>&1 | tail -3
