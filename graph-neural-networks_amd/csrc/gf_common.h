@@ -68,16 +68,18 @@ struct gf_csr_dev {
     // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes.  Work unit = OCTET (8 consecutive rows = one 128-byte
     // line of a column panel); octets are sorted by their longest row and a slice = 8 octets = one wavefront (lane l handles
     // row pn_oct[8s + l/8] * 8 + l%8), so the rows a wave walks together have similar lengths and every octet still stores a
-    // full line.  Entries are an ELL block per slice: group-row j (steps 4j .. 4j+3) x 64 lanes, one 8-byte word of
-    // 4 x 16-bit columns and one 16-byte word of 4 fp32 values per lane; empty slots = {column N = the LDS zero slot, 0}.
+    // full line.  Entries are an ELL block per slice: group-row j (steps 4j .. 4j+3) x 64 lanes, one 16-byte word of
+    // 4 LDS byte offsets (column * 16: no unpacking in the kernel) and one 16-byte word of 4 fp32 values per lane; empty
+    // slots = {column N = the LDS zero slot, 0}; group-rows per slice are padded to an even count.
     //   address of (slice s, group-row j, lane l) = (pn_slice[s].x + j) * 64 + l      -- no per-lane bookkeeping at all.
     // pn_uniform: every stored value equals pn_uval (adjacency / lambda_max of an unweighted graph): the value stream is not read.
     int32_t pn_slices = 0;          // 0 = no panel image
     int2* pn_slice = nullptr;       // [pn_slices]  {group-row offset, group-rows = ceil(longest row / 4)}
     int32_t* pn_oct = nullptr;      // [pn_slices * (64 >> pn_ushift)]  unit handled by lanes (i << ushift) .. of the slice (-1 = none)
     int32_t pn_ushift = 3;          // log2(rows per unit): 3 = octets (full 128-byte lines), 2 = quads (64 bytes), 1 = pairs
-    uint2* pn_col4 = nullptr;       // [(group-rows + 2) * 64]
-    float4* pn_val4 = nullptr;      // [(group-rows + 2) * 64]
+    uint4* pn_col4 = nullptr;       // [(group-rows + 2) * 64]  value-free stream: LDS byte offsets (column * 16), no unpacking in the kernel
+    uint2* pn_col2 = nullptr;       // [(group-rows + 2) * 64]  weighted stream: 4 x 16-bit columns (the entry bytes bound that kernel)
+    float4* pn_val4 = nullptr;      // [(group-rows + 2) * 64]  weighted stream only
     int32_t pn_sentinel = 0;        // group-row index of two all-sentinel group-rows after the last real one
     double pn_fill = 1.0;           // real entries / ELL slots (diagnostic)
     int32_t pn_uniform = 0;

@@ -34,11 +34,14 @@ namespace {
 
 constexpr int kGC = 2;   // entry groups (of 4 neighbours) per lane gathered per round
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int UNIFORM> struct ColWord { typedef u32x2 type; };   // weighted stream: 4 x 16-bit columns
+template <> struct ColWord<1> { typedef u32x4 type; };            // value-free stream: 4 LDS byte offsets
 
 template <int UNIFORM>
 __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict__ slice, const int32_t* __restrict__ octs,
-                                                          const uint2* __restrict__ cols, const float4* __restrict__ vals,
+                                                          const void* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
                                                           int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug,
                                                           int stagger, int ush, int nHops, int64_t tapStride) {
@@ -50,7 +53,9 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     int p = blockIdx.x;
     if (p >= nPanels) return;  // whole workgroup
     f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
-    const u32x2* col4 = reinterpret_cast<const u32x2*>(cols) + lane;
+    typedef typename ColWord<UNIFORM>::type colw;
+    const colw* col4 = reinterpret_cast<const colw*>(cols) + lane;
+    const char* ldsb = reinterpret_cast<const char*>(panel);
     const f32x4* val4 = reinterpret_cast<const f32x4*>(vals) + lane;
 
     if (tid == 0) lds4[N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slot empty ELL slots gather from
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     }
 
     // request group-rows [g0, g0 + kGC) of an ELL block (g0 = absolute group-row index)
-    auto load_chunk = [&](u32x2 (&cc)[kGC], f32x4 (&vv)[kGC], int g0) {
+    auto load_chunk = [&](colw (&cc)[kGC], f32x4 (&vv)[kGC], int g0) {
 #pragma unroll
         for (int g = 0; g < kGC; ++g) {
             cc[g] = col4[(int64_t)(g0 + g) * 64];
@@ -105,28 +110,30 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
             }
             int j0 = 0;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            u32x2 cA[kGC], cB[kGC];
+            colw cA[kGC], cB[kGC];
             f32x4 vA[kGC], vB[kGC];
             load_chunk(cA, vA, si.y > 0 ? si.x : sentinel);
 
             // gathers + FMAs of the chunk held in (cc, vv) = group-rows [j0, j0 + kGC) of slice s, after requesting the
             // following chunk into (cn, vn).  Returns true when the wave has no slice left.
-            auto process = [&](u32x2 (&cc)[kGC], f32x4 (&vv)[kGC], u32x2 (&cn)[kGC], f32x4 (&vn)[kGC]) -> bool {
+            auto process = [&](colw (&cc)[kGC], f32x4 (&vv)[kGC], colw (&cn)[kGC], f32x4 (&vn)[kGC]) -> bool {
                 const bool same = (j0 + kGC) < si.y;  // wave-uniform: the next chunk belongs to the same slice
-                // next chunk: same slice, or the head of the next slice (the sentinel rows when it is empty / absent).
-                // A chunk may run one group-row past its slice's block: it then reads the following block's (or the
-                // sentinel's) first row, whose gathers the exhausted-row test below discards.
+                // next chunk: same slice (group-rows per slice are even: a chunk never straddles two blocks), or the head of
+                // the next slice (the sentinel rows when it is empty / absent)
                 const int gnext = same ? si.x + j0 + kGC : (sin.y > 0 ? sin.x : sentinel);
                 load_chunk(cn, vn, gnext);
 #pragma unroll
                 for (int g = 0; g < kGC; ++g) {
-                    const bool live = (j0 + g) < si.y;  // wave-uniform: group-row belongs to this slice
-                    const unsigned c01 = live ? cc[g].x : ((unsigned)N | ((unsigned)N << 16));
-                    const unsigned c23 = live ? cc[g].y : ((unsigned)N | ((unsigned)N << 16));
-                    const f32x4 x0 = lds4[c01 & 0xffffu];
-                    const f32x4 x1 = lds4[c01 >> 16];
-                    const f32x4 x2 = lds4[c23 & 0xffffu];
-                    const f32x4 x3 = lds4[c23 >> 16];
+                    unsigned o0, o1, o2, o3;  // LDS byte offsets of the 4 gathered rows
+                    if constexpr (UNIFORM) {
+                        o0 = cc[g].x, o1 = cc[g].y, o2 = cc[g].z, o3 = cc[g].w;
+                    } else {
+                        o0 = (cc[g].x & 0xffffu) << 4, o1 = (cc[g].x >> 16) << 4, o2 = (cc[g].y & 0xffffu) << 4, o3 = (cc[g].y >> 16) << 4;
+                    }
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(ldsb + o0);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(ldsb + o1);
+                    const f32x4 x2 = *reinterpret_cast<const f32x4*>(ldsb + o2);
+                    const f32x4 x3 = *reinterpret_cast<const f32x4*>(ldsb + o3);
                     if (UNIFORM) {
                         acc0 += x0;
                         acc1 += x1;
@@ -268,7 +275,7 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     const bool uniform = m.pn_uniform && g_tune.panel_uniform;
     auto kern = uniform ? spmm_panel_kernel<1> : spmm_panel_kernel<0>;
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_oct, m.pn_col4, m.pn_val4, m.pn_uval, Xin,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
                        Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;

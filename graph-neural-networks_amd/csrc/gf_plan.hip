@@ -213,14 +213,15 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     if (g_tune.panel_sort)
         std::stable_sort(oct.begin(), oct.begin() + noct, [&](int32_t x, int32_t y) { return omax[x] > omax[y]; });
     std::vector<int2> slice(ns);
-    std::vector<uint2> col4;   // ELL: [slice][group j][lane] -> 4 x 16-bit columns of steps 4j .. 4j+3
+    std::vector<uint4> col4;   // ELL: [slice][group j][lane] -> 4 LDS byte offsets (column * 16) of steps 4j .. 4j+3 (value-free stream)
+    std::vector<uint2> col2;   // the same as 4 x 16-bit columns (weighted stream: 8 + 16 bytes per group instead of 16 + 16)
     std::vector<float4> val4;
     const bool reorder = g_tune.panel_order != 0;
     double cycles = 0.0;
     int64_t steps = 0, slots = 0;
     std::vector<std::vector<int32_t>> rest(64);  // remaining entry indices (into a.col / a.val) per lane
     std::vector<int32_t> picks;                  // [step][lane] chosen entry (-1 = row exhausted)
-    const uint32_t nn = (uint32_t)n | ((uint32_t)n << 16);
+    const uint32_t nn = (uint32_t)n * 16u;
     for (int32_t sl = 0; sl < ns; ++sl) {
         int32_t w = 0;
         for (int l = 0; l < 64; ++l) {
@@ -232,7 +233,7 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
                 w = std::max<int32_t>(w, (int32_t)rest[l].size());
             }
         }
-        const int32_t gmax = (w + 3) / 4;
+        const int32_t gmax = (((w + 3) / 4) + 1) & ~1;             // even: the kernel walks group-rows two at a time
         slice[sl] = make_int2((int32_t)(col4.size() / 64), gmax);   // group-row offset (x 64 lanes), group-steps
         picks.assign((size_t)gmax * 4 * 64, -1);
         for (int32_t k = 0; k < w; ++k) {
@@ -283,14 +284,15 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
         // emit the slice's ELL block: gmax group-rows of 64 lanes; empty slots = {column N = the LDS zero slot, value 0}
         for (int32_t j = 0; j < gmax; ++j)
             for (int l = 0; l < 64; ++l) {
-                uint16_t c[4];
+                uint32_t c[4];
                 float v[4];
                 for (int i = 0; i < 4; ++i) {
                     const int32_t q = picks[(size_t)(4 * j + i) * 64 + l];
-                    c[i] = q >= 0 ? (uint16_t)a.col[q] : (uint16_t)n;
+                    c[i] = (uint32_t)(q >= 0 ? a.col[q] : n) * 16u;
                     v[i] = q >= 0 ? a.val[q] : 0.f;
                 }
-                col4.push_back(make_uint2((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)c[2] | ((uint32_t)c[3] << 16)));
+                col4.push_back(make_uint4(c[0], c[1], c[2], c[3]));
+                col2.push_back(make_uint2((c[0] >> 4) | ((c[1] >> 4) << 16), (c[2] >> 4) | ((c[3] >> 4) << 16)));
                 val4.push_back(make_float4(v[0], v[1], v[2], v[3]));
             }
         slots += (int64_t)gmax * 4 * 64;
@@ -307,13 +309,15 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     d.pn_fill = slots ? (double)a.col.size() / (double)slots : 1.0;
     d.pn_sentinel = (int32_t)(col4.size() / 64);   // two all-sentinel group-rows: what a wave without further work requests
     for (int i = 0; i < 128; ++i) {
-        col4.push_back(make_uint2(nn, nn));
+        col4.push_back(make_uint4(nn, nn, nn, nn));
+        col2.push_back(make_uint2((uint32_t)n | ((uint32_t)n << 16), (uint32_t)n | ((uint32_t)n << 16)));
         val4.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
     }
     int rc;
     if ((rc = upload(slice, &d.pn_slice, bytes))) return rc;
     if ((rc = upload(oct, &d.pn_oct, bytes))) return rc;
-    if ((rc = upload(col4, &d.pn_col4, bytes))) return rc;
+    if (d.pn_uniform && (rc = upload(col4, &d.pn_col4, bytes))) return rc;
+    if ((rc = upload(col2, &d.pn_col2, bytes))) return rc;   // kept for uniform plans too (knob panel_uniform = 0)
     if ((rc = upload(val4, &d.pn_val4, bytes))) return rc;
     d.pn_slices = ns;
     d.pn_ushift = ush;
@@ -331,6 +335,7 @@ void free_csr(gf_csr_dev& d) {
     if (d.pn_slice) (void)hipFree(d.pn_slice);
     if (d.pn_oct) (void)hipFree(d.pn_oct);
     if (d.pn_col4) (void)hipFree(d.pn_col4);
+    if (d.pn_col2) (void)hipFree(d.pn_col2);
     if (d.pn_val4) (void)hipFree(d.pn_val4);
     d = gf_csr_dev{};
 }

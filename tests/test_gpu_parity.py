@@ -629,7 +629,7 @@ def test_pipelines_agree_at_full_size(cfg2, pipeline_knob):
     dict(N=64, B=2, G=8, F=8, K=3, E=1, nin=64, density=0.0),            # empty GSO: y = h_0 x + b
     dict(N=5200, B=9, G=8, F=8, K=3, E=1, nin=5200, density=0.002),      # 1024-thread panel workgroups, ragged last slice
 ], ids=lambda c: "N%d_G%d_F%d_K%d_E%d_Nin%d" % (c["N"], c["G"], c["F"], c["K"], c["E"], c["nin"]))
-@pytest.mark.parametrize("pipe", [1, 2])
+@pytest.mark.parametrize("pipe", [1, 2, 3], ids=["node_major", "panels", "panels_fused_hops"])
 def test_lsigf_edge_cases_under_both_pipelines(cfg, pipe, pipeline_knob):
     N, B, G, F, K, E, nin = (cfg[k] for k in ("N", "B", "G", "F", "K", "E", "nin"))
     rng = np.random.RandomState(N + K)
@@ -637,9 +637,9 @@ def test_lsigf_edge_cases_under_both_pipelines(cfg, pipe, pipeline_knob):
     for e in range(E):
         A = sp.random(N, N, density=cfg["density"], format="csr", random_state=rng, data_rvs=rng.randn)
         mats.append(A * (0.5 / max(1.0, abs(A).sum(axis=1).max())) if A.nnz else A)
-    pipeline_knob(pipeline=pipe)
+    pipeline_knob(pipeline=min(pipe, 2), panel_fuse_hops=int(pipe == 3))
     gso = SparseGSO(mats)
-    assert _lib.lib().gf_lsigf_pipeline(gso.plans(DEV), E, G, F) == pipe
+    assert _lib.lib().gf_lsigf_pipeline(gso.plans(DEV), E, G, F) == min(pipe, 2)
     h = (rng.uniform(-1, 1, (F, E, K, G)) / np.sqrt(G * K)).astype(np.float32)
     x = rng.randn(B, G, nin).astype(np.float32)
     b = rng.uniform(-1, 1, (F, 1)).astype(np.float32)

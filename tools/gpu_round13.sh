@@ -14,11 +14,14 @@ gso = SparseGSO([graphgen.sbm(N, seed=0)]); plans = gso.plans(dev)
 P = B * W // 4
 X = torch.randn(P, N, 4, device=dev); Y = torch.empty_like(X)
 ms = ctypes.c_float()
-for pf in (1, 0):
-  for stag in (0, 1):
+for rep in range(3):
     for uni in (1, 0):
-        tune(panel_debug=0, panel_uniform=uni, spmm_store=0, panel_stagger=stag, panel_prefetch=pf)
+        tune(panel_debug=0, panel_uniform=uni, spmm_store=0, panel_stagger=1)
         _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X.data_ptr(), Y.data_ptr(), P, 20, torch.cuda.current_stream().cuda_stream, ctypes.byref(ms)))
-        print(f"{ms.value*1e3:8.1f} us  prefetch={pf} stagger={stag} uniform={uni}", flush=True)
+        print(f"{ms.value*1e3:8.1f} us  uniform={uni}", flush=True)
+for dbg in (1, 2):
+    tune(panel_debug=dbg, panel_uniform=1)
+    _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X.data_ptr(), Y.data_ptr(), P, 20, torch.cuda.current_stream().cuda_stream, ctypes.byref(ms)))
+    print(f"{ms.value*1e3:8.1f} us  uniform=1 debug={dbg} (1 = load only, 2 = compute only)", flush=True)
 PY
-cat $O/phase.log
+cat $O/phase.log; timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k 'panel or pipelines or edge_cases' 2>&1 | tail -3
