@@ -113,6 +113,7 @@ struct gf_tuning {
     int spmm_load = 0;          // gather loads: 0 = plain, 1 = non-temporal
     int spmm_store = 2;         // output rows: 0 = plain stores, 1 = write-through (sc1), 2 = non-temporal
     int contract_generic = 0;   // 1 = force the generic contraction kernel
+    int gradw_lds = 1;          // panel tap gradients: 1 = operands transposed through LDS (coalesced loads), 0 = direct strided loads
     int pipeline = 0;           // 0 = auto, 1 = node-major (gather through L2), 2 = column panels through LDS (needs N <= 10239, G%8 == F%8 == 0)
     int panel_uniform = 1;      // 1 = use the value-free stream when the plan detected uniform values
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)

@@ -249,10 +249,117 @@ __global__ __launch_bounds__(kThreads) void grad_taps_panel_kernel(const float* 
     }
 }
 
+// ---- stage 1, column panels, operands transposed through LDS.  In panel layout a node's 4 consecutive columns are 16 contiguous
+// bytes, but the MFMA wants lane = column: the direct kernel above therefore issues, per 8-row round and tile, four 4-byte
+// loads that each touch 8 x 32-byte segments (TCP-bound: 0.53 ms at config 2 against 0.19 ms of MFMA time).  Here a wave
+// loads a tile of 8 nodes x 8 panels with ONE coalesced 16-byte load per lane (128 contiguous bytes per panel), writes it to
+// a wave-private LDS tile [panel][node][4] with the panel stride padded to 36 dwords, and reads the operand of step s as
+// LDS[q*36 + (2s+half)*4 + g%4] -- bank (4q + g%4 + const) % 32: conflict-free.  The next round's global loads are in
+// flight during the 4 x CTP MFMAs of the current one.  Same strips, accumulators and partial layout as above.
+constexpr int kTileDw = 8 * 36;  // dwords per staged tile
+
+template <int CTP>
+__global__ __launch_bounds__(kThreads) void grad_taps_panel_lds_kernel(const float* __restrict__ Zp, const float* __restrict__ P0p,
+                                                                       float* __restrict__ partial, float* __restrict__ partial_b,
+                                                                       int R, int N, int B, int G, int F, int numGI, int numCT,
+                                                                       int numFT, int passes, int rowsPerWave) {
+    __shared__ __attribute__((aligned(16))) float s_tiles[kWaves][(CTP + 1) * kTileDw];
+    const int pass = blockIdx.y;
+    const int ft = pass % numFT, cpass = pass / numFT;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wg = blockIdx.x * kWaves + wave;
+    const int r_begin = wg * rowsPerWave;  // R < 2^31 (checked by the launcher)
+    const int r_end = min(R, r_begin + rowsPerWave);
+    const int QG = G / 4, QF = F / 4;
+    const int64_t N4 = (int64_t)N * 4;
+    float* tiles = s_tiles[wave];
+
+    // load role: lane = (panel q of the tile, node j of the round)
+    const int lq = lane >> 3, lj = lane & 7;
+    const float* lbase[CTP + 1];  // tile j < CTP: Z tap/column tile; tile CTP: the P0 tile
+    bool lvalid[CTP + 1];
+    int lQ[CTP + 1];              // panels per batch entry of that operand
+#pragma unroll
+    for (int j = 0; j < CTP; ++j) {
+        const int ct = cpass * CTP + j;
+        const int t = ct / numGI, gi = ct - t * numGI;
+        const int q = gi * 8 + lq;
+        lvalid[j] = (ct < numCT) && (q < QG);
+        lbase[j] = Zp + (lvalid[j] ? ((int64_t)t * B * QG + q) * N4 : 0);
+        lQ[j] = QG;
+    }
+    {
+        const int q = ft * 8 + lq;
+        lvalid[CTP] = q < QF;
+        lbase[CTP] = P0p + (lvalid[CTP] ? (int64_t)q * N4 : 0);
+        lQ[CTP] = QF;
+    }
+    // MFMA role: lane = column (g for A tiles, f for the B tile), half = node parity
+    const int rd = (l31 >> 2) * 36 + (l31 & 3) + half * 4;  // + 8*s per step
+
+    f32x16 acc[CTP];
+#pragma unroll
+    for (int j = 0; j < CTP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum = 0.f;
+
+    float4 cur[CTP + 1], nxt[CTP + 1];
+    auto issue = [&](int r0, float4 (&dst)[CTP + 1]) {
+        const int r = r0 + lj;
+        const bool rv = r < r_end;
+        const int b = rv ? r / N : 0;
+        const int n = rv ? r - b * N : 0;
+#pragma unroll
+        for (int j = 0; j <= CTP; ++j)
+            dst[j] = (rv && lvalid[j]) ? *reinterpret_cast<const float4*>(lbase[j] + (int64_t)b * lQ[j] * N4 + (int64_t)n * 4)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    issue(r_begin, cur);
+    for (int r0 = r_begin; r0 < r_begin + rowsPerWave; r0 += 8) {
+#pragma unroll
+        for (int j = 0; j <= CTP; ++j) *reinterpret_cast<float4*>(tiles + j * kTileDw + lq * 36 + lj * 4) = cur[j];
+        if (r0 + 8 < r_begin + rowsPerWave) issue(r0 + 8, nxt);  // in flight during this round's MFMAs
+        float p[4], a[4][CTP];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            p[s] = tiles[CTP * kTileDw + rd + 8 * s];
+#pragma unroll
+            for (int j = 0; j < CTP; ++j) a[s][j] = tiles[j * kTileDw + rd + 8 * s];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bsum += p[s];
+#pragma unroll
+            for (int j = 0; j < CTP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][j], p[s], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j <= CTP; ++j) cur[j] = nxt[j];
+    }
+
+    float* pt = partial + ((int64_t)wg * passes + pass) * CTP * 1024;
+#pragma unroll
+    for (int j = 0; j < CTP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            pt[j * 1024 + i * 32 + l31] = acc[j][r];
+        }
+    if (cpass == 0) {
+        const float other = __shfl_xor(bsum, 32, 64);
+        if (half == 0) partial_b[((int64_t)wg * numFT + ft) * 32 + l31] = bsum + other;
+    }
+}
+
 template <int CTP>
 void launch_stage1_panel(const Geo& g, const float* Zp, const float* P0p, float* ws, int N, int B, int G, int F, hipStream_t st) {
-    hipLaunchKernelGGL((grad_taps_panel_kernel<CTP>), dim3(g.strips, g.passes), dim3(kThreads), 0, st, Zp, P0p, ws,
-                       ws + g.off_partial_b, (int)g.R, N, B, G, F, g.numGI, g.numCT, g.numFT, g.passes, g.rowsPerWave);
+    if (g_tune.gradw_lds)
+        hipLaunchKernelGGL((grad_taps_panel_lds_kernel<CTP>), dim3(g.strips, g.passes), dim3(kThreads), 0, st, Zp, P0p, ws,
+                           ws + g.off_partial_b, (int)g.R, N, B, G, F, g.numGI, g.numCT, g.numFT, g.passes, g.rowsPerWave);
+    else
+        hipLaunchKernelGGL((grad_taps_panel_kernel<CTP>), dim3(g.strips, g.passes), dim3(kThreads), 0, st, Zp, P0p, ws,
+                           ws + g.off_partial_b, (int)g.R, N, B, G, F, g.numGI, g.numCT, g.numFT, g.passes, g.rowsPerWave);
 }
 
 int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, int E, int K, hipStream_t st) {

@@ -37,6 +37,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_ucap")) g_tune.spmm_ucap = value;
     else if (!strcmp(key, "contract_generic")) g_tune.contract_generic = value;
     else if (!strcmp(key, "pipeline")) g_tune.pipeline = value;
+    else if (!strcmp(key, "gradw_lds")) g_tune.gradw_lds = value;
     else if (!strcmp(key, "panel_uniform")) g_tune.panel_uniform = value;
     else if (!strcmp(key, "panel_order")) g_tune.panel_order = value;
     else if (!strcmp(key, "panel_sort")) g_tune.panel_sort = value;

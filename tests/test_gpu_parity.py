@@ -568,16 +568,21 @@ def test_contract_and_grad_taps_panel_against_einsum(shape, transpose):
     dh = torch.full((F, E, K, G), float("nan"), device=DEV)
     db = torch.full((F,), float("nan"), device=DEV)
     dYt = cu(to_panels(dY, N))
-    _lib.check(L.gf_grad_taps_panel(Zt.data_ptr(), dYt.data_ptr(), dh.data_ptr(), db.data_ptr(),
-                                    ws.data_ptr(), nb, B, N, G, F, E, K, stream()))
     full = np.einsum("tbgn,bfn->tfg", Zn.astype(np.float64), dY.astype(np.float64))
     want_dh = np.zeros((F, E, K, G))
     for e in range(E):
         want_dh[:, e, 0] = full[0]
         for k in range(1, K):
             want_dh[:, e, k] = full[1 + e * (K - 1) + (k - 1)]
-    assert relerr(dh.cpu().numpy(), want_dh) < 5e-6
-    assert relerr(db.cpu().numpy(), dY.astype(np.float64).sum(axis=(0, 2))) < 5e-6
+    for lds in (1, 0):                                                    # operands transposed through LDS / direct strided loads
+        tune(gradw_lds=lds)
+        dh.fill_(float("nan"))
+        db.fill_(float("nan"))
+        _lib.check(L.gf_grad_taps_panel(Zt.data_ptr(), dYt.data_ptr(), dh.data_ptr(), db.data_ptr(),
+                                        ws.data_ptr(), nb, B, N, G, F, E, K, stream()))
+        assert relerr(dh.cpu().numpy(), want_dh) < 5e-6, lds
+        assert relerr(db.cpu().numpy(), dY.astype(np.float64).sum(axis=(0, 2))) < 5e-6, lds
+    tune(gradw_lds=1)
 
 
 @pytest.mark.parametrize("pipe", [1, 2])
