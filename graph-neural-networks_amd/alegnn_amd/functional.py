@@ -29,7 +29,7 @@ def _require_f32_cuda(name, t):
 
 class _LSIGFFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h, bias, gso: SparseGSO):
+    def forward(ctx, x, h, bias, gso: SparseGSO, relu=False):
         L = _lib.lib()
         B, G, Nin = x.shape
         F_, E, K, G2 = h.shape
@@ -43,19 +43,21 @@ class _LSIGFFunction(torch.autograd.Function):
             Z = torch.empty((T, B, N, G), dtype=torch.float32, device=x.device)
             y = torch.empty((B, F_, Nin), dtype=torch.float32, device=x.device)
             stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(L.gf_lsigf_forward(plans, E, x.data_ptr(), h.data_ptr(), _ptr(bias_c), Z.data_ptr(), y.data_ptr(),
-                                          B, G, F_, K, Nin, stream), "gf_lsigf_forward")
+            fwd = L.gf_lsigf_forward_relu if relu else L.gf_lsigf_forward
+            _lib.check(fwd(plans, E, x.data_ptr(), h.data_ptr(), _ptr(bias_c), Z.data_ptr(), y.data_ptr(),
+                           B, G, F_, K, Nin, stream), "gf_lsigf_forward")
         ctx.gso = gso
         ctx.dims = (B, G, F_, E, K, Nin, N, T)
         ctx.has_bias = bias is not None
         need_taps = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])  # dh / db read Z
-        ctx.save_for_backward(h, Z if need_taps else None)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(h, Z if need_taps else None, y if relu else None)   # the ReLU mask is (y > 0)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        h, Z = ctx.saved_tensors
+        h, Z, y_act = ctx.saved_tensors
         B, G, F_, E, K, Nin, N, T = ctx.dims
         need_dx, need_dh, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dy = dy.contiguous()
@@ -72,12 +74,17 @@ class _LSIGFFunction(torch.autograd.Function):
                 ws_bytes = L.gf_grad_taps_workspace_bytes(B, N, G, F_, E, K)
                 ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(L.gf_lsigf_backward(plans, E, dy.data_ptr(), _ptr(Z), h.data_ptr(), P.data_ptr(), _ptr(dx), _ptr(dh),
-                                           _ptr(db), _ptr(ws), ws_bytes, B, G, F_, K, Nin, stream), "gf_lsigf_backward")
-        return dx, dh, db, None
+            if ctx.relu:
+                _lib.check(L.gf_lsigf_backward_relu(plans, E, dy.data_ptr(), y_act.data_ptr(), _ptr(Z), h.data_ptr(), P.data_ptr(),
+                                                    _ptr(dx), _ptr(dh), _ptr(db), _ptr(ws), ws_bytes, B, G, F_, K, Nin, stream),
+                           "gf_lsigf_backward_relu")
+            else:
+                _lib.check(L.gf_lsigf_backward(plans, E, dy.data_ptr(), _ptr(Z), h.data_ptr(), P.data_ptr(), _ptr(dx), _ptr(dh),
+                                               _ptr(db), _ptr(ws), ws_bytes, B, G, F_, K, Nin, stream), "gf_lsigf_backward")
+        return dx, dh, db, None, None
 
 
-def LSIGF(h, S, x, b=None):
+def LSIGF(h, S, x, b=None, activation=None):
     """Linear shift-invariant graph filter, reference signature and semantics (graphML.py:83-176):
 
         y[b,f,n] = sum_{e,k,g} h[f,e,k,g] * (x_g S_e^k)[b,n] + b[f]
@@ -85,6 +92,8 @@ def LSIGF(h, S, x, b=None):
     ``S`` may be the reference's dense ``[E,N,N]`` tensor or anything ``SparseGSO.from_any`` accepts.
     ``x`` may have fewer nodes than S (Nin < N): it is zero-padded and the output keeps the first Nin nodes,
     which is what GraphFilter.forward does around its LSIGF call (graphML.py:2131-2143).
+    ``activation='relu'`` (superset) fuses the ReLU that follows the filter in SelectionGNN (architectures.py:286-289) into the
+    contraction's epilogue and its mask into the backward pass; it needs the per-feature bias form ``b [F,1]`` (or None).
     """
     gso = SparseGSO.from_any(S)
     assert h.dim() == 4 and x.dim() == 3
@@ -103,7 +112,11 @@ def LSIGF(h, S, x, b=None):
             fused_bias = b
         else:                                          # per-node bias [F,N] (graphML.py:110-112): broadcast add, plumbing
             late_bias = b
-    y = _LSIGFFunction.apply(x, h, fused_bias, gso)
+    assert activation in (None, "relu")
+    relu = activation == "relu"
+    if relu and late_bias is not None:                         # the activation must see the bias: apply both outside
+        return torch.relu(_LSIGFFunction.apply(x, h, None, gso, False) + late_bias[:, : x.shape[2]])
+    y = _LSIGFFunction.apply(x, h, fused_bias, gso, relu)
     if late_bias is not None:
         y = y + late_bias[:, : y.shape[2]]
     return y
@@ -178,3 +191,41 @@ def EVGF_edges(pattern: EdgePattern, wdiag, wedge, x, b=None):
         _require_f32_cuda("b", b)
         assert b.dim() == 2 and b.shape[0] == F_ and b.shape[1] == 1
     return _EVGFFunction.apply(x, wdiag, wedge, b, pattern)
+
+
+class _MaxPoolLocalFunction(torch.autograd.Function):
+    """MaxPoolLocal forward / backward through gf_maxpool_forward / gf_maxpool_backward (include/gfhip.h)."""
+
+    @staticmethod
+    def forward(ctx, x, nbh, rev_ptr, rev_i, rev_p):
+        L = _lib.lib()
+        B, F_, Nin = x.shape
+        Nout, M = nbh.shape
+        x = x.contiguous()
+        with torch.cuda.device(x.device):
+            v = torch.empty((B, F_, Nout), dtype=torch.float32, device=x.device)
+            arg = torch.empty((B, F_, Nout), dtype=torch.int32, device=x.device)
+            _lib.check(L.gf_maxpool_forward(x.data_ptr(), nbh.data_ptr(), v.data_ptr(), arg.data_ptr(), B, F_, Nin, Nout, M,
+                                            torch.cuda.current_stream().cuda_stream), "gf_maxpool_forward")
+        ctx.save_for_backward(arg, rev_ptr, rev_i, rev_p)
+        ctx.dims = (B, F_, Nin, Nout)
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        L = _lib.lib()
+        arg, rev_ptr, rev_i, rev_p = ctx.saved_tensors
+        B, F_, Nin, Nout = ctx.dims
+        dv = dv.contiguous()
+        with torch.cuda.device(dv.device):
+            dx = torch.empty((B, F_, Nin), dtype=torch.float32, device=dv.device)
+            _lib.check(L.gf_maxpool_backward(dv.data_ptr(), arg.data_ptr(), rev_ptr.data_ptr(), rev_i.data_ptr(), rev_p.data_ptr(),
+                                             dx.data_ptr(), B, F_, Nin, Nout, torch.cuda.current_stream().cuda_stream),
+                       "gf_maxpool_backward")
+        return dx, None, None, None, None
+
+
+def max_pool_local(x, nbh, rev_ptr, rev_i, rev_p):
+    """v[b,f,i] = max_{j in nbh[i]} x[b,f,j] (reference MaxPoolLocal.forward, graphML.py:1996-2021) on the HIP path."""
+    _require_f32_cuda("x", x)
+    return _MaxPoolLocalFunction.apply(x, nbh, rev_ptr, rev_i, rev_p)

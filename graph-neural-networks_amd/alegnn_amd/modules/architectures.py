@@ -65,7 +65,11 @@ class SelectionGNN(nn.Module):
         for l in range(self.L):
             gfl.append(gml.GraphFilter(self.F[l], self.F[l + 1], self.K[l], self.E, self.bias))   # :277-278
             gfl[3 * l].addGSO(self._gso)
-            gfl.append(self.sigma())                                                              # :287
+            if self.sigma is nn.ReLU:              # sigma = ReLU runs in the filter's epilogue / backward mask
+                gfl[3 * l].fused_activation = "relu"
+                gfl.append(gml.FusedReLU())
+            else:
+                gfl.append(self.sigma())                                                          # :287
             gfl.append(self.rho(self.N[l], self.N[l + 1], self.alpha[l]))                        # :292
             gfl[3 * l + 2].addGSO(self._gso)
         self.GFL = nn.Sequential(*gfl)

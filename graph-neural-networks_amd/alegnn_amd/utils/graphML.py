@@ -18,11 +18,16 @@ import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
-from ..functional import EVGF_edges, LSIGF
+from ..functional import EVGF_edges, LSIGF, max_pool_local
 from ..gso import EdgePattern, SparseGSO
 from . import graphTools
 
-__all__ = ["LSIGF", "GraphFilter", "EdgeVariantGF", "NoPool", "MaxPoolLocal"]
+__all__ = ["LSIGF", "GraphFilter", "EdgeVariantGF", "NoPool", "MaxPoolLocal", "FusedReLU"]
+
+
+class FusedReLU(nn.Identity):
+    """Placeholder that keeps SelectionGNN's ``GFL`` layout [GraphFilter, sigma, rho] (and therefore the state_dict keys
+    ``GFL.3.weight`` ...) when sigma = ReLU has been fused into the preceding GraphFilter's epilogue."""
 
 
 class GraphFilter(nn.Module):
@@ -40,6 +45,7 @@ class GraphFilter(nn.Module):
         self.E = E
         self.S = None                      # no GSO assigned yet (graphML.py:2099)
         self._gso = None
+        self.fused_activation = None       # 'relu': y = max(0, filter(x) + b) in one pass (set by SelectionGNN)
         self.weight = nn.parameter.Parameter(torch.Tensor(F, E, K, G))
         if bias:
             self.bias = nn.parameter.Parameter(torch.Tensor(F, 1))
@@ -68,7 +74,7 @@ class GraphFilter(nn.Module):
         # the output keeps numberNodesIn nodes, :2142-2143 -- both happen inside the HIP path, no copies here)
         assert self._gso is not None, "GraphFilter.forward called before addGSO"
         assert x.dim() == 3 and x.shape[2] <= self.N
-        return LSIGF(self.weight, self._gso, x, self.bias)
+        return LSIGF(self.weight, self._gso, x, self.bias, activation=self.fused_activation)
 
     def extra_repr(self):
         reprString = "in_features=%d, out_features=%d, " % (self.G, self.F) + "filter_taps=%d, " % (self.K) + \
@@ -224,7 +230,8 @@ class MaxPoolLocal(nn.Module):
         self.nInputNodes = nInputNodes
         self.nOutputNodes = nOutputNodes
         self.nHops = nHops
-        self.register_buffer("neighborhood", None, persistent=False)
+        for name in ("neighborhood", "_rev_ptr", "_rev_i", "_rev_p"):
+            self.register_buffer(name, None, persistent=False)
 
     def addGSO(self, S):
         assert len(S.shape) == 3                                 # graphML.py:1942
@@ -238,18 +245,33 @@ class MaxPoolLocal(nn.Module):
         else:
             pattern_src = S
         nbh = graphTools.computeNeighborhood(pattern_src, self.nHops, self.nOutputNodes, self.nInputNodes, 'matrix')
-        nbh = torch.as_tensor(nbh, dtype=torch.int64)
+        nbh = np.ascontiguousarray(nbh, dtype=np.int32)
         assert nbh.shape[0] == self.nOutputNodes                 # graphML.py:1962-1963
         assert int(nbh.max()) <= self.nInputNodes
         self.maxNeighborhoodSize = nbh.shape[1]
-        self.neighborhood = nbh.to(device) if device is not None else nbh
+        # reverse lists for the backward gather: input node j -> (output node i, FIRST position of j in nbh[i])
+        rows, pos, cols = [], [], []
+        for i in range(nbh.shape[0]):
+            seen = set()
+            for p_, j in enumerate(nbh[i]):
+                if j not in seen:
+                    seen.add(int(j))
+                    cols.append(int(j)); rows.append(i); pos.append(p_)
+        order = np.lexsort((np.asarray(rows), np.asarray(cols)))          # by input node, then ascending output node
+        cols_s = np.asarray(cols, dtype=np.int64)[order]
+        rev_ptr = np.zeros(self.nInputNodes + 1, dtype=np.int32)
+        np.add.at(rev_ptr, cols_s + 1, 1)
+        rev_ptr = np.cumsum(rev_ptr).astype(np.int32)
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32))
+        bufs = dict(neighborhood=t(nbh), _rev_ptr=t(rev_ptr), _rev_i=t(np.asarray(rows)[order]), _rev_p=t(np.asarray(pos)[order]))
+        for k, v in bufs.items():
+            setattr(self, k, v.to(device) if device is not None else v)
 
     def forward(self, x):
         assert x.shape[2] == self.nInputNodes                    # graphML.py:1972-1976
         assert x.shape[2] >= self.nOutputNodes
-        xn = x[:, :, self.neighborhood]                          # B x F x nOutputNodes x maxNeighborhoodSize
-        v, _ = torch.max(xn, dim=3)
-        return v
+        # one pass over x on the HIP path (the reference repeats x maxNeighborhood times, gathers and reduces: :2003-2018)
+        return max_pool_local(x, self.neighborhood, self._rev_ptr, self._rev_i, self._rev_p)
 
     def extra_repr(self):
         reprString = "in_dim=%d, out_dim=%d, number_hops = %d, " % (self.nInputNodes, self.nOutputNodes, self.nHops)

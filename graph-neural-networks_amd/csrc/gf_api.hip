@@ -55,8 +55,8 @@ extern "C" int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t
     return pick_pipeline(plans, E, G, F);
 }
 
-extern "C" int gf_lsigf_forward(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias,
-                                float* Z, float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
+static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z,
+                              float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream, int relu) {
     GF_REQUIRE_ARG(plans && x && h && Z && y, "gf_lsigf_forward: NULL argument");
     GF_REQUIRE_SHAPE(E > 0 && B > 0 && G > 0 && F > 0 && K > 0 && Nin > 0, "gf_lsigf_forward: bad shape E=%d B=%d G=%d F=%d K=%d Nin=%d",
                      E, B, G, F, K, Nin);
@@ -70,22 +70,22 @@ extern "C" int gf_lsigf_forward(const gf_plan* const* plans, int32_t E, const fl
     const int pipe = pick_pipeline(plans, E, G, F);
     if (pipe < 0) return pipe;
     if (pipe == 2) {
-        int rc = gf_pack_panels_launch(x, Z, B, G, Nin, N, gf_stream(stream));
+        int rc = gf_pack_panels_launch(x, Z, B, G, Nin, N, gf_stream(stream), nullptr);
         if (rc != GF_OK) return rc;
         rc = khop_panel(plans, E, GF_OP_FWD, Z, B, G, K, gf_stream(stream));
         if (rc != GF_OK) return rc;
-        return gf_contract_panel_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank=*/0, gf_stream(stream));
+        return gf_contract_panel_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream));
     }
     int rc = gf_layout_bgn_to_bng(x, Z, B, G, Nin, N, stream);
     if (rc != GF_OK) return rc;
     rc = gf_khop(plans, E, GF_OP_FWD, Z, B, G, K, stream);
     if (rc != GF_OK) return rc;
-    return gf_contract_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank=*/0, gf_stream(stream));
+    return gf_contract_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream));
 }
 
-extern "C" int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const float* dy, const float* Z, const float* h,
-                                 float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
-                                 int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
+static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const float* dy, const float* Z, const float* h, float* P,
+                               float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes, int32_t B, int32_t G,
+                               int32_t F, int32_t K, int32_t Nin, void* stream, const float* y_relu) {
     GF_REQUIRE_ARG(plans && dy && h && P, "gf_lsigf_backward: NULL argument");
     GF_REQUIRE_SHAPE(E > 0 && B > 0 && G > 0 && F > 0 && K > 0 && Nin > 0, "gf_lsigf_backward: bad shape E=%d B=%d G=%d F=%d K=%d Nin=%d",
                      E, B, G, F, K, Nin);
@@ -99,7 +99,7 @@ extern "C" int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const f
     const int pipe = pick_pipeline(plans, E, G, F);
     if (pipe < 0) return pipe;
     if (pipe == 2) {
-        int rc = gf_pack_panels_launch(dy, P, B, F, Nin, N, gf_stream(stream));  // P[0] = dy as panels, rows >= Nin zero
+        int rc = gf_pack_panels_launch(dy, P, B, F, Nin, N, gf_stream(stream), y_relu);  // P[0] = dy (masked by y > 0) as panels, rows >= Nin zero
         if (rc != GF_OK) return rc;
         if (dh || dbias) {
             GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
@@ -113,7 +113,8 @@ extern "C" int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const f
         }
         return rc;
     }
-    int rc = gf_layout_bgn_to_bng(dy, P, B, F, Nin, N, stream);  // P[0] = dy, node-major, rows >= Nin zero
+    int rc = y_relu ? gf_layout_masked_launch(dy, y_relu, P, B, F, Nin, N, gf_stream(stream))
+                    : gf_layout_bgn_to_bng(dy, P, B, F, Nin, N, stream);  // P[0] = dy, node-major, rows >= Nin zero
     if (rc != GF_OK) return rc;
     if (dh || dbias) {
         GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
@@ -126,4 +127,30 @@ extern "C" int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const f
         rc = gf_contract_launch(P, h, nullptr, dx, B, N, Nin, G, F, E, K, /*transpose_bank=*/1, gf_stream(stream));
     }
     return rc;
+}
+
+extern "C" int gf_lsigf_forward(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias,
+                                float* Z, float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
+    return lsigf_forward_impl(plans, E, x, h, bias, Z, y, B, G, F, K, Nin, stream, 0);
+}
+
+extern "C" int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const float* dy, const float* Z, const float* h,
+                                 float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
+                                 int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
+    return lsigf_backward_impl(plans, E, dy, Z, h, P, dx, dh, dbias, workspace, workspace_bytes, B, G, F, K, Nin, stream, nullptr);
+}
+
+// The filter followed by the nonlinearity of SelectionGNN's layers (architectures.py:286-289: GFL = [GraphFilter, sigma, rho]),
+// for sigma = ReLU: y = max(0, LSIGF(...)) in the contraction's epilogue, and in backward the mask (y > 0) applied while dy is
+// brought into the internal layout -- torch's separate relu / threshold_backward passes (5 signal passes) disappear.
+extern "C" int gf_lsigf_forward_relu(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias,
+                                     float* Z, float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
+    return lsigf_forward_impl(plans, E, x, h, bias, Z, y, B, G, F, K, Nin, stream, 1);
+}
+
+extern "C" int gf_lsigf_backward_relu(const gf_plan* const* plans, int32_t E, const float* dy, const float* y, const float* Z,
+                                      const float* h, float* P, float* dx, float* dh, float* dbias, void* workspace,
+                                      size_t workspace_bytes, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
+    GF_REQUIRE_ARG(y != nullptr, "gf_lsigf_backward_relu: y (the saved forward output) is NULL");
+    return lsigf_backward_impl(plans, E, dy, Z, h, P, dx, dh, dbias, workspace, workspace_bytes, B, G, F, K, Nin, stream, y);
 }

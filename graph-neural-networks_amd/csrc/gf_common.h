@@ -130,7 +130,8 @@ int gf_contract_launch(const float* Z, const float* h, const float* bias, float*
                        int F, int E, int K, int transpose_bank, hipStream_t st);
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)
 bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F);
-int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st);
+int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st, const float* mask);
+int gf_layout_masked_launch(const float* dy, const float* y, float* X, int B, int G, int Nin, int N, hipStream_t st);
 int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st, int nHops,
                          int64_t tapStride);
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,

@@ -32,6 +32,8 @@ constexpr int kWaves = kThreads / 64;
 struct BankView {  // how to read Hm[c = t*Cin + ci][o] out of h[F,E,K,G]
     const float* h;
     int E, K, G, F, mode;  // mode 0: (ci, o) = (g, f);  mode 1: (ci, o) = (f, g)
+    int relu;              // 1: the epilogue applies max(0, .) (the sigma that follows the filter in SelectionGNN, architectures.py:289)
+    __device__ __forceinline__ float act(float v) const { return (relu && v <= 0.f) ? 0.f : v; }  // NaN stays NaN, like torch.relu
     __device__ __forceinline__ float at(int t, int ci, int o) const {
         const int f = mode ? ci : o, g = mode ? o : ci;
         if (t == 0) {
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void contract_mfma_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (o < Cout) ob[(int64_t)o * Nout] = acc[nt][r];
+                    if (o < Cout) ob[(int64_t)o * Nout] = bank.act(acc[nt][r]);
                 }
         }
     }
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void contract_generic_kernel(const float*
         float acc = bias ? bias[o] : 0.f;
         for (int t = 0; t < T; ++t)
             for (int ci = 0; ci < Cin; ++ci) acc = fmaf(zr[t * tapStride + ci], bank.at(t, ci, o), acc);
-        out[idx] = acc;
+        out[idx] = bank.act(acc);
     }
 }
 
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void contract_panel_kernel(const float* _
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (o < Cout) ob[(int64_t)o * Nout] = acc[nt][r];
+                    if (o < Cout) ob[(int64_t)o * Nout] = bank.act(acc[nt][r]);
                 }
         }
     }
@@ -295,8 +297,8 @@ int dispatch_cin_panel(int cin8, const float* Zp, const BankView& bank, const fl
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G, int F,
                              int E, int K, int transpose_bank, hipStream_t st) {
     const int T = gf_num_taps(E, K);
-    const int Cin = transpose_bank ? F : G, Cout = transpose_bank ? G : F;
-    BankView bank{h, E, K, G, F, transpose_bank ? 1 : 0};
+    const int Cin = (transpose_bank & 1) ? F : G, Cout = (transpose_bank & 1) ? G : F;
+    BankView bank{h, E, K, G, F, (transpose_bank & 1) ? 1 : 0, (transpose_bank >> 1) & 1};  // bit 0: transposed bank, bit 1: ReLU epilogue
     const int cin8 = Cin / 8;
     const bool cin_ok = (Cin % 8 == 0) && (cin8 == 1 || cin8 == 2 || cin8 == 4 || cin8 == 8 || cin8 == 16);
     const int nt = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4);
@@ -315,6 +317,7 @@ extern "C" int gf_contract_panel(const float* Zp, const float* h, const float* b
     GF_REQUIRE_ARG(Zp && h && out, "gf_contract_panel: NULL tensor");
     GF_REQUIRE_SHAPE(B > 0 && N > 0 && Nout > 0 && Nout <= N && G > 0 && F > 0 && E > 0 && K > 0,
                      "gf_contract_panel: bad shape B=%d N=%d Nout=%d G=%d F=%d E=%d K=%d", B, N, Nout, G, F, E, K);
+    GF_REQUIRE_ARG(transpose_bank == 0 || transpose_bank == 1, "gf_contract_panel: transpose_bank = %d", transpose_bank);
     GF_REQUIRE_ARG(!(transpose_bank && bias), "gf_contract_panel: bias is only defined for the forward bank");
     return gf_contract_panel_launch(Zp, h, bias, out, B, N, Nout, G, F, E, K, transpose_bank, gf_stream(stream));
 }
@@ -326,8 +329,8 @@ int unused_anchor_() { return 0; }
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G, int F,
                        int E, int K, int transpose_bank, hipStream_t st) {
     const int T = gf_num_taps(E, K);
-    const int Cin = transpose_bank ? F : G, Cout = transpose_bank ? G : F;
-    BankView bank{h, E, K, G, F, transpose_bank ? 1 : 0};
+    const int Cin = (transpose_bank & 1) ? F : G, Cout = (transpose_bank & 1) ? G : F;
+    BankView bank{h, E, K, G, F, (transpose_bank & 1) ? 1 : 0, (transpose_bank >> 1) & 1};  // bit 0: transposed bank, bit 1: ReLU epilogue
     static const int env_generic = getenv("GFHIP_CONTRACT_GENERIC") ? atoi(getenv("GFHIP_CONTRACT_GENERIC")) : 0;
 
     const int cin8 = Cin / 8;
@@ -354,6 +357,7 @@ extern "C" int gf_contract(const float* Z, const float* h, const float* bias, fl
     GF_REQUIRE_ARG(Z && h && out, "gf_contract: NULL tensor");
     GF_REQUIRE_SHAPE(B > 0 && N > 0 && Nout > 0 && Nout <= N && G > 0 && F > 0 && E > 0 && K > 0,
                      "gf_contract: bad shape B=%d N=%d Nout=%d G=%d F=%d E=%d K=%d", B, N, Nout, G, F, E, K);
+    GF_REQUIRE_ARG(transpose_bank == 0 || transpose_bank == 1, "gf_contract: transpose_bank = %d", transpose_bank);
     GF_REQUIRE_ARG(!(transpose_bank && bias), "gf_contract: bias is only defined for the forward bank");
     return gf_contract_launch(Z, h, bias, out, B, N, Nout, G, F, E, K, transpose_bank, gf_stream(stream));
 }

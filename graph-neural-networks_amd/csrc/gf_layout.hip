@@ -18,7 +18,7 @@ constexpr int TROWS = 8;  // 32 x 8 threads
 // With (R, C) = (G, N) this is x[B,G,Nin] -> X[B,N,G];  with (R, C) = (N, G) and swapped roles it is the inverse.
 __global__ __launch_bounds__(TILE* TROWS) void transpose_pad_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                       int R, int Cin, int Cout, int64_t in_bstride,
-                                                                      int64_t out_bstride) {
+                                                                      int64_t out_bstride, const float* __restrict__ mask) {
     __shared__ float tile[TILE][TILE + 1];
     const int b = blockIdx.z;
     const int c0 = blockIdx.x * TILE;
@@ -30,7 +30,11 @@ __global__ __launch_bounds__(TILE* TROWS) void transpose_pad_kernel(const float*
     for (int i = 0; i < TILE; i += TROWS) {
         const int r = r0 + ty + i, c = c0 + tx;
         float v = 0.f;
-        if (r < R && c < Cin) v = ib[(int64_t)r * Cin + c];
+        if (r < R && c < Cin) {
+            v = ib[(int64_t)r * Cin + c];
+            // mask = the saved ReLU output, same layout as `in`: gradient of the fused epilogue (dy where y > 0, else 0)
+            if (mask != nullptr && !(mask[(int64_t)b * in_bstride + (int64_t)r * Cin + c] > 0.f)) v = 0.f;
+        }
         tile[ty + i][tx] = v;
     }
     __syncthreads();
@@ -50,7 +54,7 @@ extern "C" int gf_layout_bgn_to_bng(const float* x, float* X, int32_t B, int32_t
     GF_REQUIRE_SHAPE(B <= 65535, "gf_layout_bgn_to_bng: batch %d > 65535", B);
     dim3 grid((N + TILE - 1) / TILE, (G + TILE - 1) / TILE, B), block(TILE, TROWS);
     hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, gf_stream(stream), x, X, G, Nin, N, (int64_t)G * Nin,
-                       (int64_t)N * G);
+                       (int64_t)N * G, (const float*)nullptr);
     GF_LAUNCH_CHECK("transpose_pad_kernel(bgn->bng)");
     return GF_OK;
 }
@@ -64,7 +68,16 @@ extern "C" int gf_layout_bng_to_bgn(const float* X, float* x, int32_t B, int32_t
     // kernel with R = Nout rows of the input (input batch stride still N*G).
     dim3 grid((G + TILE - 1) / TILE, (Nout + TILE - 1) / TILE, B), block(TILE, TROWS);
     hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, gf_stream(stream), X, x, Nout, G, G, (int64_t)N * G,
-                       (int64_t)G * Nout);
+                       (int64_t)G * Nout, (const float*)nullptr);
     GF_LAUNCH_CHECK("transpose_pad_kernel(bng->bgn)");
+    return GF_OK;
+}
+
+// dy [B,F,Nin] (reference layout) -> P0 [B,N,F] node-major with the ReLU mask of the saved output y applied on the way
+int gf_layout_masked_launch(const float* dy, const float* y, float* X, int B, int G, int Nin, int N, hipStream_t st) {
+    GF_REQUIRE_SHAPE(B <= 65535, "gf_layout: batch %d > 65535", B);
+    dim3 grid((N + TILE - 1) / TILE, (G + TILE - 1) / TILE, B), block(TILE, TROWS);
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, st, dy, X, G, Nin, N, (int64_t)G * Nin, (int64_t)N * G, y);
+    GF_LAUNCH_CHECK("transpose_pad_kernel(masked)");
     return GF_OK;
 }

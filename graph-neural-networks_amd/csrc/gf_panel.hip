@@ -192,7 +192,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
 // x[B, C, Nin] (reference layout, node index contiguous) -> Xp[B*C/4][N][4]; rows n >= Nin are zero
 // (== GraphFilter.forward's zero padding, graphML.py:2131-2135).  C % 4 == 0.
 __global__ __launch_bounds__(256) void pack_panels_kernel(const float* __restrict__ x, float* __restrict__ Xp, int Nin, int N,
-                                                          int64_t total) {
+                                                          int64_t total, const float* __restrict__ mask) {
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int64_t p = idx / N;
         const int n = (int)(idx - p * N);
@@ -203,6 +203,13 @@ __global__ __launch_bounds__(256) void pack_panels_kernel(const float* __restric
             v.y = src[Nin];
             v.z = src[2 * (int64_t)Nin];
             v.w = src[3 * (int64_t)Nin];
+            if (mask != nullptr) {  // the saved ReLU output, same layout as x: gradient of the fused epilogue
+                const float* m = mask + p * 4 * Nin + n;
+                if (!(m[0] > 0.f)) v.x = 0.f;
+                if (!(m[Nin] > 0.f)) v.y = 0.f;
+                if (!(m[2 * (int64_t)Nin] > 0.f)) v.z = 0.f;
+                if (!(m[3 * (int64_t)Nin] > 0.f)) v.w = 0.f;
+            }
         }
         reinterpret_cast<float4*>(Xp)[idx] = v;
     }
@@ -252,9 +259,9 @@ bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F) {
     return true;
 }
 
-int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st) {
+int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st, const float* mask) {
     const int64_t total = (int64_t)B * (C / 4) * N;
-    hipLaunchKernelGGL(pack_panels_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, Xp, Nin, N, total);
+    hipLaunchKernelGGL(pack_panels_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, Xp, Nin, N, total, mask);
     GF_LAUNCH_CHECK("pack_panels_kernel");
     return GF_OK;
 }
@@ -285,7 +292,7 @@ extern "C" int gf_pack_panels(const float* x, float* Xp, int32_t B, int32_t C, i
     GF_REQUIRE_ARG(x && Xp, "gf_pack_panels: NULL tensor");
     GF_REQUIRE_SHAPE(B > 0 && C > 0 && C % 4 == 0 && Nin > 0 && N >= Nin, "gf_pack_panels: bad shape B=%d C=%d (C %% 4 == 0) Nin=%d N=%d",
                      B, C, Nin, N);
-    return gf_pack_panels_launch(x, Xp, B, C, Nin, N, gf_stream(stream));
+    return gf_pack_panels_launch(x, Xp, B, C, Nin, N, gf_stream(stream), nullptr);
 }
 
 extern "C" int gf_unpack_panels(const float* Xp, float* x, int32_t B, int32_t C, int32_t N, int32_t Nout, void* stream) {

@@ -153,6 +153,25 @@ int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const float* x, co
                      const float* V, float* scratch, float* dx, float* dwdiag, float* dwedge, float* dbias, int32_t B, int32_t G,
                      int32_t F, int32_t K, int32_t Nin, void* stream);
 
+/* ---- MaxPoolLocal (graphML.py:1890-2028), the pooling that follows the filter in every SelectionGNN layer
+ * (architectures.py:286-294).  nbh [Nout, M] int32 DEVICE: row i = the alpha-hop neighbourhood of node i, padded with i
+ * (graphTools.computeNeighborhood(..., 'matrix'), graphML.py:1953-1959).  forward: x [B,F,Nin] -> v [B,F,Nout] = max over the
+ * list (replaces repeat + gather + max, :2003-2018), arg [B,F,Nout] = list position of the FIRST maximum (torch.max's rule).
+ * backward: dx [B,F,Nin] from dv [B,F,Nout] through reverse lists (DEVICE int32 CSR over input nodes j: rev_ptr [Nin+1],
+ * rev_i = output node, rev_p = first position of j in nbh[rev_i]); a gather in fixed order, no atomics. */
+int gf_maxpool_forward(const float* x, const int32_t* nbh, float* v, int32_t* arg, int32_t B, int32_t F, int32_t Nin, int32_t Nout,
+                       int32_t M, void* stream);
+int gf_maxpool_backward(const float* dv, const int32_t* arg, const int32_t* rev_ptr, const int32_t* rev_i, const int32_t* rev_p,
+                        float* dx, int32_t B, int32_t F, int32_t Nin, int32_t Nout, void* stream);
+
+/* ---- GraphFilter followed by sigma = ReLU (SelectionGNN layers, architectures.py:286-289): y = max(0, LSIGF(...)) fused into the
+ * contraction's epilogue; backward takes the saved output y [B,F,Nin] and applies the mask (y > 0) to dy on the way in. */
+int gf_lsigf_forward_relu(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias,
+                          float* Z, float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
+int gf_lsigf_backward_relu(const gf_plan* const* plans, int32_t E, const float* dy, const float* y, const float* Z, const float* h,
+                           float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
+                           int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
+
 /* ---- measurement hook: run ONE hop `iters` times on `stream` bracketed by HIP events on that stream and return
  * the average milliseconds per launch (bench.py's roofline leg; hipEvents see the launch stream, torch events may not). */
 int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* X_out, int32_t B, int32_t W,

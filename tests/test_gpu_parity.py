@@ -663,3 +663,63 @@ def test_lsigf_edge_cases_under_both_pipelines(cfg, pipe, pipeline_knob):
     assert relerr(xt.grad.cpu().numpy(), dx[:, :, :nin]) < GRAD_RTOL
     assert relerr(ht.grad.cpu().numpy(), dh) < GRAD_RTOL
     assert relerr(bt.grad.cpu().numpy(), db) < GRAD_RTOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MaxPoolLocal: HIP kernel against the reference's own formulation (gather + torch.max + autograd)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,Nout,hops,B,F", [(100, 10, 2, 6, 32), (234, 234, 1, 3, 8), (500, 77, 3, 2, 5)])
+def test_max_pool_local_matches_reference_formulation(N, Nout, hops, B, F):
+    A = graphgen.sbm(N, avg_degree=4.0, seed=N)
+    pool = gml.MaxPoolLocal(N, Nout, hops)
+    pool.addGSO(SparseGSO([A]))
+    pool.to(DEV)
+    rng = np.random.RandomState(0)
+    xv = np.maximum(rng.randn(B, F, N), 0).astype(np.float32)          # ReLU output: many exact ties at 0
+    x = cu(xv, True)
+    v = pool(x)
+    w = cu(rng.randn(B, F, Nout))
+    (v * w).sum().backward()
+    xr = cu(xv, True)                                                    # graphML.py:2003-2018 in torch ops
+    nb = pool.neighborhood.long()
+    vr, _ = torch.max(xr[:, :, nb], dim=3)
+    (vr * w).sum().backward()
+    assert torch.equal(v, vr)
+    assert torch.allclose(x.grad, xr.grad, rtol=0, atol=1e-6)           # same arg-max element (first maximum) per output
+    assert float((x.grad.sum() - xr.grad.sum()).abs()) < 1e-3
+    x2 = cu(xv, True)
+    v2 = pool(x2)
+    (v2 * w).sum().backward()
+    assert torch.equal(x.grad, x2.grad)                                  # deterministic
+
+
+@pytest.mark.parametrize("pipe", [1, 2])
+@pytest.mark.parametrize("G,F,nin", [(32, 32, 300), (8, 64, 200), (3, 5, 300)])
+def test_fused_relu_epilogue_equals_separate_relu(pipe, G, F, nin, pipeline_knob):
+    """activation='relu' (epilogue max(0, .) + masked backward) == torch.relu applied to the plain filter: values bitwise,
+    gradients to round-off (the mask is the same, only the order of additions upstream differs)."""
+    N, B, K = 300, 7, 4
+    if pipe == 2 and (G % 8 or F % 8):
+        pytest.skip("panel pipeline needs MFMA-tile widths")
+    pipeline_knob(pipeline=pipe)
+    A = graphgen.sbm(N, seed=21, directed=True)
+    gso = SparseGSO([A])
+    rng = np.random.RandomState(1)
+    h = (rng.uniform(-1, 1, (F, 1, K, G)) / np.sqrt(G * K)).astype(np.float32)
+    x = rng.randn(B, G, nin).astype(np.float32)
+    b = rng.uniform(-1, 1, (F, 1)).astype(np.float32)
+    w = rng.randn(B, F, nin).astype(np.float32)
+    outs = []
+    for fused in (True, False):
+        ht, xt, bt = cu(h, True), cu(x, True), cu(b, True)
+        y = LSIGF(ht, gso, xt, bt, activation="relu") if fused else torch.relu(LSIGF(ht, gso, xt, bt))
+        (y * cu(w)).sum().backward()
+        outs.append((y.detach(), xt.grad, ht.grad, bt.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and float((outs[0][0] == 0).float().mean()) > 0.2
+    for a, r in zip(outs[0][1:], outs[1][1:]):
+        assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
+    # per-node bias [F, N] (graphML.py:110-112) cannot be fused: same result through the unfused path
+    bn = rng.uniform(-1, 1, (F, N)).astype(np.float32)
+    y1 = LSIGF(cu(h), gso, cu(x), cu(bn), activation="relu")
+    y2 = torch.relu(LSIGF(cu(h), gso, cu(x), cu(bn)))
+    assert torch.equal(y1, y2)

@@ -167,7 +167,9 @@ def test_selection_gnn_checkpoint_compatibility(name):
         assert tuple(v.shape) == tuple(ref_sd[k].shape), k
     net.load_state_dict(ref_sd, strict=True)                                    # reference checkpoint loads
     assert net.N == [d["S"].shape[1]] + d["cfg"]["nSelectedNodes"]
-    assert isinstance(net.GFL[0], gml.GraphFilter) and isinstance(net.GFL[1], torch.nn.ReLU)
+    # sigma = ReLU is fused into the filter's epilogue; a parameter-free placeholder keeps the GFL indices (state_dict keys)
+    assert isinstance(net.GFL[0], gml.GraphFilter) and isinstance(net.GFL[1], gml.FusedReLU)
+    assert net.GFL[0].fused_activation == "relu"
 
 
 def test_selection_gnn_ctor_options():
@@ -188,15 +190,24 @@ def test_selection_gnn_ctor_options():
 
 
 def test_max_pool_local_semantics():
+    """Host side of MaxPoolLocal: neighbourhood lists == the reference's, reverse lists consistent; the compute is HIP-only."""
     d = load(os.path.join(GOLDEN, "selgnn_cfg1_sbm100.npz"))
     S = d["S"]
     pool = gml.MaxPoolLocal(100, 10, 2)
     pool.addGSO(torch.tensor(S))
-    x = torch.randn(3, 4, 100)
-    v = pool(x)
     nbh = gt.computeNeighborhood(S, 2, 10, 100, "list")
-    want = torch.stack([x[:, :, nb].max(dim=2).values for nb in nbh], dim=2)
-    assert torch.equal(v, want) and "neighborhood" not in pool.state_dict()
+    got = pool.neighborhood.numpy()
+    assert got.shape == (10, max(len(nb) for nb in nbh)) and pool.maxNeighborhoodSize == got.shape[1]
+    for i, nb in enumerate(nbh):
+        assert set(got[i].tolist()) == set(nb)               # padded with the node itself (graphTools 'matrix' output)
+    rp, ri, rpos = pool._rev_ptr.numpy(), pool._rev_i.numpy(), pool._rev_p.numpy()
+    assert rp[0] == 0 and rp[-1] == len(ri) == sum(len(set(nb)) for nb in nbh)
+    for j in range(100):
+        for q in range(rp[j], rp[j + 1]):
+            assert got[ri[q], rpos[q]] == j and j not in got[ri[q], :rpos[q]]     # FIRST position of j in that list
+    assert "neighborhood" not in pool.state_dict() and "_rev_ptr" not in pool.state_dict()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pool(torch.randn(3, 4, 100))
 
 
 # ---- EdgeVariantGF host logic (pattern construction, parameter surface) -------------------------------------------
