@@ -119,7 +119,8 @@ struct gf_tuning {
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
     int panel_fuse_hops = 0;    // 1 = the K-1 hops of a chain are one launch (each workgroup walks its panels through all hops); measured: no gain
     int panel_stagger = 1;      // unified mode: start delay step between workgroup phases, in ~2 us units (0 = start together)
-    int panel_debug = 0;        // timing experiments only: 1 = skip the compute phase, 2 = skip the panel load (WRONG RESULTS)
+    int panel_debug = 0;        // timing experiments only (WRONG RESULTS): 1 = panel loads only, 2 = compute only, 3 = compute only with
+                                // every entry load redirected to the L1-resident sentinel rows, 4 = compute only without stores
     int panel_unit = 8;         // rows per work unit of the panel image: 8 | 4 | 2 (set BEFORE gf_plan_create)
     int panel_sort = 1;         // 1 = octets sorted by their longest row (set BEFORE gf_plan_create)
 };

@@ -55,7 +55,11 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
     typedef typename ColWord<UNIFORM>::type colw;
     const colw* col4 = reinterpret_cast<const colw*>(cols) + lane;
-    const char* ldsb = reinterpret_cast<const char*>(panel);
+    // gathers address LDS absolutely: the dynamic panel is this kernel's only LDS object, so it starts at LDS address 0 and a
+    // stored byte offset IS the ds_read address (through the `panel` symbol the compiler adds a relocatable base -- a useless
+    // v_add per gather in an issue-bound loop)
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // a static __shared__ object would shift the panel
+    const unsigned lds_zero = 0u;
     const f32x4* val4 = reinterpret_cast<const f32x4*>(vals) + lane;
 
     if (tid == 0) lds4[N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slot empty ELL slots gather from
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
       for (int h = 0; h < nHops; ++h) {
         const float* srcp = (h == 0 ? Xin : Xout + (int64_t)(h - 1) * tapStride) + (int64_t)p * pstride;
         float* outp = Xout + (int64_t)h * tapStride + (int64_t)p * pstride;
-        if (debug != 2) {
+        if (debug != 2 && debug != 3 && debug != 4) {
             // HBM-bound phase: every wave loads its share of the panel (N <= kNVU * blockDim.x rows of 16 bytes).
             // (Requesting the NEXT panel from inside the compute phase instead -- registers, one HBM-latency stall per wave
             // and panel -- was measured and gave nothing: 184 vs 181 us; a CU pulls at most ~22 GB/s from HBM and the
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 const bool same = (j0 + kGC) < si.y;  // wave-uniform: the next chunk belongs to the same slice
                 // next chunk: same slice (group-rows per slice are even: a chunk never straddles two blocks), or the head of
                 // the next slice (the sentinel rows when it is empty / absent)
-                const int gnext = same ? si.x + j0 + kGC : (sin.y > 0 ? sin.x : sentinel);
+                int gnext = same ? si.x + j0 + kGC : (sin.y > 0 ? sin.x : sentinel);
+                if (debug == 3) gnext = sentinel;  // timing experiment: every entry load hits the same (L1-resident) sentinel rows
                 load_chunk(cn, vn, gnext);
 #pragma unroll
                 for (int g = 0; g < kGC; ++g) {
@@ -130,10 +135,11 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                     } else {
                         o0 = (cc[g].x & 0xffffu) << 4, o1 = (cc[g].x >> 16) << 4, o2 = (cc[g].y & 0xffffu) << 4, o3 = (cc[g].y >> 16) << 4;
                     }
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(ldsb + o0);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(ldsb + o1);
-                    const f32x4 x2 = *reinterpret_cast<const f32x4*>(ldsb + o2);
-                    const f32x4 x3 = *reinterpret_cast<const f32x4*>(ldsb + o3);
+                    typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+                    const f32x4 x0 = *reinterpret_cast<lds_f32x4*>(o0 + lds_zero);
+                    const f32x4 x1 = *reinterpret_cast<lds_f32x4*>(o1 + lds_zero);
+                    const f32x4 x2 = *reinterpret_cast<lds_f32x4*>(o2 + lds_zero);
+                    const f32x4 x3 = *reinterpret_cast<lds_f32x4*>(o3 + lds_zero);
                     if (UNIFORM) {
                         acc0 += x0;
                         acc1 += x1;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                     return false;
                 }
                 const int row = (oc << ush) + (lane & ((1 << ush) - 1));
-                if (oc >= 0 && row < N) {
+                if (oc >= 0 && row < N && !(debug == 4 && acc0.x != 12345.678f)) {  // debug 4: no stores (timing experiment)
                     f32x4 acc = acc0 + acc1;
                     if (UNIFORM) acc *= uval;
                     f32x4* dst = reinterpret_cast<f32x4*>(outp + (int64_t)row * 4);

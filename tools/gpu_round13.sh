@@ -19,9 +19,9 @@ for rep in range(3):
         tune(panel_debug=0, panel_uniform=uni, spmm_store=0, panel_stagger=1)
         _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X.data_ptr(), Y.data_ptr(), P, 20, torch.cuda.current_stream().cuda_stream, ctypes.byref(ms)))
         print(f"{ms.value*1e3:8.1f} us  uniform={uni}", flush=True)
-for dbg in (1, 2):
+for dbg in (1, 2, 3, 4):
     tune(panel_debug=dbg, panel_uniform=1)
     _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X.data_ptr(), Y.data_ptr(), P, 20, torch.cuda.current_stream().cuda_stream, ctypes.byref(ms)))
-    print(f"{ms.value*1e3:8.1f} us  uniform=1 debug={dbg} (1 = load only, 2 = compute only)", flush=True)
+    print(f"{ms.value*1e3:8.1f} us  uniform=1 debug={dbg} (1 = load only, 2 = compute only, 3 = compute only with L1-resident entry loads, 4 = compute only without stores)", flush=True)
 PY
 cat $O/phase.log; timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k 'panel or pipelines or edge_cases' 2>&1 | tail -3
