@@ -118,7 +118,10 @@ struct gf_tuning {
     int panel_uniform = 1;      // 1 = use the value-free stream when the plan detected uniform values
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
     int panel_fuse_hops = 0;    // 1 = the K-1 hops of a chain are one launch (each workgroup walks its panels through all hops); measured: no gain
-    int panel_stagger = 1;      // unified mode: start delay step between workgroup phases, in ~2 us units (0 = start together)
+    int panel_stagger = 20;     // start delay between workgroup phases: low 4 bits = ~0.5 us quanta per phase step, bits 4+ = log2(phases) - 2
+                                // (20 = 8 phases x 2 us, the measured optimum at N = 1e4); 0 = start together
+    int panel_rotate = 1;       // 1 = each workgroup walks the slice list from its own starting offset
+    int panel_grid = 0;         // experiments: cap on the panel kernel's grid (0 = one workgroup per LDS-full)
     int panel_debug = 0;        // timing experiments only (WRONG RESULTS): 1 = panel loads only, 2 = compute only, 3 = compute only with
                                 // every entry load redirected to the L1-resident sentinel rows, 4 = compute only without stores
     int panel_unit = 8;         // rows per work unit of the panel image: 8 | 4 | 2 (set BEFORE gf_plan_create)

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                                                           const void* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
                                                           int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug,
-                                                          int stagger, int ush, int nHops, int64_t tapStride) {
+                                                          int stagger, int ush, int nHops, int64_t tapStride, int rotate) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,10 +63,20 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     const f32x4* val4 = reinterpret_cast<const f32x4*>(vals) + lane;
 
     if (tid == 0) lds4[N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slot empty ELL slots gather from
+    const int rot = rotate ? (int)((blockIdx.x * 41u) % (unsigned)nSlices) : 0;
     {
         // De-synchronise the workgroups once (see the header comment).
-        const int phase = (int)((blockIdx.x >> 3) & 7);  // workgroups b, b+8, ... share an XCD: spread within each XCD
-        for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(64);  // 64 * 64 cycles ~ 2 us each
+        // stagger = 16 * (log2 of the number of phases - 2) + sleep quanta of 16 * 64 cycles (~0.5 us) per phase step
+        if (stagger >= 64) {  // pseudo-random start delay in [0, (stagger - 64) * 0.5 us)
+            unsigned hsh = (blockIdx.x >> 3) * 2654435761u;
+            hsh ^= hsh >> 15;
+            const int q = (int)((hsh & 1023u) * (unsigned)(stagger - 64) >> 10);
+            for (int i = 0; i < q; ++i) __builtin_amdgcn_s_sleep(16);
+        } else {
+            const int nph = 4 << (stagger >> 4);
+            const int phase = (int)((blockIdx.x >> 3) & (nph - 1));  // workgroups b, b+8, ... share an XCD: spread within each XCD
+            for (int i = 0; i < phase * (stagger & 15); ++i) __builtin_amdgcn_s_sleep(16);
+        }
     }
 
     // request group-rows [g0, g0 + kGC) of an ELL block (g0 = absolute group-row index)
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
             f32x4 tmp[kNVU];
             const int nthr = (int)blockDim.x;
 #pragma unroll
-            for (int j = 0; j < kNVU; ++j) tmp[j] = src[min(tid + j * nthr, N - 1)];
+            for (int j = 0; j < kNVU; ++j) tmp[j] = src[min(tid + j * nthr, N - 1)];  // (a non-temporal hint here: no effect)
 #pragma unroll
             for (int j = 0; j < kNVU; ++j)
                 if (tid + j * nthr < N) lds4[tid + j * nthr] = tmp[j];
@@ -103,14 +113,17 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
         __syncthreads();  // B1: panel p is in LDS
         if (wave < nSlices && debug != 1) {
             int s = wave;                       // slice in hand
-            int2 si = slice[s];                 // {group-row offset, group-rows}
-            int oc = octs[(s << (6 - ush)) + (lane >> ush)];
+            // Workgroups walk the slice list rotated by a workgroup-specific offset: at any moment the 256 CUs read different parts
+            // of the (shared, L2-resident) entry arrays instead of queueing on the same L2 channels.
+            auto rs = [&](int q) { const int t = q + rot; return t >= nSlices ? t - nSlices : t; };
+            int2 si = slice[rs(s)];             // {group-row offset, group-rows}
+            int oc = octs[(rs(s) << (6 - ush)) + (lane >> ush)];
             int sn = s + CW;                    // next slice of this wave (its header is fetched one slice ahead)
             int2 sin = make_int2(sentinel, 0);
             int ocn = -1;
             if (sn < nSlices) {
-                sin = slice[sn];
-                ocn = octs[(sn << (6 - ush)) + (lane >> ush)];
+                sin = slice[rs(sn)];
+                ocn = octs[(rs(sn) << (6 - ush)) + (lane >> ush)];
             }
             int j0 = 0;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -177,8 +190,8 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 sin = make_int2(sentinel, 0);
                 ocn = -1;
                 if (sn < nSlices) {
-                    sin = slice[sn];
-                    ocn = octs[(sn << (6 - ush)) + (lane >> ush)];
+                    sin = slice[rs(sn)];
+                    ocn = octs[(rs(sn) << (6 - ush)) + (lane >> ush)];
                 }
                 return false;
             };
@@ -285,11 +298,12 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     if (wgPerCU < 1) wgPerCU = 1;
     int64_t grid = (int64_t)num_cus() * wgPerCU;
     if (grid > nPanels) grid = nPanels;
+    if (g_tune.panel_grid > 0 && grid > g_tune.panel_grid) grid = g_tune.panel_grid;  // experiments: fewer workgroups than CUs
     const bool uniform = m.pn_uniform && g_tune.panel_uniform;
     auto kern = uniform ? spmm_panel_kernel<1> : spmm_panel_kernel<0>;
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride);
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride, g_tune.panel_rotate);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # full parity suite, bench (both pipelines), rocprof stats, PMC traffic of the panel hop
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out/r19; rm -rf $O; mkdir -p $O
+O=gpurun_out/r23; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log
 tail -4 $O/pytest_gpu.log
 timeout 400 python bench.py --detail > $O/bench_cfg2.json 2> $O/bench_cfg2.err; cat $O/bench_cfg2.json
@@ -11,13 +11,13 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats_full.csv
 python - <<'PY'
 import csv
-rows = list(csv.reader(open("gpurun_out/r19/bench_kernel_stats_full.csv")))
-with open("gpurun_out/r19/bench_kernel_stats.csv", "w") as f:
+rows = list(csv.reader(open("gpurun_out/r23/bench_kernel_stats_full.csv")))
+with open("gpurun_out/r23/bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f)
     for r in rows:
         r[0] = r[0][:150]
         w.writerow(r)
-print(open("gpurun_out/r19/bench_kernel_stats.csv").read()[:2500])
+print(open("gpurun_out/r23/bench_kernel_stats.csv").read()[:2500])
 PY
 rm -rf $O/prof $O/bench_kernel_stats_full.csv
 i=0
@@ -28,7 +28,7 @@ done
 python - <<'PY'
 import csv, glob, collections, json
 tot = {}
-for d in sorted(glob.glob("gpurun_out/r19/pmc*/pmc_counter_collection.csv")):
+for d in sorted(glob.glob("gpurun_out/r23/pmc*/pmc_counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(d)):
         if "spmm_panel" in r["Kernel_Name"]:
@@ -36,6 +36,6 @@ for d in sorted(glob.glob("gpurun_out/r19/pmc*/pmc_counter_collection.csv")):
     for k, v in agg.items():
         tot[k] = sum(v) / len(v)
 print(tot)
-json.dump(tot, open("gpurun_out/r19/pmc_panel_raw.json", "w"))
+json.dump(tot, open("gpurun_out/r23/pmc_panel_raw.json", "w"))
 PY
 rm -rf $O/pmc*/
