@@ -142,6 +142,9 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 load_chunk(cn, vn, gnext);
 #pragma unroll
                 for (int g = 0; g < kGC; ++g) {
+                    // a slice with an odd number of group-rows: the round's second group belongs to the next block -- its
+                    // (already requested) entries are dropped by a wave-uniform branch instead of gathering padding
+                    if (g > 0 && j0 + g >= si.y) break;
                     unsigned o0, o1, o2, o3;  // LDS byte offsets of the 4 gathered rows
                     if constexpr (UNIFORM) {
                         o0 = cc[g].x, o1 = cc[g].y, o2 = cc[g].z, o3 = cc[g].w;

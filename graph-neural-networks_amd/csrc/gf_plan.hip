@@ -41,6 +41,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_uniform")) g_tune.panel_uniform = value;
     else if (!strcmp(key, "panel_order")) g_tune.panel_order = value;
     else if (!strcmp(key, "panel_sort")) g_tune.panel_sort = value;
+    else if (!strcmp(key, "panel_even")) g_tune.panel_even = value;
     else if (!strcmp(key, "panel_unit")) g_tune.panel_unit = value;
     else if (!strcmp(key, "panel_debug")) g_tune.panel_debug = value;
     else if (!strcmp(key, "panel_grid")) g_tune.panel_grid = value;
@@ -236,7 +237,7 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
                 w = std::max<int32_t>(w, (int32_t)rest[l].size());
             }
         }
-        const int32_t gmax = (((w + 3) / 4) + 1) & ~1;             // even: the kernel walks group-rows two at a time
+        const int32_t gmax = g_tune.panel_even ? ((((w + 3) / 4) + 1) & ~1) : (w + 3) / 4;  // (even: a two-group round never straddles blocks)
         slice[sl] = make_int2((int32_t)(col4.size() / 64), gmax);   // group-row offset (x 64 lanes), group-steps
         picks.assign((size_t)gmax * 4 * 64, -1);
         for (int32_t k = 0; k < w; ++k) {
