@@ -125,6 +125,7 @@ struct gf_tuning {
     int panel_debug = 0;        // timing experiments only (WRONG RESULTS): 1 = panel loads only, 2 = compute only, 3 = compute only with
                                 // every entry load redirected to the L1-resident sentinel rows, 4 = compute only without stores
     int panel_unit = 8;         // rows per work unit of the panel image: 8 | 4 | 2 (set BEFORE gf_plan_create)
+    int panel_np = 0;           // panels per workgroup pass: 0 = heuristic (2 while two workgroups still fit a CU's LDS), 1, 2
     int panel_even = 0;         // 1 = pad every slice to an even number of group-rows (set BEFORE gf_plan_create)
     int panel_sort = 1;         // 1 = octets sorted by their longest row (set BEFORE gf_plan_create)
 };

@@ -39,7 +39,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int UNIFORM> struct ColWord { typedef u32x2 type; };   // weighted stream: 4 x 16-bit columns
 template <> struct ColWord<1> { typedef u32x4 type; };            // value-free stream: 4 LDS byte offsets
 
-template <int UNIFORM>
+template <int UNIFORM, int NP>
 __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict__ slice, const int32_t* __restrict__ octs,
                                                           const void* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
@@ -50,8 +50,9 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int CW = (int)(blockDim.x >> 6);
     const int64_t pstride = (int64_t)N * 4;  // floats per panel
+    const int nGroups = (nPanels + NP - 1) / NP;  // passes: NP panels each
     int p = blockIdx.x;
-    if (p >= nPanels) return;  // whole workgroup
+    if (p >= nGroups) return;  // whole workgroup
     f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
     typedef typename ColWord<UNIFORM>::type colw;
     const colw* col4 = reinterpret_cast<const colw*>(cols) + lane;
@@ -62,7 +63,10 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     const unsigned lds_zero = 0u;
     const f32x4* val4 = reinterpret_cast<const f32x4*>(vals) + lane;
 
-    if (tid == 0) lds4[N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slot empty ELL slots gather from
+    // NP panels per pass live side by side in LDS (region k = float4 index k*(N+1), each with its own zero slot): one entry word
+    // then drives NP gathers -- the (column, value) stream and its bookkeeping are amortised over NP x 16 bytes per edge.
+    const unsigned regionB = (unsigned)(N + 1) * 16u;
+    if (tid < NP) lds4[tid * (N + 1) + N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slots empty ELL slots gather from
     const int rot = rotate ? (int)((blockIdx.x * 41u) % (unsigned)nSlices) : 0;
     {
         // De-synchronise the workgroups once (see the header comment).
@@ -93,22 +97,27 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
       // workgroup just stored (tap stride tapStride), i.e. from L2 / Infinity Cache instead of an HBM-latency-bound reload,
       // and the K-1 hops of a chain are one launch.
       for (int h = 0; h < nHops; ++h) {
-        const float* srcp = (h == 0 ? Xin : Xout + (int64_t)(h - 1) * tapStride) + (int64_t)p * pstride;
-        float* outp = Xout + (int64_t)h * tapStride + (int64_t)p * pstride;
+        const float* srcp = (h == 0 ? Xin : Xout + (int64_t)(h - 1) * tapStride) + (int64_t)p * NP * pstride;
+        float* outp = Xout + (int64_t)h * tapStride + (int64_t)p * NP * pstride;
+        const int nvalid = min(NP, nPanels - p * NP);  // panels of this pass (the last pass may be short)
         if (debug != 2 && debug != 3 && debug != 4) {
             // HBM-bound phase: every wave loads its share of the panel (N <= kNVU * blockDim.x rows of 16 bytes).
             // (Requesting the NEXT panel from inside the compute phase instead -- registers, one HBM-latency stall per wave
             // and panel -- was measured and gave nothing: 184 vs 181 us; a CU pulls at most ~22 GB/s from HBM and the
             // entry streams compete for the same L1 miss queue.)
             constexpr int kNVU = 10;
-            const f32x4* src = reinterpret_cast<const f32x4*>(srcp);
-            f32x4 tmp[kNVU];
             const int nthr = (int)blockDim.x;
 #pragma unroll
-            for (int j = 0; j < kNVU; ++j) tmp[j] = src[min(tid + j * nthr, N - 1)];  // (a non-temporal hint here: no effect)
+            for (int k = 0; k < NP; ++k) {
+                if (k >= nvalid) break;
+                const f32x4* src = reinterpret_cast<const f32x4*>(srcp + (int64_t)k * pstride);
+                f32x4 tmp[kNVU];
 #pragma unroll
-            for (int j = 0; j < kNVU; ++j)
-                if (tid + j * nthr < N) lds4[tid + j * nthr] = tmp[j];
+                for (int j = 0; j < kNVU; ++j) tmp[j] = src[min(tid + j * nthr, N - 1)];  // (a non-temporal hint here: no effect)
+#pragma unroll
+                for (int j = 0; j < kNVU; ++j)
+                    if (tid + j * nthr < N) lds4[k * (N + 1) + tid + j * nthr] = tmp[j];
+            }
         }
         __syncthreads();  // B1: panel p is in LDS
         if (wave < nSlices && debug != 1) {
@@ -126,7 +135,9 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 ocn = octs[(rs(sn) << (6 - ush)) + (lane >> ush)];
             }
             int j0 = 0;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc0[NP], acc1[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc0[k] = acc1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
             colw cA[kGC], cB[kGC];
             f32x4 vA[kGC], vB[kGC];
             load_chunk(cA, vA, si.y > 0 ? si.x : sentinel);
@@ -152,20 +163,24 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                         o0 = (cc[g].x & 0xffffu) << 4, o1 = (cc[g].x >> 16) << 4, o2 = (cc[g].y & 0xffffu) << 4, o3 = (cc[g].y >> 16) << 4;
                     }
                     typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
-                    const f32x4 x0 = *reinterpret_cast<lds_f32x4*>(o0 + lds_zero);
-                    const f32x4 x1 = *reinterpret_cast<lds_f32x4*>(o1 + lds_zero);
-                    const f32x4 x2 = *reinterpret_cast<lds_f32x4*>(o2 + lds_zero);
-                    const f32x4 x3 = *reinterpret_cast<lds_f32x4*>(o3 + lds_zero);
-                    if (UNIFORM) {
-                        acc0 += x0;
-                        acc1 += x1;
-                        acc0 += x2;
-                        acc1 += x3;
-                    } else {
-                        acc0 += vv[g].x * x0;   // contracted to FMAs; two accumulators: fixed order, shorter dependency chain
-                        acc1 += vv[g].y * x1;
-                        acc0 += vv[g].z * x2;
-                        acc1 += vv[g].w * x3;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const unsigned rb = lds_zero + k * regionB;
+                        const f32x4 x0 = *reinterpret_cast<lds_f32x4*>(o0 + rb);
+                        const f32x4 x1 = *reinterpret_cast<lds_f32x4*>(o1 + rb);
+                        const f32x4 x2 = *reinterpret_cast<lds_f32x4*>(o2 + rb);
+                        const f32x4 x3 = *reinterpret_cast<lds_f32x4*>(o3 + rb);
+                        if (UNIFORM) {
+                            acc0[k] += x0;
+                            acc1[k] += x1;
+                            acc0[k] += x2;
+                            acc1[k] += x3;
+                        } else {
+                            acc0[k] += vv[g].x * x0;   // contracted to FMAs; two accumulators: fixed order, shorter dependency chain
+                            acc1[k] += vv[g].y * x1;
+                            acc0[k] += vv[g].z * x2;
+                            acc1[k] += vv[g].w * x3;
+                        }
                     }
                 }
                 if (same) {
@@ -173,17 +188,21 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                     return false;
                 }
                 const int row = (oc << ush) + (lane & ((1 << ush) - 1));
-                if (oc >= 0 && row < N && !(debug == 4 && acc0.x != 12345.678f)) {  // debug 4: no stores (timing experiment)
-                    f32x4 acc = acc0 + acc1;
-                    if (UNIFORM) acc *= uval;
-                    f32x4* dst = reinterpret_cast<f32x4*>(outp + (int64_t)row * 4);
-                    if (store_mode == 2)
-                        __builtin_nontemporal_store(acc, dst);
-                    else
-                        *dst = acc;
+                if (oc >= 0 && row < N && !(debug == 4 && acc0[0].x != 12345.678f)) {  // debug 4: no stores (timing experiment)
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        if (k >= nvalid) break;
+                        f32x4 acc = acc0[k] + acc1[k];
+                        if (UNIFORM) acc *= uval;
+                        f32x4* dst = reinterpret_cast<f32x4*>(outp + (int64_t)k * pstride + (int64_t)row * 4);
+                        if (store_mode == 2)
+                            __builtin_nontemporal_store(acc, dst);
+                        else
+                            *dst = acc;
+                    }
                 }
-                acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NP; ++k) acc0[k] = acc1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 s = sn;
                 if (s >= nSlices) return true;
                 si = sin;
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
         __syncthreads();  // B2: every wave is done reading panel p
       }
         p += (int)gridDim.x;
-        if (p >= nPanels) break;
+        if (p >= nGroups) break;
     }
 }
 
@@ -293,19 +312,32 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     const gf_csr_dev& m = plan->mat[op];
     const int N = plan->n;
     GF_REQUIRE_ARG(m.pn_slices > 0, "gf_spmm_hop_panel: the plan has no panel image (N = %d > %d?)", N, kPanelMaxNodes);
-    const int threads = N > 5120 ? 1024 : (N > 2560 ? 512 : 256);
-    const size_t lds = (size_t)(N + 1) * 16;
+    // NP panels per pass while the LDS still takes two workgroups per CU (their load and compute phases then overlap);
+    // knob panel_np forces 1 / 2
+    // (measured, tools/gpu_round25.sh: value-free stream +2-4 % for N <= 2559, mixed above; weighted stream +13-15 % up to N = 5119,
+    // where the pair fills the LDS and only one workgroup fits a CU)
+    const bool uniform = m.pn_uniform && g_tune.panel_uniform;
+    const size_t pair = 2 * (size_t)(N + 1) * 16;
+    int np = (pair <= 80 * 1024 || (!uniform && pair <= 160 * 1024)) ? 2 : 1;
+    if (g_tune.panel_np == 1 || (g_tune.panel_np == 2 && pair <= 160 * 1024)) np = g_tune.panel_np;
+    if (nPanels < 2 * num_cus()) np = 1;  // not enough panels to keep every CU busy with pairs
+    const size_t lds = (size_t)np * (N + 1) * 16;
+    const int threads = N > 5120 ? 1024 : ((N > 2560 || (np == 2 && N > 1280)) ? 512 : 256);
+    const int thr = (lds > 80 * 1024) ? 1024 : threads;  // one workgroup per CU: give it all 16 waves
     int wgPerCU = (int)((160 * 1024) / (lds < 1024 ? 1024 : lds));
-    const int waveCap = 32 / (threads / 64);
+    const int waveCap = 32 / (thr / 64);
     if (wgPerCU > waveCap) wgPerCU = waveCap;
     if (wgPerCU < 1) wgPerCU = 1;
+    const int nGroups = (nPanels + np - 1) / np;
     int64_t grid = (int64_t)num_cus() * wgPerCU;
-    if (grid > nPanels) grid = nPanels;
+    if (grid > nGroups) grid = nGroups;
     if (g_tune.panel_grid > 0 && grid > g_tune.panel_grid) grid = g_tune.panel_grid;  // experiments: fewer workgroups than CUs
-    const bool uniform = m.pn_uniform && g_tune.panel_uniform;
-    auto kern = uniform ? spmm_panel_kernel<1> : spmm_panel_kernel<0>;
+    typedef void (*kern_t)(const int2*, const int32_t*, const void*, const float4*, float, const float*, float*, int, int, int, int, int,
+                           int, int, int, int, int64_t, int);
+    kern_t kern = np == 2 ? (uniform ? (kern_t)spmm_panel_kernel<1, 2> : (kern_t)spmm_panel_kernel<0, 2>)
+                          : (uniform ? (kern_t)spmm_panel_kernel<1, 1> : (kern_t)spmm_panel_kernel<0, 1>);
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
                        Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride, g_tune.panel_rotate);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;

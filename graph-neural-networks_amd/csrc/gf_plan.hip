@@ -42,6 +42,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_order")) g_tune.panel_order = value;
     else if (!strcmp(key, "panel_sort")) g_tune.panel_sort = value;
     else if (!strcmp(key, "panel_even")) g_tune.panel_even = value;
+    else if (!strcmp(key, "panel_np")) g_tune.panel_np = value;
     else if (!strcmp(key, "panel_unit")) g_tune.panel_unit = value;
     else if (!strcmp(key, "panel_debug")) g_tune.panel_debug = value;
     else if (!strcmp(key, "panel_grid")) g_tune.panel_grid = value;

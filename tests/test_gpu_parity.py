@@ -452,7 +452,7 @@ def tune(**kw):
 @pytest.fixture
 def pipeline_knob():
     yield tune
-    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_fuse_hops=0)
+    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_fuse_hops=0, panel_np=0)
 
 
 def to_panels(x, N):
@@ -480,6 +480,7 @@ def test_pack_unpack_panels(B, C, Nin, N):
 @pytest.mark.parametrize("N,P,kind", [
     (100, 3, "weighted"), (1000, 40, "weighted"), (1000, 40, "uniform"), (2561, 64, "weighted"), (5000, 300, "uniform"),
     (5121, 700, "weighted"), (10000, 520, "uniform"), (10239, 300, "weighted"), (64, 2, "weighted"), (63, 5, "uniform"),
+    (1000, 601, "uniform"), (2000, 1030, "weighted"), (300, 515, "weighted"),      # two panels per pass, odd panel counts
 ], ids=lambda v: str(v))
 def test_spmm_hop_panel_against_scipy(N, P, kind, pipeline_knob):
     """One LDS-panel hop, both operators, against scipy: workgroup sizes 256 / 512 / 1024, more panels than workgroups,
@@ -515,8 +516,10 @@ def test_spmm_hop_panel_against_scipy(N, P, kind, pipeline_knob):
             want = np.stack([M.astype(np.float64) @ X[p].astype(np.float64) for p in range(P)])
             assert relerr(out.cpu().numpy(), want) < 2e-6, (op, use_uniform)
             out2 = torch.empty_like(out)
+            pipeline_knob(panel_np=2 if N <= 5119 else 1)     # force the two-panels-per-pass kernel where the LDS allows it
             _lib.check(L.gf_spmm_hop_panel(plans[0], op, Xt.data_ptr(), out2.data_ptr(), P, stream()))
-            assert torch.equal(out, out2)                    # bitwise deterministic
+            pipeline_knob(panel_np=0)
+            assert torch.equal(out, out2)                    # bitwise deterministic, whatever the pass width
 
 
 def test_spmm_hop_panel_does_not_spread_nonfinite_values():
