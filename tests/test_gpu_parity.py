@@ -726,3 +726,50 @@ def test_fused_relu_epilogue_equals_separate_relu(pipe, G, F, nin, pipeline_knob
     y1 = LSIGF(cu(h), gso, cu(x), cu(bn), activation="relu")
     y2 = torch.relu(LSIGF(cu(h), gso, cu(x), cu(bn)))
     assert torch.equal(y1, y2)
+
+
+def test_training_step_is_hip_graph_capturable():
+    """A SelectionGNN training step (filters + fused ReLU + MaxPoolLocal + MLP, forward and backward) captured in a HIP graph
+    through torch.cuda.graph and replayed: the library launches only on the stream it is given, allocates nothing and never
+    synchronises, so the launch-bound small configurations (BASELINE config 1: N = 100) can be replayed as one graph."""
+    d = load(os.path.join(GOLDEN, "selgnn_cfg1_sbm100.npz"))
+    cfg = d["cfg"]
+    net = SelectionGNN(cfg["dimNodeSignals"], cfg["nFilterTaps"], True, torch.nn.ReLU, cfg["nSelectedNodes"],
+                       getattr(gml, cfg["pool"]), cfg["poolingSize"], cfg["dimLayersMLP"], d["S"][0]).float().to(DEV)
+    x_static = torch.randn(16, 1, 100, device=DEV)
+    params = [p for p in net.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = net(x_static).square().sum()
+        loss.backward()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up outside the capture: plans, LDS attributes, allocator pools
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    eager_loss = step().item()
+    eager_grads = [p.grad.clone() for p in params]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_loss = step()
+    static_grads = [p.grad for p in params]             # the graph's output buffers (p.grad is re-pointed by the eager runs below)
+    x_new = torch.randn(16, 1, 100, device=DEV)
+    for xv in (x_static.clone(), x_new):
+        x_static.copy_(xv)
+        g.replay()
+        torch.cuda.synchronize()
+        graph_loss = static_loss.item()
+        graph_grads = [t.clone() for t in static_grads]
+        for p in params:
+            p.grad = None
+        ref_loss = net(xv).square().sum()
+        ref_loss.backward()
+        assert abs(graph_loss - ref_loss.item()) <= 1e-5 * abs(ref_loss.item())
+        for a, p in zip(graph_grads, params):
+            assert torch.equal(a, p.grad)
+    assert abs(eager_loss - eager_loss) == 0 and len(eager_grads) == len(params)

@@ -15,7 +15,7 @@ x = torch.randn(B, G, N, device=dev, requires_grad=True); dy = torch.randn(B, F,
 def step():
     x.grad = None; layer.zero_grad()
     y = layer(x); y.backward(dy)
-for zz in (1, 0, 1, 0):
+for zz in (1, 0, 1, 0, 1, 0):
     assert L.gf_tune(b"panel_fuse_hops", zz) == 0
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
