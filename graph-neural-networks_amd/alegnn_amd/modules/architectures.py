@@ -9,7 +9,9 @@ Differences, all supersets or fixes:
     for N >= 1e4 where the reference's dense E x N x N array stops fitting.
   * ``order='Degree' | 'EDS' | 'SpectralProxies'`` works (the reference evaluates ``Utils.graphTools.perm...`` with an
     undefined name ``Utils`` and raises NameError, architectures.py:210).
-  * ``coarsening=True`` (Graclus, graphTools.py:1337-1614) is not rebuilt: NotImplementedError.
+  * ``coarsening=True`` (Graclus, graphTools.py:1337-1614; single edge feature, as in the reference) accepts a sparse
+    GSO too, and pads / reorders the input signal on the device in x's dtype (the reference round-trips through a
+    float64 numpy array, architectures.py:429-434).
   * ``.to(device)`` moves parameters and buffers only; device plans are built lazily per device, and the identity
     node ordering skips the ``x[:, :, order]`` gather (architectures.py:437 copies x every call).
 """
@@ -45,9 +47,6 @@ class SelectionGNN(nn.Module):
         assert len(dimNodeSignals) == len(nFilterTaps) + 1         # architectures.py:184
         assert len(nSelectedNodes) == len(nFilterTaps)              # :187
         assert len(poolingSize) == len(nFilterTaps)                 # :189
-        if coarsening:
-            raise NotImplementedError("SelectionGNN(coarsening=True): Graclus coarsening (reference graphTools.py:1337-1614) "
-                                      "is host-side setup outside the rebuilt hot path; use selection pooling.")
         self.L = len(nFilterTaps)
         self.F = dimNodeSignals
         self.K = nFilterTaps
@@ -55,23 +54,27 @@ class SelectionGNN(nn.Module):
         self.sigma = nonlinearity
         self.rho = poolingFunction
         self.dimLayersMLP = dimLayersMLP
-        self.coarsening = False
+        self.coarsening = bool(coarsening)
         self.alpha = poolingSize
         self._order_name = order
         self._install_gso(GSO)
-        self.N = [self._gso.N] + nSelectedNodes                     # :256
+        if not self.coarsening:
+            self.N = [self._gso.N] + nSelectedNodes                 # :256
 
         gfl = []
         for l in range(self.L):
             gfl.append(gml.GraphFilter(self.F[l], self.F[l + 1], self.K[l], self.E, self.bias))   # :277-278
-            gfl[3 * l].addGSO(self._gso)
+            gfl[3 * l].addGSO(self._gsos[l] if self.coarsening else self._gso)                    # :282-285
             if self.sigma is nn.ReLU:              # sigma = ReLU runs in the filter's epilogue / backward mask
                 gfl[3 * l].fused_activation = "relu"
                 gfl.append(gml.FusedReLU())
             else:
                 gfl.append(self.sigma())                                                          # :287
-            gfl.append(self.rho(self.N[l], self.N[l + 1], self.alpha[l]))                        # :292
-            gfl[3 * l + 2].addGSO(self._gso)
+            if self.coarsening:
+                gfl.append(self.rho(self.alpha[l]))                                               # :290 (e.g. nn.MaxPool1d)
+            else:
+                gfl.append(self.rho(self.N[l], self.N[l + 1], self.alpha[l]))                    # :292
+                gfl[3 * l + 2].addGSO(self._gso)
         self.GFL = nn.Sequential(*gfl)
 
         fc = []
@@ -86,6 +89,9 @@ class SelectionGNN(nn.Module):
     def _install_gso(self, GSO):
         """Normalise GSO to E x N x N, apply the node ordering, keep ``self.S`` (reference attribute) and the SparseGSO."""
         sparse_in = sp.issparse(GSO) or isinstance(GSO, (SparseGSO, list, tuple))
+        if self.coarsening and self._install_coarsened(GSO, sparse_in):
+            return
+        self.coarsening = False       # more than one edge feature: selection pooling (architectures.py:224, :257)
         if sparse_in:
             if self._order_name is not None:
                 raise NotImplementedError("node reordering needs the dense GSO (it is O(N^3) host work); pass order=None "
@@ -113,8 +119,51 @@ class SelectionGNN(nn.Module):
         self._identity_order = list(self.order) == list(range(len(self.order)))
         self._order_index = None
 
+    def _install_coarsened(self, GSO, sparse_in):
+        """Graclus branch of the constructor / changeGSO (architectures.py:224-247, :393-415): L+1 coarsened GSOs, one
+        per layer input, binary-tree node order, pooling size 2.  False when the GSO has several edge features."""
+        if sparse_in:
+            if isinstance(GSO, SparseGSO):
+                mats = GSO.mats
+            else:
+                mats = [GSO] if sp.issparse(GSO) else list(GSO)
+            if len(mats) != 1:
+                return False
+            W = sp.csr_matrix(mats[0])
+        else:
+            if isinstance(GSO, torch.Tensor):
+                GSO = GSO.detach().cpu().numpy()
+            GSO = np.asarray(GSO)
+            assert len(GSO.shape) == 2 or len(GSO.shape) == 3       # :192
+            if len(GSO.shape) == 3:
+                assert GSO.shape[1] == GSO.shape[2]
+                if GSO.shape[0] != 1:
+                    return False
+                GSO = GSO[0]
+            assert GSO.shape[0] == GSO.shape[1]
+            W = sp.csr_matrix(GSO)
+        self.E = 1
+        graphs, self.order = graphTools.coarsen(W, levels=self.L, self_connections=False)      # :227-228
+        self._gsos = [SparseGSO.from_any(g) for g in graphs]
+        self._gso = self._gsos[0]
+        # reference attribute: list of 1 x N_l x N_l tensors (:232-245); a sparse GSO in stays sparse
+        self.S = self._gsos if sparse_in else [torch.tensor(g.toarray().reshape(1, g.shape[0], g.shape[1])) for g in graphs]
+        self.N = [g.shape[0] for g in graphs]
+        self.alpha = [2] * self.L                                   # :247
+        self._n_real = W.shape[0]
+        self._identity_order = False
+        self._order_index = None
+        return True
+
     def changeGSO(self, GSO, nSelectedNodes=[], poolingSize=[]):
-        """Swap the graph under the same filter taps -- architectures.py:322-420 (selection pooling branch)."""
+        """Swap the graph under the same filter taps -- architectures.py:322-420."""
+        if self.coarsening:
+            # the pooling modules do not depend on the graph, nSelectedNodes / poolingSize are ignored (:357, :364)
+            self._install_gso(GSO)
+            assert self.coarsening, "changeGSO: the model was built with coarsening, the new GSO must have one edge feature"
+            for l in range(self.L):
+                self.GFL[3 * l].addGSO(self._gsos[l])              # :413-415
+            return
         self._install_gso(GSO)
         if len(poolingSize) > 0:
             assert len(poolingSize) == self.L
@@ -135,7 +184,18 @@ class SelectionGNN(nn.Module):
 
     # ---- forward ----------------------------------------------------------------------------------------------
     def splitForward(self, x):
-        if not self._identity_order:
+        if self.coarsening:
+            if self._order_index is None or self._order_index.device != x.device:
+                # fake nodes (index >= number of real nodes) read the zero column appended below
+                idx = np.minimum(np.asarray(self.order, dtype=np.int64), self._n_real)
+                self._order_index = torch.as_tensor(idx, dtype=torch.int64, device=x.device)
+                self._order_plain = torch.as_tensor(np.asarray(self.order, dtype=np.int64), device=x.device)
+            if x.shape[2] != self.N[0]:                             # :429-434 permCoarsening, kept on the device
+                assert x.shape[2] == self._n_real
+                x = torch.cat((x, x.new_zeros(x.shape[0], x.shape[1], 1)), dim=2)[:, :, self._order_index]
+            else:
+                x = x[:, :, self._order_plain]                      # :437
+        elif not self._identity_order:
             if self._order_index is None or self._order_index.device != x.device:
                 self._order_index = torch.as_tensor(self.order, dtype=torch.int64, device=x.device)
             x = x[:, :, self._order_index]                          # :437

@@ -3,8 +3,11 @@
 Mirrors the parts of the reference's alegnn/utils/graphTools.py that SelectionGNN touches:
   permIdentity / permDegree / permSpectralProxies / permEDS   (graphTools.py:990-1161)   node orderings
   computeNeighborhood                                         (graphTools.py:378-527)    K-hop neighbourhoods for MaxPoolLocal
-re-written on sparse boolean reachability instead of Python list BFS.  Everything else in that file (graph
-generation, GFT, Graclus coarsening, plotting) is outside the hot path.
+  coarsen / metis / metis_one_level / compute_perm / perm_adjacency / permCoarsening
+                                                              (graphTools.py:1337-1614)  Graclus multilevel coarsening
+re-written on sparse boolean reachability instead of Python list BFS, and on CSR segments instead of per-entry Python
+loops.  Everything else in that file (graph generation, GFT, plotting) is outside the hot path (SURVEY.md section 2,
+item 17).
 """
 from __future__ import annotations
 
@@ -118,3 +121,145 @@ def computeNeighborhood(S, K, N='all', nb='all', outputType='list'):
             out[i, len(v):] = i
         return out
     return neighbors
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Graclus multilevel coarsening (SelectionGNN(coarsening=True)), graphTools.py:1337-1614
+# ---------------------------------------------------------------------------------------------------------------
+def metis_one_level(rr, cc, vv, rid, weights):
+    """One greedy Graclus pairing pass -- graphTools.py:1453-1499.
+
+    ``rr`` (sorted), ``cc``, ``vv``: the graph's entries by row; ``rid``: visiting order; ``weights``: node degrees.
+    Every unmarked node, in visiting order, is merged with the unmarked neighbour that maximises
+    w_ij (1/d_i + 1/d_j) (strictly positive, first maximum wins) or stays alone.  Returns cluster_id[N].
+
+    The reference's row bookkeeping (:1467-1472) is reproduced as is, because it decides the clusters: row lengths are
+    accumulated one entry late, so the first row's candidate list also holds the first entry of the second row and
+    the last row's list misses its last entry; rows are numbered by order of appearance in ``rr`` (a node without
+    entries shifts the numbering of the rows after it)."""
+    rr = np.asarray(rr)
+    nnz = rr.shape[0]
+    N = int(rr[nnz - 1]) + 1
+    first = np.flatnonzero(np.concatenate(([True], rr[1:] != rr[:-1])))     # first entry of every row present
+    m = first.shape[0]
+    rowstart = np.zeros(N, dtype=np.int64)
+    rowlength = np.zeros(N, dtype=np.int64)
+    rowstart[:m] = first
+    rowlength[:m] = np.diff(np.concatenate((first, [nnz])))
+    if m > 1:
+        rowlength[0] += 1
+        rowlength[m - 1] -= 1
+    inv = 1.0 / np.asarray(weights, dtype=np.float64)
+    marked = np.zeros(N, dtype=bool)
+    cluster_id = np.zeros(N, dtype=np.int32)
+    clusters = 0
+    for t in (int(v) for v in rid[:N]):
+        if marked[t]:
+            continue
+        marked[t] = True
+        seg = slice(rowstart[t], rowstart[t] + rowlength[t])
+        nb = cc[seg]
+        score = np.where(marked[nb], 0.0, vv[seg] * (inv[t] + inv[nb]))
+        score = np.where(np.isnan(score), 0.0, score)                       # "nan > wmax" is False in the reference loop
+        cluster_id[t] = clusters
+        if score.shape[0] > 0:
+            j = int(np.argmax(score))
+            if score[j] > 0.0:
+                cluster_id[nb[j]] = clusters
+                marked[nb[j]] = True
+        clusters += 1
+    return cluster_id
+
+
+def metis(W, levels, rid=None):
+    """``levels`` successive pairings of a symmetric sparse W -- graphTools.py:1369-1450.
+    Returns (graphs[levels+1], parents[levels]); parents[i][n] = cluster of node n of graphs[i] in graphs[i+1].
+    The first visiting order is ``np.random.permutation(range(N))`` (seed numpy's global RNG for reproducibility),
+    later ones sort the coarse nodes by degree."""
+    N = W.shape[0]
+    if rid is None:
+        rid = np.random.permutation(range(N))
+    degree = W.sum(axis=0) - W.diagonal()                                   # self loops left out at the finest level only
+    graphs, parents = [W], []
+    for _ in range(levels):
+        weights = np.array(degree).squeeze()
+        rows, cols, vals = sp.find(W)
+        by_row = np.argsort(rows)                                           # same (unstable) sort as :1413: it fixes tie order
+        rr, cc, vv = rows[by_row], cols[by_row], vals[by_row]
+        cluster_id = metis_one_level(rr, cc, vv, rid, weights)
+        parents.append(cluster_id)
+        Nc = int(cluster_id.max()) + 1
+        W = sp.csr_matrix((vv, (cluster_id[rr], cluster_id[cc])), shape=(Nc, Nc))   # duplicates add up
+        W.eliminate_zeros()
+        graphs.append(W)
+        degree = W.sum(axis=0)
+        rid = np.argsort(np.array(degree).squeeze())
+    return graphs, parents
+
+
+def compute_perm(parents):
+    """Node orderings, finest level first, under which clusters are consecutive pairs (a binary tree) --
+    graphTools.py:1501-1547.  Single nodes get a fake sibling, fake nodes two fake children; fake ids start at the
+    level's real node count."""
+    if len(parents) == 0:
+        return []
+    layers = [list(range(int(max(parents[-1])) + 1))]
+    for parent in parents[::-1]:
+        parent = np.asarray(parent)
+        by_cluster = np.argsort(parent, kind="stable")                      # children of a cluster in increasing id
+        lo = np.searchsorted(parent[by_cluster], np.arange(len(layers[-1]) + 1))
+        fake = len(parent)
+        layer = []
+        for i in layers[-1]:
+            pair = [int(c) for c in by_cluster[lo[i]:lo[i + 1]]] if i < len(lo) - 1 else []
+            assert len(pair) <= 2
+            while len(pair) < 2:
+                pair.append(fake)
+                fake += 1
+            layer.extend(pair)
+        layers.append(layer)
+    for i, layer in enumerate(layers):
+        assert sorted(layer) == list(range(len(layers[0]) * 2 ** i))
+    return layers[::-1]
+
+
+def perm_adjacency(A, indices):
+    """Append len(indices) - M isolated nodes to A and renumber node ``indices[i]`` as ``i`` -- graphTools.py:1549-1579."""
+    if indices is None:
+        return A
+    A = sp.coo_matrix(A)
+    M, Mnew = A.shape[0], len(indices)
+    assert Mnew >= M
+    rank = np.argsort(indices)
+    return sp.coo_matrix((A.data, (rank[A.row], rank[A.col])), shape=(Mnew, Mnew))
+
+
+def coarsen(A, levels, self_connections=False):
+    """Multilevel Graclus coarsening -- graphTools.py:1337-1367.
+    Returns (graphs, perm): levels+1 CSR matrices, each but the coarsest padded with fake nodes and reordered so that
+    pooling pairs of consecutive nodes walks the cluster tree; perm = the ordering of the finest level (entries >= N
+    are fake nodes), or None when levels == 0."""
+    graphs, parents = metis(A, levels)
+    perms = compute_perm(parents)
+    for i, g in enumerate(graphs):
+        g = sp.coo_matrix(g)
+        if not self_connections:
+            g.setdiag(0)
+        if i < levels:
+            g = perm_adjacency(g, perms[i])
+        g = sp.csr_matrix(g)
+        g.eliminate_zeros()
+        graphs[i] = g
+    return graphs, (perms[0] if levels > 0 else None)
+
+
+def permCoarsening(x, indices):
+    """Reorder the node axis of x [B, F, N] by ``indices``; fake nodes (index >= N) are zero signals, so that max
+    pooling keeps their real sibling -- graphTools.py:1581-1614.  numpy in, numpy out (x's dtype is kept)."""
+    if indices is None:
+        return x
+    B, F, N = x.shape
+    idx = np.asarray(indices, dtype=np.int64)
+    assert idx.shape[0] >= N
+    padded = np.concatenate((x, np.zeros((B, F, 1), dtype=x.dtype)), axis=2)
+    return padded[:, :, np.minimum(idx, N)]

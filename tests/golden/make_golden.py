@@ -101,6 +101,50 @@ def selection_gnn_case(name, S2d, dimNodeSignals, nFilterTaps, nSelectedNodes, p
     print(f"selgnn_{name}: N={N} y{tuple(y.shape)} ygnn{tuple(ygnn.shape)} keys={[k for k in out if k.startswith('sd:')]}")
 
 
+def selection_gnn_coarsen_case(name, S2d, dimNodeSignals, nFilterTaps, dimLayersMLP, B, seed=0):
+    """SelectionGNN(coarsening=True) with nn.MaxPool1d (architectures.py:224-247) + the Graclus outputs themselves.
+    graphTools.py:1458 still says np.bool (removed in numpy 1.24): aliased here for the duration of the call only."""
+    rng = np.random.RandomState(seed)
+    L = len(nFilterTaps)
+    np.bool = bool
+    try:
+        np.random.seed(seed)                                     # metis draws the first visiting order (graphTools.py:1393)
+        graphs, perm = gt.coarsen(scipy.sparse.csr_matrix(S2d), levels=L, self_connections=False)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        net = archit.SelectionGNN(dimNodeSignals, nFilterTaps, True, torch.nn.ReLU, [0] * L, torch.nn.MaxPool1d, [2] * L,
+                                  dimLayersMLP, S2d, coarsening=True)
+    finally:
+        del np.bool
+    assert [int(v) for v in net.order] == [int(v) for v in perm]
+    N = S2d.shape[0]
+    x = rng.randn(B, dimNodeSignals[0], N)
+    # With fake nodes the reference pads through numpy (architectures.py:429-434), which cannot carry a gradient; feeding
+    # the signal already zero-padded to N[0] nodes takes the differentiable branch (:437) and is the same computation.
+    xt = torch.tensor(np.concatenate((x, np.zeros((B, dimNodeSignals[0], net.N[0] - N))), axis=2), requires_grad=True)
+    y, ygnn = net.splitForward(xt)
+    if net.N[0] != N:
+        with torch.no_grad():
+            y_np, _ = net.splitForward(torch.tensor(x))
+        assert torch.equal(y_np, y.detach())
+    w = rng.randn(*y.shape)
+    (y * torch.tensor(w)).sum().backward()
+    out = dict(x=x, w=w, y=y.detach().numpy(), ygnn=ygnn.detach().numpy(), dx=xt.grad.numpy()[:, :, :N], seed=np.array(seed),
+               perm=np.array([int(v) for v in perm]), **coo(S2d[None]))
+    for l, g in enumerate(graphs):
+        g = g.tocoo()
+        out[f"graph{l}_r"], out[f"graph{l}_c"], out[f"graph{l}_v"] = g.row.astype(np.int32), g.col.astype(np.int32), g.data
+        out[f"graph{l}_n"] = np.array(g.shape[0])
+    for k, v in net.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    cfg = dict(dimNodeSignals=dimNodeSignals, nFilterTaps=nFilterTaps, dimLayersMLP=dimLayersMLP)
+    out["cfg"] = np.array(repr(cfg))
+    np.savez_compressed(os.path.join(HERE, f"selgnn_coarsen_{name}.npz"), **out)
+    print(f"selgnn_coarsen_{name}: N={net.N} y{tuple(y.shape)} ygnn{tuple(ygnn.shape)}")
+
+
 def evgf_case(name, S, B, G, F, K, M, Nin=None, bias=True, seed=0):
     """EdgeVariantGF forward + autograd (graphML.py:2511-2712): full EV (M = N), hybrid (M < N, LSI part + the bias
     counted twice), Nin < N zero-padding.  The dense weightEV [F,E,K,G,N,N] is stored masked (off-pattern entries are
@@ -150,6 +194,11 @@ def main():
     G.computeGFT()
     sbm = (G.S / np.max(np.real(G.E)))                                   # sourceLocGNN.py:752
 
+    if "--coarsen-only" in sys.argv:
+        # SelectionGNN with Graclus coarsening + MaxPool1d (the reference's third pooling mode, architectures.py:224-247)
+        selection_gnn_coarsen_case("sbm100_L2", sbm, [1, 8, 16], [3, 4], [5], B=4, seed=3)       # 100 -> 104/52/26: fake nodes
+        selection_gnn_coarsen_case("fbego_L3", fb[0], [2, 8, 8, 16], [3, 3, 2], [4], B=3, seed=1)
+        return
     # ---- graphTools pieces SelectionGNN depends on (orderings, MaxPoolLocal neighbourhoods) -------------------
     gt_out = dict(S=sbm)
     for (K, N, nb) in [(6, 10, 100), (8, 10, 10), (1, 100, 100), (0, 5, 100), (2, 37, 20)]:
@@ -175,6 +224,8 @@ def main():
     evgf_case("sbm100_hybrid", sbm[None], B=4, G=4, F=4, K=3, M=30)
     if "--evgf-only" in sys.argv:
         return
+    selection_gnn_coarsen_case("sbm100_L2", sbm, [1, 8, 16], [3, 4], [5], B=4, seed=3)
+    selection_gnn_coarsen_case("fbego_L3", fb[0], [2, 8, 8, 16], [3, 3, 2], [4], B=3, seed=1)
     # ---- LSIGF -----------------------------------------------------------------------------
     lsigf_case("ring_dir", ring, B=2, G=2, F=3, K=3)
     lsigf_case("asym_E2", asym, B=3, G=3, F=5, K=4)

@@ -232,6 +232,33 @@ def test_selection_gnn_matches_reference(name):
         assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
 
 
+@pytest.mark.parametrize("name", ["sbm100_L2", "fbego_L3"])
+@pytest.mark.parametrize("sparse", [False, True], ids=["denseGSO", "sparseGSO"])
+def test_selection_gnn_coarsening_matches_reference(name, sparse):
+    """SelectionGNN(coarsening=True) + nn.MaxPool1d (architectures.py:224-247): Graclus graphs with fake nodes, one GSO
+    per layer, the reference's weights.  x has the real nodes only, so the fake-node padding path (:429-434) runs."""
+    d = load(os.path.join(GOLDEN, f"selgnn_coarsen_{name}.npz"))
+    cfg, S = d["cfg"], d["S"][0]
+    L = len(cfg["nFilterTaps"])
+    np.random.seed(int(d["seed"]))
+    net = SelectionGNN(cfg["dimNodeSignals"], cfg["nFilterTaps"], True, torch.nn.ReLU, [0] * L, torch.nn.MaxPool1d,
+                       [2] * L, cfg["dimLayersMLP"], sp.csr_matrix(S) if sparse else S, coarsening=True)
+    assert [int(v) for v in net.order] == d["perm"].tolist()
+    net.load_state_dict({k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")})
+    net = net.float().to(DEV)
+    x = cu(d["x"], True)
+    y, ygnn = net.splitForward(x)
+    (y * cu(d["w"])).sum().backward()
+    assert relerr(ygnn.detach().cpu().numpy(), d["ygnn"]) < FWD_RTOL
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < 5 * FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    for k, p in net.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
+    # already padded input takes the plain reordering branch (:437) and gives the same output
+    xp = torch.cat((x.detach(), x.new_zeros(x.shape[0], x.shape[1], net.N[0] - x.shape[2])), dim=2)
+    assert torch.equal(net(xp), y.detach())
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # seeded random inputs vs the CPU oracle (sparse restatement), sizes the oracle finishes in seconds
 # ---------------------------------------------------------------------------------------------------------------

@@ -179,14 +179,66 @@ def test_selection_gnn_ctor_options():
     g = dict(np.load(os.path.join(GOLDEN, "graphtools_sbm100.npz")))
     assert list(net.order) == list(g["order_Degree"])                           # the reference's NameError path, fixed
     assert np.array_equal(net.S.numpy()[0], g["S_Degree"])          # S is kept E x N x N (architectures.py:195)
-    with pytest.raises(NotImplementedError):
-        SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [10], gml.NoPool, [1], [], S, coarsening=True)
     with pytest.raises(AssertionError):
         SelectionGNN([1, 8, 8], [3], True, torch.nn.ReLU, [10], gml.NoPool, [1], [], S)
     sparse_net = SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [100], gml.NoPool, [1], [], sp.csr_matrix(S))
     assert sparse_net.E == 1 and sparse_net.N == [100, 100] and len(sparse_net.MLP) == 0
     sparse_net.changeGSO(sp.csr_matrix(S[:50, :50]), nSelectedNodes=[50])
     assert sparse_net.N == [50, 50] and sparse_net.GFL[0].N == 50
+
+
+@pytest.mark.parametrize("name", ["sbm100_L2", "fbego_L3"])
+def test_graclus_coarsening_matches_reference(name):
+    """coarsen() against the reference's own outputs (graphs level by level, fake nodes, node order), and the
+    SelectionGNN(coarsening=True) bookkeeping built on it (architectures.py:224-247, :282-290)."""
+    d = load(os.path.join(GOLDEN, f"selgnn_coarsen_{name}.npz"))
+    cfg, S = d["cfg"], d["S"][0]
+    L = len(cfg["nFilterTaps"])
+    np.random.seed(int(d["seed"]))
+    graphs, perm = gt.coarsen(sp.csr_matrix(S), levels=L, self_connections=False)
+    assert [int(v) for v in perm] == d["perm"].tolist()
+    for l, g in enumerate(graphs):
+        n = int(d[f"graph{l}_n"])
+        want = sp.coo_matrix((d[f"graph{l}_v"], (d[f"graph{l}_r"], d[f"graph{l}_c"])), shape=(n, n)).toarray()
+        assert g.shape == (n, n) and np.array_equal(g.toarray(), want)
+    x = np.random.RandomState(0).randn(2, 3, S.shape[0]).astype(np.float32)
+    xp = gt.permCoarsening(x, perm)
+    assert xp.dtype == np.float32 and xp.shape[2] == len(perm)
+    for i, j in enumerate(perm):
+        assert np.array_equal(xp[:, :, i], x[:, :, j] if j < S.shape[0] else np.zeros((2, 3), np.float32))
+
+    def build(gso):
+        np.random.seed(int(d["seed"]))
+        return SelectionGNN(cfg["dimNodeSignals"], cfg["nFilterTaps"], True, torch.nn.ReLU, [0] * L, torch.nn.MaxPool1d,
+                            [7] * L, cfg["dimLayersMLP"], gso, order="Degree", coarsening=True)   # order / alpha are overridden
+    for net in (build(S), build(sp.csr_matrix(S))):
+        assert net.coarsening and net.alpha == [2] * L and net.E == 1
+        assert net.N == [int(d[f"graph{l}_n"]) for l in range(L + 1)]
+        assert [int(v) for v in net.order] == d["perm"].tolist()
+        for l in range(L):
+            assert isinstance(net.GFL[3 * l + 2], torch.nn.MaxPool1d) and net.GFL[3 * l].N == net.N[l]
+        ref_sd = {k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")}
+        assert list(net.state_dict().keys()) == list(ref_sd.keys())
+        net.load_state_dict(ref_sd, strict=True)
+    dense = build(S)
+    assert [tuple(t.shape) for t in dense.S] == [(1, n, n) for n in dense.N]       # reference attribute (:232-245)
+    two = SelectionGNN([1, 4], [2], True, torch.nn.ReLU, [10], gml.NoPool, [1], [], np.stack([S, S]), coarsening=True)
+    assert not two.coarsening and two.N == [S.shape[0], 10]                      # E = 2 falls back to selection (:224, :257)
+    np.random.seed(0)
+    dense.changeGSO(S[:60, :60])
+    assert dense.N[0] >= 60 and dense.GFL[0].N == dense.N[0] and dense.GFL[3].N == dense.N[1]
+
+
+def test_graclus_edge_cases():
+    g, perm = gt.coarsen(sp.csr_matrix(np.ones((4, 4)) - np.eye(4)), levels=0)
+    assert perm is None and len(g) == 1 and g[0].nnz == 12
+    path = sp.diags([np.ones(6), np.ones(6)], [1, -1]).tocsr()                   # 7-node path: odd count forces a fake node
+    np.random.seed(0)
+    g, perm = gt.coarsen(path, levels=2)
+    assert g[0].shape[0] == 2 * g[1].shape[0] == 4 * g[2].shape[0] and sorted(perm) == list(range(g[0].shape[0]))
+    assert g[0].shape[0] >= 8 and all(abs(m - m.T).nnz == 0 for m in g)
+    assert gt.compute_perm([]) == []
+    assert gt.compute_perm([np.array([0, 1, 0, 2])]) == [[0, 2, 1, 4, 3, 5], [0, 1, 2]]
 
 
 def test_max_pool_local_semantics():
