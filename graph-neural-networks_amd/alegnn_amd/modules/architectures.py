@@ -44,6 +44,22 @@ class SelectionGNN(nn.Module):
                  # Coarsening
                  coarsening=False):
         super().__init__()
+        self._build_filters(dimNodeSignals, nFilterTaps, bias, nonlinearity, nSelectedNodes, poolingFunction, poolingSize,
+                            GSO, order, coarsening)
+        self.dimLayersMLP = dimLayersMLP
+
+        fc = []
+        if len(self.dimLayersMLP) > 0:                              # :299-317
+            fc.append(nn.Linear(self.N[-1] * self.F[-1], dimLayersMLP[0], bias=self.bias))
+            for l in range(len(dimLayersMLP) - 1):
+                fc.append(self.sigma())
+                fc.append(nn.Linear(dimLayersMLP[l], dimLayersMLP[l + 1], bias=self.bias))
+        self.MLP = nn.Sequential(*fc)
+
+    def _build_filters(self, dimNodeSignals, nFilterTaps, bias, nonlinearity, nSelectedNodes, poolingFunction, poolingSize,
+                       GSO, order, coarsening):
+        """The part every GraphFilter-stack architecture shares (architectures.py:184-295, :941-1008): argument checks,
+        GSO ingest / ordering, and GFL = [GraphFilter, sigma, rho] x L."""
         assert len(dimNodeSignals) == len(nFilterTaps) + 1         # architectures.py:184
         assert len(nSelectedNodes) == len(nFilterTaps)              # :187
         assert len(poolingSize) == len(nFilterTaps)                 # :189
@@ -53,7 +69,6 @@ class SelectionGNN(nn.Module):
         self.bias = bias
         self.sigma = nonlinearity
         self.rho = poolingFunction
-        self.dimLayersMLP = dimLayersMLP
         self.coarsening = bool(coarsening)
         self.alpha = poolingSize
         self._order_name = order
@@ -76,14 +91,6 @@ class SelectionGNN(nn.Module):
                 gfl.append(self.rho(self.N[l], self.N[l + 1], self.alpha[l]))                    # :292
                 gfl[3 * l + 2].addGSO(self._gso)
         self.GFL = nn.Sequential(*gfl)
-
-        fc = []
-        if len(self.dimLayersMLP) > 0:                              # :299-317
-            fc.append(nn.Linear(self.N[-1] * self.F[-1], dimLayersMLP[0], bias=self.bias))
-            for l in range(len(dimLayersMLP) - 1):
-                fc.append(self.sigma())
-                fc.append(nn.Linear(dimLayersMLP[l], dimLayersMLP[l + 1], bias=self.bias))
-        self.MLP = nn.Sequential(*fc)
 
     # ---- GSO handling -----------------------------------------------------------------------------------------
     def _install_gso(self, GSO):
@@ -183,7 +190,8 @@ class SelectionGNN(nn.Module):
             self.GFL[3 * l].addGSO(self._gso)
 
     # ---- forward ----------------------------------------------------------------------------------------------
-    def splitForward(self, x):
+    def _reorder(self, x):
+        """x[:, :, order] (architectures.py:437), skipped for the identity; with coarsening also the fake-node padding."""
         if self.coarsening:
             if self._order_index is None or self._order_index.device != x.device:
                 # fake nodes (index >= number of real nodes) read the zero column appended below
@@ -199,6 +207,10 @@ class SelectionGNN(nn.Module):
             if self._order_index is None or self._order_index.device != x.device:
                 self._order_index = torch.as_tensor(self.order, dtype=torch.int64, device=x.device)
             x = x[:, :, self._order_index]                          # :437
+        return x
+
+    def splitForward(self, x):
+        x = self._reorder(x)
         assert len(x.shape) == 3                                    # :440-443
         batchSize = x.shape[0]
         assert x.shape[1] == self.F[0]
@@ -215,3 +227,58 @@ class SelectionGNN(nn.Module):
         # The reference moves S and re-adds it to every layer (architectures.py:463-479); here the GSO lives on the host
         # as CSR and device plans are created on first use per device, so only parameters / buffers move.
         return super().to(*args, **kwargs)
+
+
+class LocalGNN(SelectionGNN):
+    """Graph filter stack with a per-node readout -- architectures.py:816-1182.  Same constructor, same sub-module names
+    (``GFL``, ``Readout``) and state_dict keys as the reference; GSO handling, ``changeGSO`` and the fused ReLU are
+    SelectionGNN's.  Output: B x dimReadout[-1] x N[-1]."""
+
+    def __init__(self,
+                 # Graph filtering
+                 dimNodeSignals, nFilterTaps, bias,
+                 # Nonlinearity
+                 nonlinearity,
+                 # Pooling
+                 nSelectedNodes, poolingFunction, poolingSize,
+                 # MLP in the end
+                 dimReadout,
+                 # Structure
+                 GSO, order=None):
+        nn.Module.__init__(self)
+        self._build_filters(dimNodeSignals, nFilterTaps, bias, nonlinearity, nSelectedNodes, poolingFunction, poolingSize,
+                            GSO, order, False)
+        self.dimReadout = dimReadout
+        fc = []
+        if len(self.dimReadout) > 0:                                # :1011-1023: F[-1] -> dimReadout, applied node by node
+            fc.append(nn.Linear(self.F[-1], dimReadout[0], bias=self.bias))
+            for l in range(len(dimReadout) - 1):
+                fc.append(self.sigma())
+                fc.append(nn.Linear(dimReadout[l], dimReadout[l + 1], bias=self.bias))
+        self.Readout = nn.Sequential(*fc)
+
+    def splitForward(self, x):
+        assert len(x.shape) == 3                                    # :1093-1095
+        assert x.shape[1] == self.F[0]
+        assert x.shape[2] == self.N[0]
+        x = self._reorder(x)                                        # :1097
+        yGFL = self.GFL(x)                                          # :1099
+        y = self.Readout(yGFL.permute(0, 2, 1))                     # :1101-1102  B x N[-1] x dimReadout[-1]
+        return y.permute(0, 2, 1), yGFL
+
+    def singleNodeForward(self, x, nodes):
+        """Output at one node per sample (MovieLens rating prediction, architectures.py:1117-1170).  ``nodes``: an int
+        (same node for the whole batch), or a list / array of B node ids in the ORIGINAL numbering.  B x dimReadout[-1].
+        The reference multiplies by a one-hot B x N[-1] x 1 matrix (:1160-1168); this is the same selection as a gather."""
+        batchSize = x.shape[0]
+        assert type(nodes) is int or type(nodes) is list or type(nodes) is np.ndarray      # :1132-1134
+        position = np.empty(len(self.order), dtype=np.int64)
+        position[np.asarray(self.order, dtype=np.int64)] = np.arange(len(self.order))       # where each node sits after ordering
+        if type(nodes) is int:
+            nodes = np.full(batchSize, position[nodes], dtype=np.int64)
+        else:
+            nodes = position[np.asarray(nodes, dtype=np.int64)]
+        assert nodes.shape[0] == batchSize and int(nodes.max()) < self.N[-1]
+        y = self.forward(x)                                         # B x R x N[-1]
+        idx = torch.as_tensor(nodes, device=y.device).view(batchSize, 1, 1).expand(batchSize, y.shape[1], 1)
+        return torch.gather(y, 2, idx).squeeze(2)

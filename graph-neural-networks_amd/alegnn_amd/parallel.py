@@ -27,13 +27,15 @@ class GradBucket:
     (use ``bucket.zero_()`` instead of ``zero_grad(set_to_none=True)`` so the views stay attached).
     """
 
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, extra=0):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.device == dev and p.dtype == dt for p in self.params), "one device / dtype per bucket"
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        # ``extra`` trailing slots ride in the same collective (the trainer's per-step loss / cost scalars)
+        self.flat = torch.zeros(self.numel + extra, dtype=dt, device=dev)
+        self.extra = self.flat[self.numel:]
         self.group = process_group
         off = 0
         for p in self.params:

@@ -38,3 +38,25 @@ def relerr(a, ref):
 
 def case_id(path):
     return os.path.splitext(os.path.basename(path))[0]
+
+
+class ArrayData:
+    """Minimal data object with the interface the trainers use (reference dataTools.py:172-219, :321-341): samples held
+    as tensors, ``getSamples(split[, indices])``, ``evaluate`` = classification error rate.  Built from a trainer_*.npz."""
+
+    def __init__(self, d, dtype):
+        import torch
+        self.samples = {s: (torch.tensor(d["x_" + s]).to(dtype), torch.tensor(d["y_" + s])) for s in ("train", "valid", "test")}
+        self.nTrain = self.samples["train"][0].shape[0]
+        self.dtype = dtype
+
+    def getSamples(self, samplesType, *args):
+        x, y = self.samples[samplesType]
+        if len(args) == 1:
+            x, y = x[args[0]], y[args[0]]
+        return x, y
+
+    def evaluate(self, yHat, y, tol=1e-9):
+        import torch
+        wrong = torch.sum(torch.abs(torch.argmax(yHat, dim=1) - y) > tol)
+        return wrong.to(self.dtype) / len(y)

@@ -145,6 +145,93 @@ def selection_gnn_coarsen_case(name, S2d, dimNodeSignals, nFilterTaps, dimLayers
     print(f"selgnn_coarsen_{name}: N={net.N} y{tuple(y.shape)} ygnn{tuple(ygnn.shape)}")
 
 
+def local_gnn_case(name, S2d, dimNodeSignals, nFilterTaps, nSelectedNodes, pool, poolingSize, dimReadout, B, seed=0):
+    """LocalGNN forward / backward and singleNodeForward (architectures.py:816-1170), the MovieLens recipe's architecture."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    N = S2d.shape[0]
+    net = archit.LocalGNN(dimNodeSignals, nFilterTaps, True, torch.nn.ReLU, nSelectedNodes, getattr(gml, pool), poolingSize,
+                          dimReadout, S2d)
+    x = rng.randn(B, dimNodeSignals[0], N)
+    nodes = rng.randint(0, nSelectedNodes[-1], size=B)
+    xt = torch.tensor(x, requires_grad=True)
+    y, ygnn = net.splitForward(xt)
+    ysn = net.singleNodeForward(xt, [int(n) for n in nodes])
+    w = rng.randn(*ysn.shape)
+    (ysn * torch.tensor(w)).sum().backward()
+    out = dict(x=x, w=w, nodes=nodes, y=y.detach().numpy(), ygnn=ygnn.detach().numpy(), ysn=ysn.detach().numpy(),
+               dx=xt.grad.numpy(), **coo(S2d[None]))
+    for k, v in net.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    cfg = dict(dimNodeSignals=dimNodeSignals, nFilterTaps=nFilterTaps, nSelectedNodes=nSelectedNodes, pool=pool,
+               poolingSize=poolingSize, dimReadout=dimReadout)
+    out["cfg"] = np.array(repr(cfg))
+    np.savez_compressed(os.path.join(HERE, f"localgnn_{name}.npz"), **out)
+    print(f"localgnn_{name}: N={N} y{tuple(y.shape)} ysn{tuple(ysn.shape)}")
+
+
+def trainer_case(name, G, S2d, archit_fn, nEpochs, batchSize, seed, **trainKw):
+    """The reference's Model + Trainer + evaluate (model.py, training.py:29-578, evaluation.py:18-89) on SourceLocalization
+    data: the loss / cost trajectories, the 'Best' and 'Last' checkpoints and the evaluation result.  The checkpoint files
+    written by the reference's Model.save are kept as they are under tests/golden/ckpt/ (checkpoint compatibility)."""
+    import shutil
+    import tempfile
+    import alegnn.utils.dataTools as dataTools
+    import alegnn.modules.model as refmodel
+    import alegnn.modules.training as reftraining
+    import alegnn.modules.evaluation as refevaluation
+    import alegnn.modules.loss as refloss
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    nClasses = 5
+    sourceNodes = gt.computeSourceNodes(G.A, nClasses)
+    data = dataTools.SourceLocalization(G, 96, 32, 32, sourceNodes, tMax=25)          # sourceLocGNN.py:677-681
+    data.astype(torch.float64)
+    data.expandDims()
+    archit = archit_fn(S2d, nClasses)
+    init = {k: v.clone() for k, v in archit.state_dict().items()}
+    optim = torch.optim.Adam(archit.parameters(), lr=0.005, betas=(0.9, 0.999))       # sourceLocGNN.py:154-156
+    loss = refloss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss)
+    tmp = tempfile.mkdtemp()
+    model = refmodel.Model(archit, loss, optim, reftraining.Trainer, refevaluation.evaluate, 'cpu', name, tmp)
+    np.random.seed(seed + 1)                                        # the epoch permutations (training.py:379)
+    trainVars = model.train(data, nEpochs, batchSize, doSaveVars=False, printInterval=0, **trainKw)
+    evalVars = model.evaluate(data, doSaveVars=False)
+    out = dict(seed=np.array(seed), nEpochs=np.array(nEpochs), batchSize=np.array(batchSize),
+               trainKw=np.array(repr(trainKw)), **coo(S2d[None]))
+    for split in ("train", "valid", "test"):
+        x, y = data.getSamples(split)
+        out[f"x_{split}"], out[f"y_{split}"] = x.numpy(), y.numpy()
+    for k in ("lossTrain", "costTrain", "lossValid", "costValid"):
+        out[k] = np.asarray(trainVars[k])
+    out["costBest"], out["costLast"] = np.array(evalVars["costBest"]), np.array(evalVars["costLast"])
+    for k, v in init.items():
+        out["init:" + k] = v.numpy()
+    ckpt = os.path.join(HERE, "ckpt")
+    os.makedirs(ckpt, exist_ok=True)
+    for f in sorted(os.listdir(os.path.join(tmp, "savedModels"))):
+        shutil.copy(os.path.join(tmp, "savedModels", f), os.path.join(ckpt, f))
+    shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(HERE, f"trainer_{name}.npz"), **out)
+    print(f"trainer_{name}: steps={len(out['lossTrain'])} lossTrain[0,-1]={out['lossTrain'][0]:.4f},{out['lossTrain'][-1]:.4f} "
+          f"costValid={out['costValid']} eval={evalVars}")
+
+
+def trainer_cases(G, sbm):
+    def selgnn(S, nClasses):                                        # config-1 architecture, narrower (sourceLocGNN.py:243-260)
+        return archit.SelectionGNN([1, 8, 8], [3, 3], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2],
+                                   [nClasses], S)
+
+    def mlp(S, nClasses):                                           # graph-free: pins the Trainer logic on the CPU
+        return torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(S.shape[0], 16), torch.nn.Tanh(),
+                                   torch.nn.Linear(16, nClasses))
+    trainer_case("selgnn", G, sbm, selgnn, nEpochs=3, batchSize=32, seed=7, validationInterval=2)
+    trainer_case("mlp", G, sbm, mlp, nEpochs=6, batchSize=40, seed=8, validationInterval=1, earlyStoppingLag=3,
+                 learningRateDecayRate=0.5, learningRateDecayPeriod=2)
+
+
 def evgf_case(name, S, B, G, F, K, M, Nin=None, bias=True, seed=0):
     """EdgeVariantGF forward + autograd (graphML.py:2511-2712): full EV (M = N), hybrid (M < N, LSI part + the bias
     counted twice), Nin < N zero-padding.  The dense weightEV [F,E,K,G,N,N] is stored masked (off-pattern entries are
@@ -194,6 +281,11 @@ def main():
     G.computeGFT()
     sbm = (G.S / np.max(np.real(G.E)))                                   # sourceLocGNN.py:752
 
+    if "--trainer-only" in sys.argv:
+        trainer_cases(G, sbm)
+        local_gnn_case("fbego_movie", fb[0], [1, 64, 32], [5, 5], [234, 234], "NoPool", [1, 1], [1], B=5)
+        local_gnn_case("sbm100_pool", sbm, [2, 8, 8], [3, 3], [30, 12], "MaxPoolLocal", [2, 3], [6, 3], B=4, seed=2)
+        return
     if "--coarsen-only" in sys.argv:
         # SelectionGNN with Graclus coarsening + MaxPool1d (the reference's third pooling mode, architectures.py:224-247)
         selection_gnn_coarsen_case("sbm100_L2", sbm, [1, 8, 16], [3, 4], [5], B=4, seed=3)       # 100 -> 104/52/26: fake nodes

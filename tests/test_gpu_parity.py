@@ -259,6 +259,61 @@ def test_selection_gnn_coarsening_matches_reference(name, sparse):
     assert torch.equal(net(xp), y.detach())
 
 
+@pytest.mark.parametrize("name", ["fbego_movie", "sbm100_pool"])
+def test_local_gnn_matches_reference(name):
+    """LocalGNN (architectures.py:816-1170): per-node readout and singleNodeForward (the MovieLens recipe, configs[2]),
+    with the reference's weights; gradients flow from the single-node outputs."""
+    from alegnn_amd.modules.architectures import LocalGNN
+    d = load(os.path.join(GOLDEN, f"localgnn_{name}.npz"))
+    cfg = d["cfg"]
+    net = LocalGNN(cfg["dimNodeSignals"], cfg["nFilterTaps"], True, torch.nn.ReLU, cfg["nSelectedNodes"],
+                   getattr(gml, cfg["pool"]), cfg["poolingSize"], cfg["dimReadout"], d["S"][0])
+    net.load_state_dict({k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")})
+    net = net.float().to(DEV)
+    x = cu(d["x"], True)
+    y, ygnn = net.splitForward(x)
+    assert relerr(ygnn.detach().cpu().numpy(), d["ygnn"]) < FWD_RTOL
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < 5 * FWD_RTOL
+    ysn = net.singleNodeForward(x, [int(n) for n in d["nodes"]])
+    assert relerr(ysn.detach().cpu().numpy(), d["ysn"]) < 5 * FWD_RTOL
+    assert torch.equal(net.singleNodeForward(x, d["nodes"]), ysn)                     # ndarray form (:1150-1154)
+    same = net.singleNodeForward(x, int(d["nodes"][0]))                                # int form: one node for the batch
+    assert torch.equal(same[0], ysn[0])
+    (ysn * cu(d["w"])).sum().backward()
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    for k, p in net.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
+
+
+def test_trainer_on_gpu_follows_reference_training_run(tmp_path):
+    """Model + Trainer + evaluate driving the HIP SelectionGNN for the reference's 3-epoch run on SourceLocalization data
+    (tests/golden/make_golden.py trainer_case 'selgnn'; reference on CPU in float64, here float32 on the GPU)."""
+    import ast
+    from _util import ArrayData
+    from alegnn_amd.modules import evaluation, loss, model, training
+    d = load(os.path.join(GOLDEN, "trainer_selgnn.npz"))
+    net = SelectionGNN([1, 8, 8], [3, 3], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [5], d["S"][0])
+    net.load_state_dict({k[5:]: torch.tensor(v) for k, v in d.items() if k.startswith("init:")})
+    net = net.float()
+    optim = torch.optim.Adam(net.parameters(), lr=0.005, betas=(0.9, 0.999))
+    m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim, training.Trainer,
+                    evaluation.evaluate, DEV, "selgnn", str(tmp_path))
+    data = ArrayData(d, torch.float32)
+    np.random.seed(int(d["seed"]) + 1)
+    tv = m.train(data, int(d["nEpochs"]), int(d["batchSize"]), printInterval=0, **ast.literal_eval(str(d["trainKw"])))
+    assert tv["lossTrain"].shape == d["lossTrain"].shape and tv["lossValid"].shape == d["lossValid"].shape
+    assert np.allclose(tv["lossTrain"], d["lossTrain"], rtol=2e-4), (tv["lossTrain"], d["lossTrain"])
+    assert np.allclose(tv["lossValid"], d["lossValid"], rtol=2e-4)
+    assert np.max(np.abs(tv["costValid"] - d["costValid"])) <= 1.0 / 32 + 1e-6      # at most one borderline sample flips
+    ev = m.evaluate(data)
+    assert abs(ev["costBest"] - float(d["costBest"])) <= 1.0 / 32 + 1e-6
+    assert abs(ev["costLast"] - float(d["costLast"])) <= 1.0 / 32 + 1e-6
+    ref = torch.load(os.path.join(GOLDEN, "ckpt", "selgnnArchitLast.ckpt"))
+    last = torch.load(tmp_path / "savedModels" / "selgnnArchitLast.ckpt")
+    for k in ref:                                                    # 9 Adam steps in fp32 vs fp64
+        assert relerr(last[k].cpu().numpy(), ref[k].numpy()) < 2e-3, k
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # seeded random inputs vs the CPU oracle (sparse restatement), sizes the oracle finishes in seconds
 # ---------------------------------------------------------------------------------------------------------------

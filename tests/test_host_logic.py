@@ -315,3 +315,122 @@ def test_edge_variant_gf_surface_matches_reference():
     sparse = gml.EdgeVariantGF(G, F, K, M, N, E, True, sparse=True)
     sparse.addGSO(torch.tensor(d["S"]))
     assert tuple(sparse.weightEVedges[0].shape) == (F, K - 1, G, layer._patterns[0].nnzp)
+
+
+# ---- Model / Trainer / evaluate ----------------------------------------------------
+def _mlp(N, nClasses=5):
+    return torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(N, 16), torch.nn.Tanh(), torch.nn.Linear(16, nClasses))
+
+
+def _trainer_model(d, archit, saveDir, name, trainer=None):
+    from alegnn_amd.modules import evaluation, loss, model, training
+    archit.load_state_dict({k[5:]: torch.tensor(v) for k, v in d.items() if k.startswith("init:")})
+    optim = torch.optim.Adam(archit.parameters(), lr=0.005, betas=(0.9, 0.999))
+    return model.Model(archit, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim,
+                       trainer or training.Trainer, evaluation.evaluate, 'cpu', name, saveDir)
+
+
+def test_trainer_reproduces_reference_training_run(tmp_path):
+    """Our Model + Trainer + evaluate against the reference's own run (tests/golden/make_golden.py trainer_case 'mlp'):
+    same epoch permutations, uneven last batch, LR decay, early stopping, Best / Last checkpoints, evaluation."""
+    import ast
+    from _util import ArrayData
+    d = load(os.path.join(GOLDEN, "trainer_mlp.npz"))
+    m = _trainer_model(d, _mlp(d["S"].shape[1]).double(), str(tmp_path), "mlp")
+    np.random.seed(int(d["seed"]) + 1)
+    tv = m.train(ArrayData(d, torch.float64), int(d["nEpochs"]), int(d["batchSize"]), doSaveVars=True, printInterval=0,
+                 **ast.literal_eval(str(d["trainKw"])))
+    for k in ("lossTrain", "costTrain", "lossValid", "costValid"):
+        assert tv[k].shape == d[k].shape, k                                       # early stopping ended at the same step
+        assert np.allclose(tv[k], d[k], rtol=1e-9, atol=1e-12), k
+    assert tv["batchSize"].tolist() == [40, 40, 16] and tv["batchIndex"].tolist() == [0, 40, 80, 96]
+    ev = m.evaluate(ArrayData(d, torch.float64), doSaveVars=True)
+    assert ev == {"costBest": float(d["costBest"]), "costLast": float(d["costLast"])}
+    assert os.path.exists(tmp_path / "trainVars" / "mlptrainVars.pkl") and os.path.exists(tmp_path / "evalVars" / "mlpevalVars.pkl")
+    assert m.getTrainingOptions()["nBatches"] == 3
+    for label in ("Best", "Last"):                                   # the files we wrote == the files the reference wrote
+        for part in ("Archit", "Optim"):
+            ours = torch.load(tmp_path / "savedModels" / f"mlp{part}{label}.ckpt")
+            ref = torch.load(os.path.join(GOLDEN, "ckpt", f"mlp{part}{label}.ckpt"))
+            if part == "Archit":
+                assert list(ours) == list(ref)
+                for k in ref:
+                    assert torch.allclose(ours[k], ref[k], rtol=1e-9, atol=1e-12), (label, k)
+            else:
+                assert ours["param_groups"] == ref["param_groups"] and list(ours["state"]) == list(ref["state"])
+                for i in ref["state"]:
+                    for k in ref["state"][i]:
+                        assert torch.allclose(ours["state"][i][k].double(), ref["state"][i][k].double(), rtol=1e-9, atol=1e-14), (label, i, k)
+
+
+def test_reference_checkpoints_load_into_rebuilt_selection_gnn(tmp_path):
+    """Model.save files written by the reference (model.py:106-117) for its SelectionGNN load into ours via Model.load,
+    and what Model.save writes back is readable with the reference's keys and values (round trip)."""
+    d = load(os.path.join(GOLDEN, "trainer_selgnn.npz"))
+    net = SelectionGNN([1, 8, 8], [3, 3], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [5], d["S"][0]).double()
+    m = _trainer_model(d, net, str(tmp_path), "selgnn")
+    stem = os.path.join(GOLDEN, "ckpt", "selgnn")
+    m.load(loadFiles=(stem + "ArchitBest.ckpt", stem + "OptimBest.ckpt"))
+    ref_a, ref_o = torch.load(stem + "ArchitBest.ckpt"), torch.load(stem + "OptimBest.ckpt")
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, ref_a[k]), k
+    assert m.optim.state_dict()["param_groups"] == ref_o["param_groups"]
+    m.save(label="RoundTrip")
+    back_a = torch.load(tmp_path / "savedModels" / "selgnnArchitRoundTrip.ckpt")
+    back_o = torch.load(tmp_path / "savedModels" / "selgnnOptimRoundTrip.ckpt")
+    assert list(back_a) == list(ref_a) and all(torch.equal(back_a[k], ref_a[k]) for k in ref_a)
+    assert all(torch.equal(back_o["state"][i][k], ref_o["state"][i][k]) for i in ref_o["state"] for k in ref_o["state"][i])
+    m.load(label="RoundTrip")                                        # default path: <saveDir>/savedModels/<name>Archit<label>.ckpt
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/alegnn"), reason="needs the reference checkout (build container only)")
+def test_our_checkpoints_load_into_the_reference(tmp_path):
+    """The other direction, run where the reference is present: the reference's own SelectionGNN + Model.load read files
+    written by our Model.save."""
+    import subprocess
+    import sys
+    d = load(os.path.join(GOLDEN, "trainer_selgnn.npz"))
+    net = SelectionGNN([1, 8, 8], [3, 3], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [5], d["S"][0]).double()
+    m = _trainer_model(d, net, str(tmp_path), "ours")
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.125)
+    m.optim.zero_grad()
+    m.save(label="X")
+    np.save(tmp_path / "S.npy", d["S"][0])
+    code = f"""
+import sys, types
+for mod in ("hdf5storage", "gensim"):
+    sys.modules[mod] = types.ModuleType(mod)
+import numpy as np, scipy.sparse
+np.int = int; np.float = float
+sys.path.insert(0, "/root/reference")
+import torch
+torch.set_default_dtype(torch.float64)
+import alegnn.utils.graphML as gml, alegnn.modules.architectures as archit, alegnn.modules.model as model
+S = np.load(r"{tmp_path}/S.npy")
+net = archit.SelectionGNN([1, 8, 8], [3, 3], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [5], S)
+opt = torch.optim.Adam(net.parameters(), lr=0.005)
+m = model.Model(net, None, opt, None, None, 'cpu', 'ours', r"{tmp_path}")
+m.load(label='X')
+print("SUM", float(sum(p.sum() for p in net.parameters())))
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    want = float(sum(p.sum() for p in net.parameters()))
+    got = float(out.stdout.strip().split("SUM")[-1])
+    assert abs(got - want) < 1e-9 * max(1.0, abs(want))
+
+
+def test_local_gnn_surface_matches_reference():
+    from alegnn_amd.modules.architectures import LocalGNN
+    d = load(os.path.join(GOLDEN, "selgnn_cfg1_sbm100.npz"))
+    S = d["S"][0]
+    net = LocalGNN([1, 8, 4], [3, 2], True, torch.nn.ReLU, [100, 100], gml.NoPool, [1, 1], [6, 1], S, order="Degree")
+    assert list(net.state_dict().keys()) == ["GFL.0.weight", "GFL.0.bias", "GFL.3.weight", "GFL.3.bias",
+                                             "Readout.0.weight", "Readout.0.bias", "Readout.2.weight", "Readout.2.bias"]
+    assert tuple(net.Readout[0].weight.shape) == (6, 4) and not hasattr(net, "MLP")
+    g = dict(np.load(os.path.join(GOLDEN, "graphtools_sbm100.npz")))
+    assert list(net.order) == list(g["order_Degree"])
+    with pytest.raises(AssertionError):
+        net.singleNodeForward(torch.zeros(2, 1, 100), "3")          # architectures.py:1132-1134
