@@ -122,6 +122,83 @@ def LSIGF(h, S, x, b=None, activation=None):
     return y
 
 
+class _NVGFFunction(torch.autograd.Function):
+    """Node-variant filter: gf_nvgf_forward / gf_nvgf_backward.  h is the expanded bank [F,E,K,G,N]; the bias is added by the
+    kernel when it is per-feature ([F,1]), its gradient is a plain reduction of dy (left to autograd of the caller's add when
+    the bias is per-node)."""
+
+    @staticmethod
+    def forward(ctx, x, h, bias, gso: SparseGSO):
+        L = _lib.lib()
+        B, G, Nin = x.shape
+        F_, E, K, G2, N = h.shape
+        T = 1 + E * (K - 1)
+        x = x.contiguous()
+        h = h.contiguous()
+        bias_c = None if bias is None else bias.contiguous()
+        with torch.cuda.device(x.device):
+            plans = gso.plans(x.device)
+            Z = torch.empty((T, B, N, G), dtype=torch.float32, device=x.device)
+            y = torch.empty((B, F_, Nin), dtype=torch.float32, device=x.device)
+            n = L.gf_nvgf_scratch_floats(B, N, G, F_, E, K, 0)
+            scratch = torch.empty(n, dtype=torch.float32, device=x.device)
+            _lib.check(L.gf_nvgf_forward(plans, E, x.data_ptr(), h.data_ptr(), _ptr(bias_c), Z.data_ptr(), y.data_ptr(),
+                                         scratch.data_ptr(), n, B, G, F_, K, Nin, torch.cuda.current_stream().cuda_stream),
+                       "gf_nvgf_forward")
+        ctx.gso = gso
+        ctx.dims = (B, G, F_, E, K, Nin, N)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(h, Z if ctx.needs_input_grad[1] else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        h, Z = ctx.saved_tensors
+        B, G, F_, E, K, Nin, N = ctx.dims
+        need_dx, need_dh = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dy = dy.contiguous()
+        dev = dy.device
+        dx = dh = None
+        if need_dx or need_dh:
+            with torch.cuda.device(dev):
+                plans = ctx.gso.plans(dev)
+                dx = torch.empty((B, G, Nin), dtype=torch.float32, device=dev) if need_dx else None
+                dh = torch.empty_like(h) if need_dh else None
+                n = L.gf_nvgf_scratch_floats(B, N, G, F_, E, K, 1)
+                scratch = torch.empty(n, dtype=torch.float32, device=dev)
+                _lib.check(L.gf_nvgf_backward(plans, E, dy.data_ptr(), _ptr(Z) if need_dh else dy.data_ptr(), h.data_ptr(),
+                                              _ptr(dx), _ptr(dh), scratch.data_ptr(), n, B, G, F_, K, Nin,
+                                              torch.cuda.current_stream().cuda_stream), "gf_nvgf_backward")
+        db = dy.sum(dim=(0, 2)).unsqueeze(1) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dh, db, None
+
+
+def NVGF(h, S, x, b=None):
+    """Node-variant graph filter, reference signature and semantics (graphML.py:293-387):
+
+        y[b,f,n] = sum_{e,k,g} h[f,e,k,g,n] * (x_g S_e^k)[b,n] + b[f,n]
+
+    h [F,E,K,G,N], S dense [E,N,N] or anything SparseGSO.from_any accepts, x [B,G,Nin<=N] (zero-padded, the output keeps Nin
+    nodes: NodeVariantGF.forward's wrapper, :2487-2497), b [F,1] or [F,N] or None."""
+    gso = SparseGSO.from_any(S)
+    assert h.dim() == 5 and x.dim() == 3
+    F_, E, K, G, N = h.shape
+    assert gso.E == E and gso.N == N                                # graphML.py:346-347
+    assert x.shape[1] == G and x.shape[2] <= N                      # :350-351
+    _require_f32_cuda("x", x)
+    _require_f32_cuda("h", h)
+    fused = late = None
+    if b is not None:
+        _require_f32_cuda("b", b)
+        assert b.dim() == 2 and b.shape[0] == F_
+        fused, late = (b, None) if b.shape[1] == 1 else (None, b)
+    y = _NVGFFunction.apply(x, h, fused, gso)
+    if late is not None:
+        y = y + late[:, : y.shape[2]]
+    return y
+
+
 class _EVGFFunction(torch.autograd.Function):
     """One edge feature of EVGF with per-edge storage: two C-ABI calls (gf_evgf_forward / gf_evgf_backward)."""
 

@@ -282,3 +282,89 @@ class LocalGNN(SelectionGNN):
         y = self.forward(x)                                         # B x R x N[-1]
         idx = torch.as_tensor(nodes, device=y.device).view(batchSize, 1, 1).expand(batchSize, y.shape[1], 1)
         return torch.gather(y, 2, idx).squeeze(2)
+
+
+class GraphRecurrentNN(nn.Module):
+    """Graph recurrent network -- architectures.py:4357-4672: HiddenState (z_t = sigma(A(S)x_t + B(S)z_{t-1})), an output
+    GraphFilter on every z_t followed by rho, and a per-node readout.  Same constructor, sub-module names
+    (``hiddenState``, ``outputState``, ``Readout``) and state_dict keys.  x: B x T x F x N -> B x T x dimReadout[-1] x N.
+
+    The reference draws the initial state inside splitForward (``torch.randn`` on x's device, :4556); ``z0`` can be passed
+    instead (superset) so that a run is reproducible across devices."""
+
+    def __init__(self, dimInputSignals, dimOutputSignals, dimHiddenSignals, nFilterTaps, bias, nonlinearityHidden,
+                 nonlinearityOutput, nonlinearityReadout, dimReadout, GSO):
+        super().__init__()
+        assert len(nFilterTaps) == 2                                # :4463
+        self.F = dimInputSignals
+        self.G = dimOutputSignals
+        self.H = dimHiddenSignals
+        self.K = nFilterTaps
+        self.bias = bias
+        self.sigma = nonlinearityHidden
+        self.rho = nonlinearityOutput
+        self.nonlinearityReadout = nonlinearityReadout
+        self.dimReadout = dimReadout
+        self._install(GSO)
+        self.hiddenState = gml.HiddenState(self.F, self.H, self.K[0], nonlinearity=self.sigma, E=self.E, bias=self.bias)
+        self.outputState = gml.GraphFilter(self.H, self.G, self.K[1], E=self.E, bias=self.bias)
+        self.hiddenState.addGSO(self._gso)
+        self.outputState.addGSO(self._gso)
+        fc = []
+        if len(self.dimReadout) > 0:                                # :4507-4519
+            fc.append(nn.Linear(self.G, dimReadout[0], bias=self.bias))
+            for l in range(len(dimReadout) - 1):
+                fc.append(self.nonlinearityReadout())
+                fc.append(nn.Linear(dimReadout[l], dimReadout[l + 1], bias=self.bias))
+        self.Readout = nn.Sequential(*fc)
+
+    def _install(self, GSO):
+        if sp.issparse(GSO) or isinstance(GSO, (SparseGSO, list, tuple)):
+            self._gso = SparseGSO.from_any(GSO)
+            self.S = self._gso
+        else:
+            if isinstance(GSO, torch.Tensor):
+                GSO = GSO.detach().cpu().numpy()
+            GSO = np.asarray(GSO)
+            assert len(GSO.shape) == 2 or len(GSO.shape) == 3       # :4479
+            if len(GSO.shape) == 2:
+                assert GSO.shape[0] == GSO.shape[1]
+                GSO = GSO.reshape([1, GSO.shape[0], GSO.shape[1]])
+            else:
+                assert GSO.shape[1] == GSO.shape[2]
+            self.S = torch.tensor(GSO)
+            self._gso = SparseGSO.from_any(GSO)
+        self.E = self._gso.E
+        self.N = self._gso.N
+        self.order = list(range(self.N))     # singleNodeForward looks nodes up in self.order, which the reference never sets
+
+    def changeGSO(self, GSO):
+        self._install(GSO)                                          # :4633-4660
+        self.hiddenState.addGSO(self._gso)
+        self.outputState.addGSO(self._gso)
+
+    def splitForward(self, x, z0=None):
+        assert len(x.shape) == 4                                    # :4540-4544
+        B, T = x.shape[0], x.shape[1]
+        assert x.shape[2] == self.F and x.shape[3] == self.N
+        if z0 is None:
+            z0 = torch.randn((B, self.H, self.N), device=x.device, dtype=x.dtype)       # :4556
+        z, _ = self.hiddenState(x, z0)
+        yOut = self.rho(self.outputState(z.reshape(B * T, self.H, self.N)))             # :4559-4561
+        yOut = yOut.reshape(B, T, self.G, self.N)
+        y = self.Readout(yOut.permute(0, 1, 3, 2))                  # B x T x N x dimReadout[-1]
+        return y.permute(0, 1, 3, 2), yOut
+
+    def forward(self, x, z0=None):
+        output, _ = self.splitForward(x, z0)
+        return output
+
+    def singleNodeForward(self, x, nodes, z0=None):
+        """B x T x dimReadout[-1] at one node per sample (:4576-4631)."""
+        batchSize = x.shape[0]
+        assert type(nodes) is int or type(nodes) is list or type(nodes) is np.ndarray
+        nodes = np.full(batchSize, nodes, dtype=np.int64) if type(nodes) is int else np.asarray(nodes, dtype=np.int64)
+        assert nodes.shape[0] == batchSize
+        y = self.forward(x, z0)                                     # B x T x R x N
+        idx = torch.as_tensor(nodes, device=y.device).view(batchSize, 1, 1, 1).expand(batchSize, y.shape[1], y.shape[2], 1)
+        return torch.gather(y, 3, idx).squeeze(3)

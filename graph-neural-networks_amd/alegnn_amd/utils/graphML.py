@@ -4,6 +4,10 @@ Drop-in for the symbols SelectionGNN binds from alegnn/utils/graphML.py:
     LSIGF          (graphML.py:83-176)     -> alegnn_amd.functional.LSIGF   (HIP)
     GraphFilter    (graphML.py:2036-2155)  -> same ctor, attributes, parameter names/shapes, addGSO/forward/extra_repr
     EdgeVariantGF  (graphML.py:2511-2712)  -> same ctor / parameters (dense weightEV), or per-edge storage (sparse=True)
+    GatedGRNN      (graphML.py:1292-1527)  hidden-state recursion, one LSIGF over all B*T inputs + one per time step
+    HiddenState    (graphML.py:3540-3681)  the module around it (GraphRecurrentNN's recurrent layer)
+    NVGF           (graphML.py:293-387)    -> alegnn_amd.functional.NVGF  (HIP: LSIGF's tap stack, per-node bank)
+    NodeVariantGF  (graphML.py:2317-2509)  the module around it (NodeVariantGNN's layer)
     NoPool         (graphML.py:1850-1888)  identity pooling
     MaxPoolLocal   (graphML.py:1890-2028)  alpha-hop neighbourhood max, keep the first nOutputNodes nodes
 Checkpoints are interchangeable with the reference: ``weight [F,E,K,G]``, ``bias [F,1]``; the GSO is a plain attribute
@@ -18,11 +22,11 @@ import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
-from ..functional import EVGF_edges, LSIGF, max_pool_local
+from ..functional import EVGF_edges, LSIGF, NVGF, max_pool_local
 from ..gso import EdgePattern, SparseGSO
 from . import graphTools
 
-__all__ = ["LSIGF", "GraphFilter", "EdgeVariantGF", "NoPool", "MaxPoolLocal", "FusedReLU"]
+__all__ = ["LSIGF", "GraphFilter", "EdgeVariantGF", "NoPool", "MaxPoolLocal", "FusedReLU", "GatedGRNN", "HiddenState", "NVGF", "NodeVariantGF"]
 
 
 class FusedReLU(nn.Identity):
@@ -79,6 +83,73 @@ class GraphFilter(nn.Module):
     def extra_repr(self):
         reprString = "in_features=%d, out_features=%d, " % (self.G, self.F) + "filter_taps=%d, " % (self.K) + \
                      "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias is not None)
+        reprString += "GSO stored" if self.S is not None else "no GSO stored"
+        return reprString
+
+
+class NodeVariantGF(nn.Module):
+    """NodeVariantGF(in_features, out_features, shift_taps, node_taps, edge_features=1, bias=True) -- graphML.py:2369-2393.
+    Parameters ``weight [F,E,K,G,M]`` and ``bias [F,1]`` as in the reference.  The M node taps are spread over the N nodes by
+    ``copyNodes`` (:2411-2468): node n >= M copies the taps of the lowest-numbered node < M in its 1-hop neighbourhood (wider
+    neighbourhoods while some node has none)."""
+
+    def __init__(self, G, F, K, M, E=1, bias=True):
+        super().__init__()
+        self.G = G
+        self.F = F
+        self.K = K
+        self.M = M
+        self.E = E
+        self.S = None
+        self._gso = None
+        self.weight = nn.parameter.Parameter(torch.Tensor(F, E, K, G, M))
+        if bias:
+            self.bias = nn.parameter.Parameter(torch.Tensor(F, 1))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.G * self.K * self.M)             # :2395-2400
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        if sp.issparse(S) or isinstance(S, (list, tuple)):
+            S = SparseGSO.from_any(S)
+        assert len(S.shape) == 3 and S.shape[0] == self.E           # :2404-2406
+        self.N = S.shape[1]
+        assert S.shape[2] == self.N
+        self.S = S
+        self._gso = SparseGSO.from_any(S)
+        if self.M < self.N:
+            hops = 1
+            nbh = graphTools.computeNeighborhood(self._gso.mats, hops, nb=self.M)
+            while any(len(v) == 0 for v in nbh):                    # :2425-2449: widen until every node sees a tap node
+                hops += 1
+                assert hops <= self.N, "NodeVariantGF.addGSO: some node is not connected to any of the first M nodes"
+                wider = graphTools.computeNeighborhood(self._gso.mats, hops, nb=self.M)
+                nbh = [wider[n] if len(v) == 0 else v for n, v in enumerate(nbh)]
+            copyNodes = list(range(self.M)) + [min(nbh[m]) for m in range(self.M, self.N)]
+            self.copyNodes = torch.tensor(copyNodes)
+        else:
+            self.copyNodes = torch.arange(min(self.M, self.N))      # :2461-2468
+
+    def forward(self, x):
+        assert self._gso is not None, "NodeVariantGF.forward called before addGSO"
+        assert x.dim() == 3 and x.shape[2] <= self.N
+        if self.M == self.N:
+            h = self.weight                                         # :2482-2485
+        else:
+            if self.copyNodes.device != self.weight.device:
+                self.copyNodes = self.copyNodes.to(self.weight.device)
+            h = torch.index_select(self.weight, 4, self.copyNodes)
+        return NVGF(h, self._gso, x, self.bias)                     # padding / truncation to Nin happen in the HIP path
+
+    def extra_repr(self):
+        reprString = "in_features=%d, out_features=%d, " % (self.G, self.F) + "shift_taps=%d, node_taps=%d, " % (
+            self.K, self.M) + "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias is not None)
         reprString += "GSO stored" if self.S is not None else "no GSO stored"
         return reprString
 
@@ -276,4 +347,106 @@ class MaxPoolLocal(nn.Module):
     def extra_repr(self):
         reprString = "in_dim=%d, out_dim=%d, number_hops = %d, " % (self.nInputNodes, self.nOutputNodes, self.nHops)
         reprString += "neighborhood stored" if self.neighborhood is not None else "NO neighborhood stored"
+        return reprString
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Graph recurrent layer: LSIGF per time step
+# ---------------------------------------------------------------------------------------------------------------
+def _check_gate(q, B, T, N, name):
+    assert q.shape[0] == B or q.shape[0] == 1                       # graphML.py:1367, :1374
+    if q.dim() > 1:
+        assert q.shape[1] == T and q.shape[2] == 1 and (q.shape[3] == 1 or q.shape[3] == N), name
+    if q.dim() > 4:
+        raise NotImplementedError("edge gating (%s of shape B x T x 1 x N x N, graphML.py:1394-1419) turns the GSO into a "
+                                  "dense per-sample matrix; that is a batched dense product, not this sparse path" % name)
+
+
+def GatedGRNN(a, b, S, x, z0, sigma, q_hat=None, q_check=None, xBias=None, zBias=None):
+    """Hidden states z_t = sigma(q_hat_t * A(S) x_t + q_check_t * B(S) z_{t-1}), t = 1..T -- graphML.py:1292-1527.
+
+    a [H,E,K,F] input-to-hidden taps, b [H,E,K,H] hidden-to-hidden taps, S the GSO (dense [E,N,N] or SparseGSO),
+    x [B,T,F,N], z0 [B,H,N]; gates: None / ones(1) (no gating), [B|1,T,1,1] (time) or [B|1,T,1,N] (node);
+    xBias / zBias [H,1].  Returns z [B,T,H,N].
+    A(S)x for all B*T inputs is ONE LSIGF call (:1389-1391); the recursion is one LSIGF call per time step (:1424) --
+    T+1 launches of the HIP filter instead of (T+1)(K-1) dense N x N products."""
+    H, E, K, F = a.shape
+    assert b.shape[0] == H and b.shape[1] == E and b.shape[2] == K and b.shape[3] == H      # :1354-1357
+    gso = SparseGSO.from_any(S)
+    N = gso.N
+    B, T = x.shape[0], x.shape[1]
+    assert x.shape[2] == F and x.shape[3] == N                       # :1362-1363
+    assert z0.shape[0] == B and z0.shape[1] == H and z0.shape[2] == N
+    if q_hat is not None:
+        _check_gate(q_hat, B, T, N, "q_hat")
+    if q_check is not None:
+        _check_gate(q_check, B, T, N, "q_check")
+    Ax = LSIGF(a, gso, x.reshape(B * T, F, N), xBias).reshape(B, T, H, N)
+    if q_hat is not None:
+        Ax = q_hat * Ax                                             # :1392
+    zt = z0
+    states = []
+    for t in range(T):
+        Bz = LSIGF(b, gso, zt.reshape(B, H, N), zBias)              # :1424
+        if q_check is not None:                                     # :1426-1432  [B|1,1,1|N] broadcasts over H
+            Bz = (q_check[:, t] if q_check.dim() > 1 else q_check) * Bz
+        zt = sigma(Ax[:, t] + Bz)                                   # :1462
+        states.append(zt)
+    return torch.stack(states, dim=1)                               # B x T x H x N
+
+
+class HiddenState(nn.Module):
+    """HiddenState(signal_features, hidden_features, filter_taps, nonlinearity=torch.tanh, edge_features=1, bias=True)
+    -- graphML.py:3540-3681.  Parameters ``aWeights [H,E,K,F]``, ``bWeights [H,E,K,H]``, ``xBias``/``zBias [H,1]``
+    (same names and shapes: reference checkpoints load).  forward(x [B,T,F,N], z0 [B,H,N]) -> (z [B,T,H,N], z_T [B,1,H,N])."""
+
+    def __init__(self, F, H, K, nonlinearity=torch.tanh, E=1, bias=True):
+        super().__init__()
+        self.F = F
+        self.H = H
+        self.K = K
+        self.E = E
+        self.S = None
+        self._gso = None
+        self.bias = bias
+        self.sigma = nonlinearity
+        self.aWeights = nn.parameter.Parameter(torch.Tensor(H, E, K, F))
+        self.bWeights = nn.parameter.Parameter(torch.Tensor(H, E, K, H))
+        if self.bias:
+            self.xBias = nn.parameter.Parameter(torch.Tensor(H, 1))
+            self.zBias = nn.parameter.Parameter(torch.Tensor(H, 1))
+        else:
+            self.register_parameter('xBias', None)
+            self.register_parameter('zBias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.F * self.K)                      # graphML.py:3614-3620
+        self.aWeights.data.uniform_(-stdv, stdv)
+        self.bWeights.data.uniform_(-stdv, stdv)
+        if self.bias:
+            self.xBias.data.uniform_(-stdv, stdv)
+            self.zBias.data.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        if sp.issparse(S) or isinstance(S, (list, tuple)):
+            S = SparseGSO.from_any(S)
+        assert len(S.shape) == 3 and S.shape[0] == self.E           # :3657-3659
+        self.N = S.shape[1]
+        assert S.shape[2] == self.N
+        self.S = S
+        self._gso = SparseGSO.from_any(S)
+
+    def forward(self, x, z0):
+        assert self._gso is not None                                # :3624
+        assert len(x.shape) == 4 and x.shape[2] == self.F
+        B, T, N = x.shape[0], x.shape[1], x.shape[3]
+        assert len(z0.shape) == 3 and z0.shape[0] == B and z0.shape[1] == self.H and z0.shape[2] == N
+        z = GatedGRNN(self.aWeights, self.bWeights, self._gso, x, z0, self.sigma, xBias=self.xBias, zBias=self.zBias)
+        return z, z[:, T - 1:T].unsqueeze(1)                        # :3645-3648 (index_select(T-1) then unsqueeze(1))
+
+    def extra_repr(self):
+        reprString = "in_features=%d, hidden_features=%d, " % (self.F, self.H) + "filter_taps=%d, " % (self.K) + \
+                     "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias) + "nonlinearity=%s" % (self.sigma)
+        reprString += "GSO stored" if self.S is not None else "no GSO stored"
         return reprString

@@ -164,6 +164,17 @@ int gf_maxpool_forward(const float* x, const int32_t* nbh, float* v, int32_t* ar
 int gf_maxpool_backward(const float* dv, const int32_t* arg, const int32_t* rev_ptr, const int32_t* rev_i, const int32_t* rev_p,
                         float* dx, int32_t B, int32_t F, int32_t Nin, int32_t Nout, void* stream);
 
+/* ---- Node-variant graph filter, NVGF (graphML.py:293-387) / NodeVariantGF.forward (:2475-2498): the LSIGF tap stack contracted
+ * with a bank that has its own taps at every node:  y[b,f,n] = bias[f] + sum_{e,k,g} h[f,e,k,g,n] (x_g S_e^k)[b,n].
+ * h [F,E,K,G,N] in the reference layout (already expanded over copyNodes, :2485); x [B,G,Nin] zero-padded to N, y [B,F,Nin].
+ * forward writes the node-major tap stack Z [T,B,N,G], T = 1+E(K-1) (save it for backward); backward: dx [B,G,Nin] and/or
+ * dh [F,E,K,G,N] (NULL = skip).  scratch: gf_nvgf_scratch_floats(..., backward) floats of device memory. */
+size_t gf_nvgf_scratch_floats(int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K, int32_t backward);
+int gf_nvgf_forward(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z, float* y,
+                    float* scratch, size_t scratch_floats, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
+int gf_nvgf_backward(const gf_plan* const* plans, int32_t E, const float* dy, const float* Z, const float* h, float* dx, float* dh,
+                     float* scratch, size_t scratch_floats, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
+
 /* ---- GraphFilter followed by sigma = ReLU (SelectionGNN layers, architectures.py:286-289): y = max(0, LSIGF(...)) fused into the
  * contraction's epilogue; backward takes the saved output y [B,F,Nin] and applies the mask (y > 0) to dy on the way in. */
 int gf_lsigf_forward_relu(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias,

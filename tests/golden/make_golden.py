@@ -172,6 +172,107 @@ def local_gnn_case(name, S2d, dimNodeSignals, nFilterTaps, nSelectedNodes, pool,
     print(f"localgnn_{name}: N={N} y{tuple(y.shape)} ysn{tuple(ysn.shape)}")
 
 
+def grnn_case(name, S, B, T, F, H, K, gating, seed=0):
+    """gml.GatedGRNN through gml.HiddenState's parameters (graphML.py:1292-1527, 3540-3681): no / time / node gating."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    E, N = S.shape[0], S.shape[1]
+    layer = gml.HiddenState(F, H, K, nonlinearity=torch.tanh, E=E, bias=True)
+    layer.addGSO(torch.tensor(S))
+    x = rng.randn(B, T, F, N)
+    z0 = rng.randn(B, H, N)
+    dz = rng.randn(B, T, H, N)
+    xt, z0t = torch.tensor(x, requires_grad=True), torch.tensor(z0, requires_grad=True)
+    out = dict(x=x, z0=z0, dz=dz, gating=np.array(gating), **coo(S))
+    kw = {}
+    if gating != "none":
+        shape = (B, T, 1, 1) if gating == "time" else (1, T, 1, N)
+        out["q_hat"], out["q_check"] = rng.rand(*shape), rng.rand(*shape)
+        kw = dict(q_hat=torch.tensor(out["q_hat"]), q_check=torch.tensor(out["q_check"]))
+    z = gml.GatedGRNN(layer.aWeights, layer.bWeights, layer.S, xt, z0t, torch.tanh, xBias=layer.xBias, zBias=layer.zBias, **kw)
+    (z * torch.tensor(dz)).sum().backward()
+    out.update(z=z.detach().numpy(), dx=xt.grad.numpy(), dz0=z0t.grad.numpy())
+    for k, v in layer.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in layer.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    if gating == "none":
+        zz, zT = layer(torch.tensor(x), torch.tensor(z0))
+        assert torch.equal(zz, z.detach())
+        out["zT_shape"] = np.array(zT.shape)
+    np.savez_compressed(os.path.join(HERE, f"grnn_{name}.npz"), **out)
+    print(f"grnn_{name}: z{tuple(z.shape)} gating={gating}")
+
+
+def graph_recurrent_nn_case(name, S2d, B, T, seed=0):
+    """archit.GraphRecurrentNN (architectures.py:4357-4672).  The initial state is drawn inside splitForward (:4556); the same
+    draw is repeated here after re-seeding and stored, so that the rebuilt model can be fed the identical z0."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    N = S2d.shape[0]
+    net = archit.GraphRecurrentNN(3, 6, 8, [3, 2], True, torch.tanh, torch.tanh, torch.nn.ReLU, [5, 2], S2d)
+    x = rng.randn(B, T, 3, N)
+    xt = torch.tensor(x, requires_grad=True)
+    torch.manual_seed(seed + 100)
+    y, yOut = net.splitForward(xt)
+    torch.manual_seed(seed + 100)
+    z0 = torch.randn((B, 8, N))
+    w = rng.randn(*y.shape)
+    (y * torch.tensor(w)).sum().backward()
+    out = dict(x=x, w=w, z0=z0.numpy(), y=y.detach().numpy(), yOut=yOut.detach().numpy(), dx=xt.grad.numpy(), **coo(S2d[None]))
+    for k, v in net.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"grnnarch_{name}.npz"), **out)
+    print(f"grnnarch_{name}: y{tuple(y.shape)} keys={list(net.state_dict())}")
+
+
+def grnn_cases(sbm, asym, fb):
+    grnn_case("asym_E2_none", asym, B=3, T=4, F=3, H=5, K=3, gating="none")
+    grnn_case("sbm100_time", sbm[None], B=2, T=5, F=2, H=8, K=4, gating="time", seed=1)
+    grnn_case("sbm100_node", sbm[None], B=3, T=3, F=4, H=4, K=2, gating="node", seed=2)
+    grnn_case("fbego_none_H32", fb, B=2, T=3, F=8, H=32, K=3, gating="none", seed=3)
+    graph_recurrent_nn_case("sbm100", sbm, B=3, T=4, seed=4)
+
+
+def nvgf_case(name, S, B, G, F, K, M, Nin=None, bias_nodes=False, seed=0):
+    """gml.NVGF through gml.NodeVariantGF (graphML.py:293-387, 2317-2509): M node taps spread by copyNodes, optional Nin < N."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    E, N = S.shape[0], S.shape[1]
+    Nin = N if Nin is None else Nin
+    layer = gml.NodeVariantGF(G, F, K, M, E, True)
+    layer.addGSO(torch.tensor(S))
+    x = rng.randn(B, G, Nin)
+    xt = torch.tensor(x, requires_grad=True)
+    y = layer(xt)
+    dy = rng.randn(*y.shape)
+    y.backward(torch.tensor(dy))
+    out = dict(x=x, dy=dy, y=y.detach().numpy(), dx=xt.grad.numpy(), weight=layer.weight.detach().numpy(),
+               bias=layer.bias.detach().numpy(), dweight=layer.weight.grad.numpy(), dbias=layer.bias.grad.numpy(),
+               copyNodes=layer.copyNodes.numpy(), M=np.array(M), **coo(S))
+    if bias_nodes:                                                  # the functional form with a per-node bias [F,N] (:318-320)
+        h = torch.tensor(rng.randn(F, E, K, G, N) * 0.2, requires_grad=True)
+        bN = torch.tensor(rng.randn(F, N), requires_grad=True)
+        x2 = torch.tensor(rng.randn(B, G, N), requires_grad=True)
+        y2 = gml.NVGF(h, torch.tensor(S), x2, bN)
+        dy2 = rng.randn(*y2.shape)
+        y2.backward(torch.tensor(dy2))
+        out.update(f_h=h.detach().numpy(), f_b=bN.detach().numpy(), f_x=x2.detach().numpy(), f_y=y2.detach().numpy(), f_dy=dy2,
+                   f_dh=h.grad.numpy(), f_db=bN.grad.numpy(), f_dx=x2.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, f"nvgf_{name}.npz"), **out)
+    print(f"nvgf_{name}: N={N} Nin={Nin} M={M} y{tuple(y.shape)} copyNodes[-5:]={layer.copyNodes.numpy()[-5:]}")
+
+
+def nvgf_cases(sbm, asym, asym37, ring):
+    nvgf_case("asym_E2_M6", asym, B=3, G=3, F=5, K=4, M=6, bias_nodes=True)
+    nvgf_case("asym37_M37", asym37, B=2, G=4, F=6, K=3, M=37, seed=1)
+    nvgf_case("ring_M2", ring, B=2, G=2, F=3, K=3, M=2, seed=2)        # tap nodes several hops away
+    nvgf_case("sbm100_M10_Nin60", sbm[None], B=4, G=8, F=8, K=3, M=10, Nin=60, seed=3)
+    nvgf_case("sbm100_G16", sbm[None], B=5, G=16, F=32, K=4, M=12, seed=4)
+
+
 def trainer_case(name, G, S2d, archit_fn, nEpochs, batchSize, seed, **trainKw):
     """The reference's Model + Trainer + evaluate (model.py, training.py:29-578, evaluation.py:18-89) on SourceLocalization
     data: the loss / cost trajectories, the 'Best' and 'Last' checkpoints and the evaluation result.  The checkpoint files
@@ -281,6 +382,12 @@ def main():
     G.computeGFT()
     sbm = (G.S / np.max(np.real(G.E)))                                   # sourceLocGNN.py:752
 
+    if "--nvgf-only" in sys.argv:
+        nvgf_cases(sbm, asym, asym37, ring)
+        return
+    if "--grnn-only" in sys.argv:
+        grnn_cases(sbm, asym, fb)
+        return
     if "--trainer-only" in sys.argv:
         trainer_cases(G, sbm)
         local_gnn_case("fbego_movie", fb[0], [1, 64, 32], [5, 5], [234, 234], "NoPool", [1, 1], [1], B=5)

@@ -314,6 +314,105 @@ def test_trainer_on_gpu_follows_reference_training_run(tmp_path):
         assert relerr(last[k].cpu().numpy(), ref[k].numpy()) < 2e-3, k
 
 
+# ---- callers that reuse the K-hop kernel ---------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files("nvgf"), ids=case_id)
+def test_node_variant_gf_matches_reference(path):
+    """NodeVariantGF / NVGF (graphML.py:293-387, 2317-2509): reference weights, copyNodes expansion, Nin < N, all gradients."""
+    d = load(path)
+    F, E, K, G, M = d["weight"].shape
+    layer = gml.NodeVariantGF(G, F, K, M, E, True)
+    layer.load_state_dict({"weight": torch.tensor(d["weight"]), "bias": torch.tensor(d["bias"])})
+    layer.addGSO(torch.tensor(d["S"]))
+    layer = layer.float().to(DEV)
+    x = cu(d["x"], True)
+    y = layer(x)
+    assert tuple(y.shape) == d["y"].shape
+    y.backward(cu(d["dy"]))
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    assert relerr(layer.weight.grad.cpu().numpy(), d["dweight"]) < GRAD_RTOL
+    assert relerr(layer.bias.grad.cpu().numpy(), d["dbias"]) < GRAD_RTOL
+    if "f_h" in d:                                                  # functional form with a per-node bias [F,N]
+        from alegnn_amd.functional import NVGF
+        h, b, x2 = cu(d["f_h"], True), cu(d["f_b"], True), cu(d["f_x"], True)
+        y2 = NVGF(h, torch.tensor(d["S"]), x2, b)
+        y2.backward(cu(d["f_dy"]))
+        assert relerr(y2.detach().cpu().numpy(), d["f_y"]) < FWD_RTOL
+        for got, want in ((h.grad, "f_dh"), (b.grad, "f_db"), (x2.grad, "f_dx")):
+            assert relerr(got.cpu().numpy(), d[want]) < GRAD_RTOL, want
+
+
+def test_node_variant_random_sparse_vs_oracle():
+    """N = 3000 (no dense GSO anywhere), E = 2, widths that are not multiples of anything; forward against the numpy oracle,
+    backward against central differences of the oracle along random directions (the filter is linear in x and in h)."""
+    from alegnn_amd.functional import NVGF
+    from oracle import nvgf_oracle as nvo
+    N, B, G, F, K, E = 3000, 7, 5, 9, 3, 2
+    mats = [graphgen.sbm(N, seed=21 + e, directed=True) for e in range(E)]
+    rng = np.random.RandomState(5)
+    h = (rng.uniform(-1, 1, (F, E, K, G, N)) / np.sqrt(G * K)).astype(np.float32)
+    x = rng.randn(B, G, N).astype(np.float32)
+    b = rng.uniform(-1, 1, (F, 1)).astype(np.float32)
+    dy = rng.randn(B, F, N).astype(np.float32)
+    ht, xt, bt = cu(h, True), cu(x, True), cu(b, True)
+    y = NVGF(ht, SparseGSO(mats), xt, bt)
+    y.backward(cu(dy))
+    want = nvo.nvgf_sparse(h.astype(np.float64), mats, x.astype(np.float64), b.astype(np.float64))
+    assert relerr(y.detach().cpu().numpy(), want) < FWD_RTOL
+    # <dy, J_x u> = <dx, u> and <dy, J_h v> = <dh, v> (exact for a bilinear map): check the adjoints with random u, v
+    u, v = rng.randn(*x.shape), rng.randn(*h.shape)
+    Ju = nvo.nvgf_sparse(h.astype(np.float64), mats, u, None)
+    Jv = nvo.nvgf_sparse(v, mats, x.astype(np.float64), None)
+    assert abs(np.sum(dy * Ju) - np.sum(xt.grad.cpu().numpy().astype(np.float64) * u)) < GRAD_RTOL * np.abs(dy * Ju).sum()
+    assert abs(np.sum(dy * Jv) - np.sum(ht.grad.cpu().numpy().astype(np.float64) * v)) < GRAD_RTOL * np.abs(dy * Jv).sum()
+    assert relerr(bt.grad.cpu().numpy(), dy.astype(np.float64).sum(axis=(0, 2))[:, None]) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("path", golden_files("grnn"), ids=case_id)
+def test_gated_grnn_matches_reference(path):
+    """GatedGRNN / HiddenState (graphML.py:1292-1527, 3540-3681): one LSIGF over all B*T inputs + one per time step, with
+    no / time / node gating; every gradient including the one reaching z0 through the whole recursion."""
+    d = load(path)
+    H, E, K, F = d["sd:aWeights"].shape
+    layer = gml.HiddenState(F, H, K, nonlinearity=torch.tanh, E=E, bias=True)
+    layer.load_state_dict({k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")})
+    layer.addGSO(torch.tensor(d["S"]))
+    layer = layer.float().to(DEV)
+    x, z0 = cu(d["x"], True), cu(d["z0"], True)
+    kw = {}
+    if str(d["gating"]) != "none":
+        kw = dict(q_hat=cu(d["q_hat"]), q_check=cu(d["q_check"]))
+    z = gml.GatedGRNN(layer.aWeights, layer.bWeights, layer._gso, x, z0, torch.tanh, xBias=layer.xBias, zBias=layer.zBias, **kw)
+    (z * cu(d["dz"])).sum().backward()
+    assert relerr(z.detach().cpu().numpy(), d["z"]) < 2 * FWD_RTOL          # T chained filters + tanh
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    assert relerr(z0.grad.cpu().numpy(), d["dz0"]) < GRAD_RTOL
+    for k, p in layer.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
+    if str(d["gating"]) == "none":
+        zz, zT = layer(x.detach(), z0.detach())
+        assert torch.equal(zz, z.detach()) and list(zT.shape) == d["zT_shape"].tolist()
+
+
+def test_graph_recurrent_nn_matches_reference():
+    from alegnn_amd.modules.architectures import GraphRecurrentNN
+    d = load(os.path.join(GOLDEN, "grnnarch_sbm100.npz"))
+    net = GraphRecurrentNN(3, 6, 8, [3, 2], True, torch.tanh, torch.tanh, torch.nn.ReLU, [5, 2], d["S"][0])
+    net.load_state_dict({k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")})
+    net = net.float().to(DEV)
+    x = cu(d["x"], True)
+    y, yOut = net.splitForward(x, cu(d["z0"]))
+    (y * cu(d["w"])).sum().backward()
+    assert relerr(yOut.detach().cpu().numpy(), d["yOut"]) < 2 * FWD_RTOL
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < 5 * FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    for k, p in net.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
+    ysn = net.singleNodeForward(x.detach(), [1, 5, 9], cu(d["z0"]))
+    assert torch.equal(ysn, y.detach()[torch.arange(3), :, :, torch.tensor([1, 5, 9])])
+    assert tuple(net(x.detach()).shape) == tuple(y.shape)            # z0 drawn on the device when not given (:4556)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # seeded random inputs vs the CPU oracle (sparse restatement), sizes the oracle finishes in seconds
 # ---------------------------------------------------------------------------------------------------------------

@@ -148,3 +148,37 @@ def test_edge_variant_grads_match_reference_autograd(path):
     assert relerr(dx[:, :, :Nin], d["dx"]) < 1e-11
     if "bias" in d:
         assert relerr(db, d["dbias"]) < 1e-11
+
+
+# ---- node-variant filter: oracle/nvgf_oracle.py against the reference's NodeVariantGF ----------------
+NVGF = golden_files("nvgf")
+
+
+def _expanded_bank(d):
+    return d["weight"] if int(d["M"]) == d["S"].shape[1] else d["weight"][..., d["copyNodes"]]
+
+
+@pytest.mark.parametrize("path", NVGF, ids=case_id)
+def test_node_variant_oracle_matches_reference(path):
+    from oracle import nvgf_oracle as nvo
+    d = load(path)
+    S = d["S"]
+    E, N, _ = S.shape
+    B, G, Nin = d["x"].shape
+    assert nvo.copy_nodes([S[e] for e in range(E)], int(d["M"])) == d["copyNodes"].tolist()      # graphML.py:2411-2468
+    w = torch.tensor(d["weight"], requires_grad=True)
+    x = torch.tensor(d["x"], requires_grad=True)
+    b = torch.tensor(d["bias"], requires_grad=True)
+    h = w if int(d["M"]) == N else torch.index_select(w, 4, torch.tensor(d["copyNodes"]))
+    xp = torch.cat((x, torch.zeros(B, G, N - Nin, dtype=x.dtype)), dim=2)
+    y = nvo.nvgf_dense(h, torch.tensor(S), xp, b)[:, :, :Nin]
+    y.backward(torch.tensor(d["dy"]))
+    assert relerr(y.detach().numpy(), d["y"]) < 1e-12
+    assert relerr(x.grad.numpy(), d["dx"]) < 1e-12
+    assert relerr(w.grad.numpy(), d["dweight"]) < 1e-12
+    assert relerr(b.grad.numpy(), d["dbias"]) < 1e-12
+    ys = nvo.nvgf_sparse(_expanded_bank(d), [S[e] for e in range(E)], d["x"], d["bias"])
+    assert ys.shape == d["y"].shape and relerr(ys, d["y"]) < 1e-12
+    if "f_h" in d:                                                  # functional form, per-node bias
+        yf = nvo.nvgf_sparse(d["f_h"], [S[e] for e in range(E)], d["f_x"], d["f_b"])
+        assert relerr(yf, d["f_y"]) < 1e-12
