@@ -284,6 +284,67 @@ class LocalGNN(SelectionGNN):
         return torch.gather(y, 2, idx).squeeze(2)
 
 
+class NodeVariantGNN(SelectionGNN):
+    """Node-variant filter stack -- architectures.py:1485-1719: ``NVGFL`` = [NodeVariantGF, sigma, rho] x L and ``MLP``; same
+    constructor and state_dict keys as the reference.  GSO ingest / ordering are SelectionGNN's."""
+
+    def __init__(self,
+                 # Graph filtering
+                 dimNodeSignals, nShiftTaps, nNodeTaps, bias,
+                 # Nonlinearity
+                 nonlinearity,
+                 # Pooling
+                 nSelectedNodes, poolingFunction, poolingSize,
+                 # MLP in the end
+                 dimLayersMLP,
+                 # Structure
+                 GSO, order=None):
+        nn.Module.__init__(self)
+        assert len(dimNodeSignals) == len(nShiftTaps) + 1           # :1582-1586
+        assert len(nShiftTaps) == len(nNodeTaps)
+        assert len(nSelectedNodes) == len(nShiftTaps)
+        assert len(poolingSize) == len(nShiftTaps)
+        self.L = len(nShiftTaps)
+        self.F = dimNodeSignals
+        self.K = nShiftTaps
+        self.M = nNodeTaps
+        self.bias = bias
+        self.sigma = nonlinearity
+        self.rho = poolingFunction
+        self.alpha = poolingSize
+        self.dimLayersMLP = dimLayersMLP
+        self.coarsening = False
+        self._order_name = order
+        self._install_gso(GSO)
+        self.N = [self._gso.N] + nSelectedNodes
+        nvgfl = []
+        for l in range(self.L):                                     # :1628-1641
+            nvgfl.append(gml.NodeVariantGF(self.F[l], self.F[l + 1], self.K[l], self.M[l], self.E, self.bias))
+            nvgfl[3 * l].addGSO(self._gso)
+            nvgfl.append(self.sigma())
+            nvgfl.append(self.rho(self.N[l], self.N[l + 1], self.alpha[l]))
+            nvgfl[3 * l + 2].addGSO(self._gso)
+        self.NVGFL = nn.Sequential(*nvgfl)
+        fc = []
+        if len(self.dimLayersMLP) > 0:                              # :1645-1662
+            fc.append(nn.Linear(self.N[-1] * self.F[-1], dimLayersMLP[0], bias=self.bias))
+            for l in range(len(dimLayersMLP) - 1):
+                fc.append(self.sigma())
+                fc.append(nn.Linear(dimLayersMLP[l], dimLayersMLP[l + 1], bias=self.bias))
+        self.MLP = nn.Sequential(*fc)
+
+    def changeGSO(self, GSO, nSelectedNodes=[], poolingSize=[]):
+        raise NotImplementedError("the reference's NodeVariantGNN has no changeGSO (the node taps are tied to the graph)")
+
+    def splitForward(self, x):
+        assert len(x.shape) == 3                                    # :1684-1688
+        batchSize = x.shape[0]
+        assert x.shape[1] == self.F[0]
+        assert x.shape[2] == self.N[0]
+        y = self.NVGFL(self._reorder(x))                            # :1690-1692
+        return self.MLP(y.reshape(batchSize, self.F[-1] * self.N[-1])), y
+
+
 class GraphRecurrentNN(nn.Module):
     """Graph recurrent network -- architectures.py:4357-4672: HiddenState (z_t = sigma(A(S)x_t + B(S)z_{t-1})), an output
     GraphFilter on every z_t followed by rho, and a per-node readout.  Same constructor, sub-module names

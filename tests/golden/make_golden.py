@@ -265,7 +265,28 @@ def nvgf_case(name, S, B, G, F, K, M, Nin=None, bias_nodes=False, seed=0):
     print(f"nvgf_{name}: N={N} Nin={Nin} M={M} y{tuple(y.shape)} copyNodes[-5:]={layer.copyNodes.numpy()[-5:]}")
 
 
+def node_variant_gnn_case(name, S2d, B, seed=0):
+    """archit.NodeVariantGNN (architectures.py:1485-1719) with MaxPoolLocal pooling."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    N = S2d.shape[0]
+    net = archit.NodeVariantGNN([2, 8, 8], [3, 2], [10, 5], True, torch.nn.ReLU, [40, 10], gml.MaxPoolLocal, [2, 2], [4], S2d)
+    x = rng.randn(B, 2, N)
+    xt = torch.tensor(x, requires_grad=True)
+    y, ygnn = net.splitForward(xt)
+    w = rng.randn(*y.shape)
+    (y * torch.tensor(w)).sum().backward()
+    out = dict(x=x, w=w, y=y.detach().numpy(), ygnn=ygnn.detach().numpy(), dx=xt.grad.numpy(), **coo(S2d[None]))
+    for k, v in net.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"nvgnn_{name}.npz"), **out)
+    print(f"nvgnn_{name}: y{tuple(y.shape)} ygnn{tuple(ygnn.shape)} keys={list(net.state_dict())}")
+
+
 def nvgf_cases(sbm, asym, asym37, ring):
+    node_variant_gnn_case("sbm100", sbm, B=4, seed=6)
     nvgf_case("asym_E2_M6", asym, B=3, G=3, F=5, K=4, M=6, bias_nodes=True)
     nvgf_case("asym37_M37", asym37, B=2, G=4, F=6, K=3, M=37, seed=1)
     nvgf_case("ring_M2", ring, B=2, G=2, F=3, K=3, M=2, seed=2)        # tap nodes several hops away

@@ -368,6 +368,22 @@ def test_node_variant_random_sparse_vs_oracle():
     assert relerr(bt.grad.cpu().numpy(), dy.astype(np.float64).sum(axis=(0, 2))[:, None]) < GRAD_RTOL
 
 
+def test_node_variant_gnn_matches_reference():
+    from alegnn_amd.modules.architectures import NodeVariantGNN
+    d = load(os.path.join(GOLDEN, "nvgnn_sbm100.npz"))
+    net = NodeVariantGNN([2, 8, 8], [3, 2], [10, 5], True, torch.nn.ReLU, [40, 10], gml.MaxPoolLocal, [2, 2], [4], d["S"][0])
+    net.load_state_dict({k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")})
+    net = net.float().to(DEV)
+    x = cu(d["x"], True)
+    y, ygnn = net.splitForward(x)
+    (y * cu(d["w"])).sum().backward()
+    assert relerr(ygnn.detach().cpu().numpy(), d["ygnn"]) < FWD_RTOL
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < 5 * FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    for k, p in net.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
+
+
 @pytest.mark.parametrize("path", golden_files("grnn"), ids=case_id)
 def test_gated_grnn_matches_reference(path):
     """GatedGRNN / HiddenState (graphML.py:1292-1527, 3540-3681): one LSIGF over all B*T inputs + one per time step, with

@@ -461,3 +461,13 @@ def test_graph_recurrent_surface_matches_reference():
     with pytest.raises(NotImplementedError):                         # edge gating is a dense per-sample GSO
         gml.GatedGRNN(hs.aWeights, hs.bWeights, sp.identity(4, format="csr"), torch.zeros(2, 3, 3, 4), torch.zeros(2, 8, 4),
                       torch.tanh, q_hat=torch.ones(2, 3, 1, 4, 4))
+
+
+def test_node_variant_gnn_surface_matches_reference():
+    from alegnn_amd.modules.architectures import NodeVariantGNN
+    d = load(os.path.join(GOLDEN, "nvgnn_sbm100.npz"))
+    net = NodeVariantGNN([2, 8, 8], [3, 2], [10, 5], True, torch.nn.ReLU, [40, 10], gml.MaxPoolLocal, [2, 2], [4], d["S"][0])
+    ref = {k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")}
+    assert list(net.state_dict().keys()) == list(ref.keys())
+    net.load_state_dict(ref, strict=True)
+    assert net.N == [100, 40, 10] and isinstance(net.NVGFL[0], gml.NodeVariantGF) and net.NVGFL[3].M == 5
