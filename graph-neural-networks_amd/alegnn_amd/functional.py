@@ -174,6 +174,34 @@ class _NVGFFunction(torch.autograd.Function):
         return dx, dh, db, None
 
 
+class _ExpandTaps(torch.autograd.Function):
+    """h = weight[..., copyNodes] (NodeVariantGF.forward, graphML.py:2485).  Backward folds dh over the nodes that share a tap
+    node with gf_nvgf_fold_taps (fixed order) instead of autograd's atomic index_add."""
+
+    @staticmethod
+    def forward(ctx, weight, copyNodes, grp_ptr, grp_idx):
+        ctx.save_for_backward(grp_ptr, grp_idx)
+        ctx.M = weight.shape[-1]
+        return torch.index_select(weight, weight.dim() - 1, copyNodes)
+
+    @staticmethod
+    def backward(ctx, dh):
+        grp_ptr, grp_idx = ctx.saved_tensors
+        dh = dh.contiguous()
+        _require_f32_cuda("dh", dh)
+        N = dh.shape[-1]
+        R = dh.numel() // N
+        out = torch.empty(dh.shape[:-1] + (ctx.M,), dtype=torch.float32, device=dh.device)
+        with torch.cuda.device(dh.device):
+            _lib.check(_lib.lib().gf_nvgf_fold_taps(dh.data_ptr(), grp_ptr.data_ptr(), grp_idx.data_ptr(), out.data_ptr(), R, N, ctx.M,
+                                                    torch.cuda.current_stream().cuda_stream), "gf_nvgf_fold_taps")
+        return out, None, None, None
+
+
+def expand_node_taps(weight, copyNodes, grp_ptr, grp_idx):
+    return _ExpandTaps.apply(weight, copyNodes, grp_ptr, grp_idx)
+
+
 def NVGF(h, S, x, b=None):
     """Node-variant graph filter, reference signature and semantics (graphML.py:293-387):
 

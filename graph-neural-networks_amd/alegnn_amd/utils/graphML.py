@@ -22,7 +22,7 @@ import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
-from ..functional import EVGF_edges, LSIGF, NVGF, max_pool_local
+from ..functional import EVGF_edges, LSIGF, NVGF, expand_node_taps, max_pool_local
 from ..gso import EdgePattern, SparseGSO
 from . import graphTools
 
@@ -135,6 +135,11 @@ class NodeVariantGF(nn.Module):
             self.copyNodes = torch.tensor(copyNodes)
         else:
             self.copyNodes = torch.arange(min(self.M, self.N))      # :2461-2468
+        # the nodes sharing each tap node, as CSR (the weight gradient is a gather over these groups)
+        cn = self.copyNodes.numpy()
+        order = np.argsort(cn, kind="stable")
+        self._grp_idx = torch.tensor(order.astype(np.int32))
+        self._grp_ptr = torch.tensor(np.concatenate(([0], np.cumsum(np.bincount(cn, minlength=self.M)))).astype(np.int32))
 
     def forward(self, x):
         assert self._gso is not None, "NodeVariantGF.forward called before addGSO"
@@ -143,8 +148,9 @@ class NodeVariantGF(nn.Module):
             h = self.weight                                         # :2482-2485
         else:
             if self.copyNodes.device != self.weight.device:
-                self.copyNodes = self.copyNodes.to(self.weight.device)
-            h = torch.index_select(self.weight, 4, self.copyNodes)
+                dev = self.weight.device
+                self.copyNodes, self._grp_ptr, self._grp_idx = self.copyNodes.to(dev), self._grp_ptr.to(dev), self._grp_idx.to(dev)
+            h = expand_node_taps(self.weight, self.copyNodes, self._grp_ptr, self._grp_idx)
         return NVGF(h, self._gso, x, self.bias)                     # padding / truncation to Nin happen in the HIP path
 
     def extra_repr(self):

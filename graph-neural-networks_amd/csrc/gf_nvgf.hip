@@ -70,69 +70,243 @@ __global__ __launch_bounds__(256) void nv_bank_out_kernel(const float* __restric
     }
 }
 
-// One workgroup per node.  Thread -> (4 consecutive samples, one f); lanes along f: Ht rows are read unit-stride, the four Z
-// values are wave-uniform per f-group (broadcast loads).
-template <int BT>
+// ---- the three per-node products, operands staged in LDS ------------------------------------------------------------
+// For node n let A = Z_n [B x TG] (A[b][c] = Z[t][b][n][g], c = t*G + g), H = Ht_n [TG x F], D = dY_n [B x F]:
+//     forward   Y  = A H          backward   dZ_n = D H^T          dHt_n = A^T D
+// One workgroup (256 threads) per (node, column chunk): H and the A / D rows of a batch chunk are brought to LDS with
+// unit-stride reads (a Z row is G contiguous floats, a dY row F, the bank chunk CC*F), the FMAs then read LDS only:
+// one operand is a wave-wide broadcast, the other is unit-stride (rows padded by one float where lanes walk down a column).
+constexpr int NV_BC = 32;     // samples per batch chunk
+
+// samples per batch chunk of nv_dz_kernel: its D tile [chunk][F] stays within 32 KiB of LDS
+__host__ __device__ inline int nv_dz_batch(int F) {
+    int b = (8192 / F) & ~3;
+    return b < 4 ? 4 : (b > 128 ? 128 : b);
+}
+
+struct NvShape {
+    int B, N, G, F, T, CC;    // CC = bank columns (t,g) per chunk
+};
+
+__device__ __forceinline__ const float* nv_zrow(const float* Z, const NvShape& s, int n, int c, int b) {
+    const int t = c / s.G, g = c - t * s.G;
+    return Z + (((int64_t)t * s.B + b) * s.N + n) * s.G + g;
+}
+
+// Every thread owns a 4 x 4 register tile of the output: per reduction step it reads 4 + 4 operands from LDS for 16 FMAs.
+// Lanes are consecutive along the unit-stride operand (f for H / D rows, c for the padded H^T rows), the other operand is
+// a broadcast within the lanes that share the tile row.
+
+// Y[b][n][f] = bias[f] + sum_c A[b][c] H[c][f].  grid = N; the workgroup walks the column chunks itself (the sum runs over them).
+// thread -> (bq, fq): samples b0 + 4 bq + i, features fq + k FQ (FQ = ceil(F / 4)); batch chunk = 4 * (256 / FQ) samples, at most 128.
 __global__ __launch_bounds__(256) void nv_contract_kernel(const float* __restrict__ Z, const float* __restrict__ Ht,
-                                                          const float* __restrict__ bias, float* __restrict__ Y, int B, int N,
-                                                          int G, int F, int T) {
-    const int n = blockIdx.x;
-    const int TG = T * G;
+                                                          const float* __restrict__ bias, float* __restrict__ Y, NvShape s) {
+    extern __shared__ float sm[];
+    const int TG = s.T * s.G, F = s.F, CC = s.CC;
+    const int FQ = (F + 3) / 4;
+    const int BCH = min(128, 4 * (256 / FQ));
+    float* Hs = sm;                      // [CC][F]
+    float* As = sm + (size_t)CC * F;     // [BCH][CC + 1]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int fq = tid % FQ, bq = tid / FQ;
     const float* hn = Ht + (int64_t)n * TG * F;
-    const int groups = (B + BT - 1) / BT;
-    for (int idx = threadIdx.x; idx < groups * F; idx += blockDim.x) {
-        const int f = idx % F, b0 = (idx / F) * BT;
-        float acc[BT];
+    int fk[4];
 #pragma unroll
-        for (int j = 0; j < BT; ++j) acc[j] = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float* zt = Z + (((int64_t)t * B + b0) * N + n) * G;
-            const float* ht = hn + (int64_t)t * G * F + f;
-            for (int g = 0; g < G; ++g) {
-                const float w = ht[(int64_t)g * F];
+    for (int k = 0; k < 4; ++k) fk[k] = min(fq + k * FQ, F - 1);
+    for (int b0 = 0; b0 < s.B; b0 += BCH) {
+        const int nb = min(BCH, s.B - b0);
+        float acc[4][4];
 #pragma unroll
-                for (int j = 0; j < BT; ++j) {
-                    const float z = (b0 + j < B) ? zt[(int64_t)j * N * G + g] : 0.f;
-                    acc[j] = fmaf(z, w, acc[j]);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+        const bool active = 4 * bq < nb;
+        for (int c0 = 0; c0 < TG; c0 += CC) {
+            const int nc = min(CC, TG - c0);
+            __syncthreads();
+            for (int i = tid; i < nc * F; i += 256) Hs[i] = hn[(int64_t)c0 * F + i];
+            for (int i = tid; i < nb * nc; i += 256) {
+                const int b = i / nc, c = i - b * nc;
+                As[b * (CC + 1) + c] = *nv_zrow(Z, s, n, c0 + c, b0 + b);
+            }
+            __syncthreads();
+            if (active) {
+                const float* a0 = As + min(4 * bq + 0, nb - 1) * (CC + 1);
+                const float* a1 = As + min(4 * bq + 1, nb - 1) * (CC + 1);
+                const float* a2 = As + min(4 * bq + 2, nb - 1) * (CC + 1);
+                const float* a3 = As + min(4 * bq + 3, nb - 1) * (CC + 1);
+                for (int c = 0; c < nc; ++c) {
+                    const float av[4] = {a0[c], a1[c], a2[c], a3[c]};
+                    const float* hr = Hs + c * F;
+                    const float hv[4] = {hr[fk[0]], hr[fk[1]], hr[fk[2]], hr[fk[3]]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[i][k] = fmaf(av[i], hv[k], acc[i][k]);
                 }
             }
         }
-        const float bf = bias ? bias[f] : 0.f;
+        if (active) {
 #pragma unroll
-        for (int j = 0; j < BT; ++j)
-            if (b0 + j < B) Y[((int64_t)(b0 + j) * N + n) * F + f] = acc[j] + bf;
+            for (int i = 0; i < 4; ++i) {
+                const int b = 4 * bq + i;
+                if (b >= nb) break;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = fq + k * FQ;
+                    if (f < F) Y[((int64_t)(b0 + b) * s.N + n) * F + f] = acc[i][k] + (bias ? bias[f] : 0.f);
+                }
+            }
+        }
     }
 }
 
-// dZ[t][b][n][g] = sum_f dY[b][n][f] Ht[n][t][g][f]; thread -> (b, c = t*G + g), lanes along c: writes are unit-stride in g.
+// dZ[t][b][n][g] = sum_f D[b][f] H[c][f].  grid = (N, column chunks).
+// thread -> (bq, cq): samples 4 bq + i of the batch chunk, columns cq + k CQ (CQ = ceil(nc / 4)): lanes consecutive along c.
 __global__ __launch_bounds__(256) void nv_dz_kernel(const float* __restrict__ dY, const float* __restrict__ Ht,
-                                                    float* __restrict__ dZ, int B, int N, int G, int F, int T) {
-    const int n = blockIdx.x;
-    const int TG = T * G;
-    const float* hn = Ht + (int64_t)n * TG * F;
-    for (int idx = threadIdx.x; idx < B * TG; idx += blockDim.x) {
-        const int c = idx % TG, b = idx / TG;
-        const float* dy = dY + ((int64_t)b * N + n) * F;
-        const float* hr = hn + (int64_t)c * F;
-        float acc = 0.f;
-        for (int f = 0; f < F; ++f) acc = fmaf(dy[f], hr[f], acc);
-        const int t = c / G, g = c % G;
-        dZ[(((int64_t)t * B + b) * N + n) * G + g] = acc;
+                                                    float* __restrict__ dZ, NvShape s) {
+    extern __shared__ float sm[];
+    const int TG = s.T * s.G, F = s.F, CC = s.CC;
+    float* Hs = sm;                            // [CC][F + 1]: lanes walk down a column of H^T
+    float* Ds = sm + (size_t)CC * (F + 1);     // [BCH][F]
+    const int n = blockIdx.x, c0 = blockIdx.y * CC, tid = threadIdx.x;
+    const int nc = min(CC, TG - c0);
+    const int CQ = (nc + 3) / 4;
+    const int BCH = min(nv_dz_batch(F), 4 * (256 / CQ));
+    const int cq = tid % CQ, bq = tid / CQ;
+    const float* hn = Ht + ((int64_t)n * TG + c0) * F;
+    for (int i = tid; i < nc * F; i += 256) {
+        const int c = i / F, f = i - c * F;
+        Hs[c * (F + 1) + f] = hn[i];
+    }
+    const float* h0 = Hs + min(cq + 0 * CQ, nc - 1) * (F + 1);
+    const float* h1 = Hs + min(cq + 1 * CQ, nc - 1) * (F + 1);
+    const float* h2 = Hs + min(cq + 2 * CQ, nc - 1) * (F + 1);
+    const float* h3 = Hs + min(cq + 3 * CQ, nc - 1) * (F + 1);
+    for (int b0 = 0; b0 < s.B; b0 += BCH) {
+        const int nb = min(BCH, s.B - b0);
+        __syncthreads();
+        for (int i = tid; i < nb * F; i += 256) {
+            const int b = i / F, f = i - b * F;
+            Ds[i] = dY[((int64_t)(b0 + b) * s.N + n) * F + f];
+        }
+        __syncthreads();
+        if (4 * bq < nb) {
+            float acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+            const float* d0 = Ds + min(4 * bq + 0, nb - 1) * F;
+            const float* d1 = Ds + min(4 * bq + 1, nb - 1) * F;
+            const float* d2 = Ds + min(4 * bq + 2, nb - 1) * F;
+            const float* d3 = Ds + min(4 * bq + 3, nb - 1) * F;
+            for (int f = 0; f < F; ++f) {
+                const float dv[4] = {d0[f], d1[f], d2[f], d3[f]};
+                const float hv[4] = {h0[f], h1[f], h2[f], h3[f]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[i][k] = fmaf(dv[i], hv[k], acc[i][k]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = 4 * bq + i;
+                if (b >= nb) break;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = cq + k * CQ;
+                    if (c < nc) {
+                        const int cc = c0 + c, t = cc / s.G, g = cc - t * s.G;
+                        dZ[(((int64_t)t * s.B + b0 + b) * s.N + n) * s.G + g] = acc[i][k];
+                    }
+                }
+            }
+        }
     }
 }
 
-// dHt[n][c][f] = sum_b Z[t][b][n][g] dY[b][n][f]; thread -> (c, f), lanes along f; fixed summation order over b.
+// dHt[n][c][f] = sum_b A[b][c] D[b][f], b ascending (fixed order).  grid = (N, column chunks); CC <= 4 * (256 / FQ).
+// thread -> (cq, fq): columns 4 cq + i of the chunk, features fq + k FQ.
 __global__ __launch_bounds__(256) void nv_dbank_kernel(const float* __restrict__ Z, const float* __restrict__ dY,
-                                                       float* __restrict__ dHt, int B, int N, int G, int F, int T) {
-    const int n = blockIdx.x;
-    const int TG = T * G;
-    for (int idx = threadIdx.x; idx < TG * F; idx += blockDim.x) {
-        const int f = idx % F, c = idx / F;
-        const int t = c / G, g = c % G;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            acc = fmaf(Z[(((int64_t)t * B + b) * N + n) * G + g], dY[((int64_t)b * N + n) * F + f], acc);
-        dHt[((int64_t)n * TG + c) * F + f] = acc;
+                                                       float* __restrict__ dHt, NvShape s) {
+    extern __shared__ float sm[];
+    const int TG = s.T * s.G, F = s.F, CC = s.CC;
+    float* As = sm;                            // [NV_BC][CC]
+    float* Ds = sm + (size_t)NV_BC * CC;       // [NV_BC][F]
+    const int n = blockIdx.x, c0 = blockIdx.y * CC, tid = threadIdx.x;
+    const int nc = min(CC, TG - c0);
+    const int FQ = (F + 3) / 4;
+    const int fq = tid % FQ, cq = tid / FQ;
+    const bool active = 4 * cq < nc;
+    int ci[4], fk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ci[i] = min(4 * cq + i, nc - 1);
+        fk[i] = min(fq + i * FQ, F - 1);
+    }
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+    for (int b0 = 0; b0 < s.B; b0 += NV_BC) {
+        const int nb = min(NV_BC, s.B - b0);
+        __syncthreads();
+        for (int i = tid; i < nb * nc; i += 256) {
+            const int b = i / nc, c = i - b * nc;
+            As[b * CC + c] = *nv_zrow(Z, s, n, c0 + c, b0 + b);
+        }
+        for (int i = tid; i < nb * F; i += 256) {
+            const int b = i / F, f = i - b * F;
+            Ds[i] = dY[((int64_t)(b0 + b) * s.N + n) * F + f];
+        }
+        __syncthreads();
+        if (active) {
+            for (int b = 0; b < nb; ++b) {
+                const float* ar = As + b * CC;
+                const float* dr = Ds + b * F;
+                const float av[4] = {ar[ci[0]], ar[ci[1]], ar[ci[2]], ar[ci[3]]};
+                const float dv[4] = {dr[fk[0]], dr[fk[1]], dr[fk[2]], dr[fk[3]]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[i][k] = fmaf(av[i], dv[k], acc[i][k]);
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * cq + i;
+            if (c >= nc) break;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = fq + k * FQ;
+                if (f < F) dHt[((int64_t)n * TG + c0 + c) * F + f] = acc[i][k];
+            }
+        }
+    }
+}
+
+// out[r][m] = sum over the nodes n of group m (ascending) of dh[r][n]: the adjoint of NodeVariantGF's tap expansion
+// h = weight[..., copyNodes] (graphML.py:2485), as a gather in fixed order instead of an atomic scatter.
+__global__ __launch_bounds__(256) void nv_fold_kernel(const float* __restrict__ dh, const int32_t* __restrict__ grp_ptr,
+                                                      const int32_t* __restrict__ grp_idx, float* __restrict__ out, int N, int M,
+                                                      int staged) {
+    extern __shared__ float rowbuf[];  // the row, read once with unit stride; the group gathers then hit LDS
+    const float* row = dh + (int64_t)blockIdx.x * N;
+    if (staged) {
+        for (int i = threadIdx.x; i < N; i += 256) rowbuf[i] = row[i];
+        __syncthreads();
+    }
+    for (int m = threadIdx.x; m < M; m += 256) {
+        float a = 0.f;
+        if (staged)
+            for (int i = grp_ptr[m]; i < grp_ptr[m + 1]; ++i) a += rowbuf[grp_idx[i]];
+        else
+            for (int i = grp_ptr[m]; i < grp_ptr[m + 1]; ++i) a += row[grp_idx[i]];
+        out[(int64_t)blockIdx.x * M + m] = a;
     }
 }
 
@@ -141,6 +315,19 @@ __global__ __launch_bounds__(256) void nv_add_kernel(float* __restrict__ dst, co
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = i; j < count; j += stride) dst[j] += src[j];
 }
+
+// bank columns per chunk: nv_dbank_kernel covers a chunk with 4 x 4 tiles, (CC / 4) * ceil(F / 4) <= 256 threads; balanced over the chunks
+NvShape nv_shape(int B, int N, int G, int F, int T) {
+    const int TG = T * G;
+    int cap = 4 * (256 / ((F + 3) / 4));
+    if (cap > 96) cap = 96;
+    const int chunks = (TG + cap - 1) / cap;
+    NvShape s{B, N, G, F, T, (TG + chunks - 1) / chunks};
+    return s;
+}
+size_t nv_lds_contract(const NvShape& s) { return ((size_t)s.CC * s.F + (size_t)128 * (s.CC + 1)) * 4; }
+size_t nv_lds_dz(const NvShape& s) { return ((size_t)s.CC * (s.F + 1) + (size_t)nv_dz_batch(s.F) * s.F) * 4; }
+size_t nv_lds_dbank(const NvShape& s) { return ((size_t)NV_BC * s.CC + (size_t)NV_BC * s.F) * 4; }
 
 int check_plans(const gf_plan* const* plans, int E, const char* who) {
     GF_REQUIRE_ARG(plans && E > 0 && plans[0], "%s: NULL plans", who);
@@ -183,7 +370,9 @@ extern "C" int gf_nvgf_forward(const gf_plan* const* plans, int32_t E, const flo
     GF_REQUIRE_SHAPE(T * G <= 65535, "gf_nvgf_forward: T*G = %d > 65535", T * G);
     hipLaunchKernelGGL(nv_bank_in_kernel, dim3((N + TT - 1) / TT, (F + TT - 1) / TT, T * G), dim3(TT, 8), 0, st, h, Ht, F, E, K, G, N);
     GF_LAUNCH_CHECK("nv_bank_in_kernel");
-    hipLaunchKernelGGL(nv_contract_kernel<4>, dim3(N), dim3(256), 0, st, Z, Ht, bias, Y, B, N, G, F, T);
+    const NvShape shp = nv_shape(B, N, G, F, T);
+    GF_REQUIRE_SHAPE(F <= 256, "gf_nvgf_forward: F = %d > 256", F);   // nv_contract_kernel keeps NV_BC * F / 256 outputs per thread
+    hipLaunchKernelGGL(nv_contract_kernel, dim3(N), dim3(256), nv_lds_contract(shp), st, Z, Ht, bias, Y, shp);
     GF_LAUNCH_CHECK("nv_contract_kernel");
     return gf_layout_bng_to_bgn(Y, y, B, F, N, Nin, stream);
 }
@@ -209,8 +398,12 @@ extern "C" int gf_nvgf_backward(const gf_plan* const* plans, int32_t E, const fl
     float* tmp = dZ + (size_t)T * tap;
     rc = gf_layout_bgn_to_bng(dy, dY, B, F, Nin, N, stream);  // rows >= Nin zero: dropped outputs carry no gradient
     if (rc != GF_OK) return rc;
+    const NvShape shp = nv_shape(B, N, G, F, T);
+    GF_REQUIRE_SHAPE(F <= 256, "gf_nvgf_backward: F = %d > 256", F);
+    const int chunks = (T * G + shp.CC - 1) / shp.CC;
+    GF_REQUIRE_SHAPE(chunks <= 65535, "gf_nvgf_backward: %d column chunks", chunks);
     if (dh) {
-        hipLaunchKernelGGL(nv_dbank_kernel, dim3(N), dim3(256), 0, st, Z, dY, dHt, B, N, G, F, T);
+        hipLaunchKernelGGL(nv_dbank_kernel, dim3(N, chunks), dim3(256), nv_lds_dbank(shp), st, Z, dY, dHt, shp);
         GF_LAUNCH_CHECK("nv_dbank_kernel");
         hipLaunchKernelGGL(nv_bank_out_kernel, dim3((N + TT - 1) / TT, (F + TT - 1) / TT, E * K * G), dim3(TT, 8), 0, st, dHt, dh,
                            F, E, K, G, N);
@@ -219,7 +412,7 @@ extern "C" int gf_nvgf_backward(const gf_plan* const* plans, int32_t E, const fl
     if (dx) {
         hipLaunchKernelGGL(nv_bank_in_kernel, dim3((N + TT - 1) / TT, (F + TT - 1) / TT, T * G), dim3(TT, 8), 0, st, h, Ht, F, E, K, G, N);
         GF_LAUNCH_CHECK("nv_bank_in_kernel");
-        hipLaunchKernelGGL(nv_dz_kernel, dim3(N), dim3(256), 0, st, dY, Ht, dZ, B, N, G, F, T);
+        hipLaunchKernelGGL(nv_dz_kernel, dim3(N, chunks), dim3(256), nv_lds_dz(shp), st, dY, Ht, dZ, shp);
         GF_LAUNCH_CHECK("nv_dz_kernel");
         const int addBlocks = (int)((tap + 255) / 256 < 4096 ? (tap + 255) / 256 : 4096);
         for (int e = 0; e < E; ++e)
@@ -234,4 +427,16 @@ extern "C" int gf_nvgf_backward(const gf_plan* const* plans, int32_t E, const fl
         rc = gf_layout_bng_to_bgn(dZ, dx, B, G, N, Nin, stream);
     }
     return rc;
+}
+
+// dweight[R, M] from dh[R, N] (R = F*E*K*G rows): groups = the nodes that copy tap node m, DEVICE int32 CSR (grp_ptr [M+1], grp_idx)
+extern "C" int gf_nvgf_fold_taps(const float* dh, const int32_t* grp_ptr, const int32_t* grp_idx, float* dweight, int64_t R,
+                                 int32_t N, int32_t M, void* stream) {
+    GF_REQUIRE_ARG(dh && grp_ptr && grp_idx && dweight, "gf_nvgf_fold_taps: NULL argument");
+    GF_REQUIRE_SHAPE(R > 0 && R <= 2147483647 && N > 0 && M > 0, "gf_nvgf_fold_taps: bad shape R=%lld N=%d M=%d", (long long)R, N, M);
+    const int staged = (size_t)N * 4 <= 64 * 1024;
+    hipLaunchKernelGGL(nv_fold_kernel, dim3((unsigned)R), dim3(256), staged ? (size_t)N * 4 : 0, gf_stream(stream), dh, grp_ptr, grp_idx,
+                       dweight, N, M, staged);
+    GF_LAUNCH_CHECK("nv_fold_kernel");
+    return GF_OK;
 }

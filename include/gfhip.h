@@ -174,6 +174,11 @@ int gf_nvgf_forward(const gf_plan* const* plans, int32_t E, const float* x, cons
                     float* scratch, size_t scratch_floats, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
 int gf_nvgf_backward(const gf_plan* const* plans, int32_t E, const float* dy, const float* Z, const float* h, float* dx, float* dh,
                      float* scratch, size_t scratch_floats, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
+/* adjoint of NodeVariantGF's tap expansion h = weight[..., copyNodes] (graphML.py:2485; autograd's index_add there):
+ * dweight [R, M] = sum of dh [R, N] over the nodes that copy tap node m, R = F*E*K*G.  DEVICE int32 CSR of the groups:
+ * grp_ptr [M+1], grp_idx [N] (nodes of group m ascending) -- a gather in fixed order, no atomics. */
+int gf_nvgf_fold_taps(const float* dh, const int32_t* grp_ptr, const int32_t* grp_idx, float* dweight, int64_t R, int32_t N,
+                      int32_t M, void* stream);
 
 /* ---- GraphFilter followed by sigma = ReLU (SelectionGNN layers, architectures.py:286-289): y = max(0, LSIGF(...)) fused into the
  * contraction's epilogue; backward takes the saved output y [B,F,Nin] and applies the mask (y > 0) to dy on the way in. */
