@@ -4,7 +4,11 @@ Layout mirrors the reference package so that call sites read the same:
     alegnn.utils.graphML.GraphFilter            ->  alegnn_amd.utils.graphML.GraphFilter
     alegnn.utils.graphML.LSIGF                  ->  alegnn_amd.utils.graphML.LSIGF
     alegnn.utils.graphML.EdgeVariantGF          ->  alegnn_amd.utils.graphML.EdgeVariantGF
-    alegnn.modules.architectures.SelectionGNN   ->  alegnn_amd.modules.architectures.SelectionGNN
+    alegnn.utils.graphML.NodeVariantGF / NVGF   ->  alegnn_amd.utils.graphML.NodeVariantGF / NVGF
+    alegnn.utils.graphML.HiddenState / GatedGRNN->  alegnn_amd.utils.graphML.HiddenState / GatedGRNN
+    alegnn.modules.architectures.SelectionGNN   ->  alegnn_amd.modules.architectures.SelectionGNN   (+ LocalGNN, NodeVariantGNN,
+                                                                                                     GraphRecurrentNN)
+    alegnn.modules.{model,training,evaluation,loss} ->  alegnn_amd.modules.{model,training,evaluation,loss}  (Trainer with batch DP)
 `install(reference_gml)` rebinds the reference's own symbols.
 """
 from .functional import EVGF_edges, LSIGF
@@ -22,4 +26,8 @@ def install(reference_graphML_module):
     reference_graphML_module.GraphFilter = amd_gml.GraphFilter
     reference_graphML_module.LSIGF = amd_gml.LSIGF
     reference_graphML_module.EdgeVariantGF = amd_gml.EdgeVariantGF      # architectures.py:1877, 2111
+    reference_graphML_module.NVGF = amd_gml.NVGF
+    reference_graphML_module.NodeVariantGF = amd_gml.NodeVariantGF      # architectures.py:1630
+    reference_graphML_module.GatedGRNN = amd_gml.GatedGRNN              # graphML.py:3642, 3810, 3985, 4163 (the HiddenState family)
+    reference_graphML_module.HiddenState = amd_gml.HiddenState          # architectures.py:4497
     return reference_graphML_module
