@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import types
 
 import numpy as np
 import pytest
@@ -471,3 +472,82 @@ def test_node_variant_gnn_surface_matches_reference():
     assert list(net.state_dict().keys()) == list(ref.keys())
     net.load_state_dict(ref, strict=True)
     assert net.N == [100, 40, 10] and isinstance(net.NVGFL[0], gml.NodeVariantGF) and net.NVGFL[3].M == 5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/alegnn"), reason="needs the reference checkout (build container only)")
+def test_install_rebinds_the_reference_symbols():
+    """alegnn_amd.install(gml): the reference's own architectures then build on the HIP layers (construction only here -- the
+    forward needs a GPU; tests/test_gpu_parity.py runs the same layers against the reference's outputs)."""
+    import subprocess
+    import sys
+    code = """
+import sys, types
+for mod in ("hdf5storage", "gensim"):
+    sys.modules[mod] = types.ModuleType(mod)
+import numpy as np, scipy.sparse
+np.int = int; np.float = float
+sys.path[:0] = ["/root/reference", %r]
+import torch
+import alegnn.utils.graphML as gml, alegnn.modules.architectures as archit
+import alegnn_amd
+from alegnn_amd.utils import graphML as amd
+alegnn_amd.install(gml)
+S = np.eye(12, k=1) + np.eye(12, k=-1)
+net = archit.SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [6], gml.NoPool, [1], [2], S)
+assert type(net.GFL[0]) is amd.GraphFilter
+nv = archit.NodeVariantGNN([1, 8], [3], [4], True, torch.nn.ReLU, [12], gml.NoPool, [1], [2], S)
+assert type(nv.NVGFL[0]) is amd.NodeVariantGF and nv.NVGFL[0].copyNodes.shape[0] == 12
+rn = archit.GraphRecurrentNN(2, 3, 4, [3, 2], True, torch.tanh, torch.tanh, torch.nn.ReLU, [2], S)
+assert type(rn.hiddenState) is amd.HiddenState and type(rn.outputState) is amd.GraphFilter
+assert gml.LSIGF is amd.LSIGF and gml.NVGF is amd.NVGF and gml.GatedGRNN is amd.GatedGRNN
+print("OK")
+""" % os.path.join(ROOT, "graph-neural-networks_amd")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_trainer_single_node_uses_label_ids(tmp_path):
+    """TrainerSingleNode / evaluateSingleNode (training.py:580-714, evaluation.py:91-168): the loss is taken at one target node
+    per sample, looked up through data.getLabelID(split[, indices]) and archit.singleNodeForward(x, ids)."""
+    from alegnn_amd.modules import evaluation, loss, model, training
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(1, 1).double()
+
+        def forward(self, x):                                        # B x 1 x N -> B x 1 x N
+            return self.lin(x.permute(0, 2, 1)).permute(0, 2, 1)
+
+        def singleNodeForward(self, x, nodes):
+            y = self.forward(x)
+            return y[torch.arange(x.shape[0]), :, torch.as_tensor(nodes)]
+
+    class Data:
+        def __init__(self):
+            g = torch.Generator().manual_seed(3)
+            self.x = {s: torch.randn(n, 1, 6, generator=g).double() for s, n in (("train", 10), ("valid", 4), ("test", 4))}
+            self.ids = {s: torch.randint(0, 6, (v.shape[0],), generator=g).numpy() for s, v in self.x.items()}
+            self.y = {s: 2.0 * v[torch.arange(v.shape[0]), 0, torch.as_tensor(self.ids[s])] + 1.0 for s, v in self.x.items()}
+            self.nTrain = 10
+
+        def getSamples(self, split, *a):
+            return (self.x[split][a[0]], self.y[split][a[0]]) if a else (self.x[split], self.y[split])
+
+        def getLabelID(self, split, *a):
+            return self.ids[split][a[0]] if a else self.ids[split]
+
+        def evaluate(self, yHat, y):
+            return torch.sqrt(torch.mean((yHat.squeeze(-1) - y) ** 2))
+
+    net, data = Net(), Data()
+    optim = torch.optim.SGD(net.parameters(), lr=0.05)
+    m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.MSELoss), optim, training.TrainerSingleNode,
+                    evaluation.evaluateSingleNode, 'cpu', 'sn', str(tmp_path))
+    np.random.seed(0)
+    tv = m.train(data, 40, 5, printInterval=0, doSaveVars=False)
+    assert tv["lossTrain"][-1] < 0.05 * tv["lossTrain"][0]          # y = 2 x[target] + 1 is learnt only if the right node is read
+    ev = m.evaluate(data, doSaveVars=False)
+    assert ev["costBest"] < 0.2 and set(ev) == {"costBest", "costLast"}
+    with pytest.raises(AssertionError):                              # an architecture without singleNodeForward is refused
+        training.TrainerSingleNode(types.SimpleNamespace(archit=torch.nn.Linear(1, 1)), data, 1, 5)
