@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64, help="batch entries of the workload timed on the CPU")
     ap.add_argument("--detail", action="store_true", help="per-kernel timings to stderr")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2], help="0 auto | 1 node-major (L2 gathers) | 2 column panels (LDS gathers)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="gf_tune knob for experiments (repeatable)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,6 +81,9 @@ def main():
 
     if args.pipeline:
         _lib.check(_lib.lib().gf_tune(b"pipeline", args.pipeline), "gf_tune pipeline")
+    for kv in args.tune:
+        key, val = kv.split("=")
+        _lib.check(_lib.lib().gf_tune(key.encode(), int(val)), "gf_tune " + key)
     wl = WORKLOADS[args.workload]
     N, B, G, F, K = wl["N"], wl["B"], wl["G"], wl["F"], wl["K"]
     A = (graphgen.sbm if wl["model"] == "sbm" else graphgen.er)(N, avg_degree=wl["deg"], seed=0)

@@ -53,6 +53,8 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     const int nGroups = (nPanels + NP - 1) / NP;  // passes: NP panels each
     int p = blockIdx.x;
     if (p >= nGroups) return;  // whole workgroup
+    const int dbg = debug & 7;       // timing experiments (see gf_common.h)
+    const bool dma = (debug & 8) != 0;  // panel load phase through LDS-DMA
     f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
     typedef typename ColWord<UNIFORM>::type colw;
     const colw* col4 = reinterpret_cast<const colw*>(cols) + lane;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
         const float* srcp = (h == 0 ? Xin : Xout + (int64_t)(h - 1) * tapStride) + (int64_t)p * NP * pstride;
         float* outp = Xout + (int64_t)h * tapStride + (int64_t)p * NP * pstride;
         const int nvalid = min(NP, nPanels - p * NP);  // panels of this pass (the last pass may be short)
-        if (debug != 2 && debug != 3 && debug != 4) {
+        if (dbg != 2 && dbg != 3 && dbg != 4) {
             // HBM-bound phase: every wave loads its share of the panel (N <= kNVU * blockDim.x rows of 16 bytes).
             // (Requesting the NEXT panel from inside the compute phase instead -- registers, one HBM-latency stall per wave
             // and panel -- was measured and gave nothing: 184 vs 181 us; a CU pulls at most ~22 GB/s from HBM and the
@@ -111,6 +113,19 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
             for (int k = 0; k < NP; ++k) {
                 if (k >= nvalid) break;
                 const f32x4* src = reinterpret_cast<const f32x4*>(srcp + (int64_t)k * pstride);
+                if (dma) {
+                    // LDS-DMA: the wave's 64 rows land as 1 KiB at a wave-uniform LDS base (+ lane * 16), no staging registers and
+                    // no ds_write pass
+                    typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+                    for (int j = 0; j < kNVU; ++j) {
+                        const int row0 = wave * 64 + j * nthr;  // wave-uniform
+                        if (row0 + lane < N)
+                            __builtin_amdgcn_global_load_lds(src + row0 + lane,
+                                                             (lds_void*)(uintptr_t)((unsigned)(k * (N + 1) + row0) * 16u), 16, 0, 0);
+                    }
+                    continue;
+                }
                 f32x4 tmp[kNVU];
 #pragma unroll
                 for (int j = 0; j < kNVU; ++j) tmp[j] = src[min(tid + j * nthr, N - 1)];  // (a non-temporal hint here: no effect)
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
             }
         }
         __syncthreads();  // B1: panel p is in LDS
-        if (wave < nSlices && debug != 1) {
+        if (wave < nSlices && dbg != 1) {
             int s = wave;                       // slice in hand
             // Workgroups walk the slice list rotated by a workgroup-specific offset: at any moment the 256 CUs read different parts
             // of the (shared, L2-resident) entry arrays instead of queueing on the same L2 channels.
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 // next chunk: same slice (group-rows per slice are even: a chunk never straddles two blocks), or the head of
                 // the next slice (the sentinel rows when it is empty / absent)
                 int gnext = same ? si.x + j0 + kGC : (sin.y > 0 ? sin.x : sentinel);
-                if (debug == 3) gnext = sentinel;  // timing experiment: every entry load hits the same (L1-resident) sentinel rows
+                if (dbg == 3) gnext = sentinel;  // timing experiment: every entry load hits the same (L1-resident) sentinel rows
                 load_chunk(cn, vn, gnext);
 #pragma unroll
                 for (int g = 0; g < kGC; ++g) {
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                     return false;
                 }
                 const int row = (oc << ush) + (lane & ((1 << ush) - 1));
-                if (oc >= 0 && row < N && !(debug == 4 && acc0[0].x != 12345.678f)) {  // debug 4: no stores (timing experiment)
+                if (oc >= 0 && row < N && !(dbg == 4 && acc0[0].x != 12345.678f)) {  // debug 4: no stores (timing experiment)
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         if (k >= nvalid) break;
@@ -338,7 +353,7 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
                           : (uniform ? (kern_t)spmm_panel_kernel<1, 1> : (kern_t)spmm_panel_kernel<0, 1>);
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug, wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride, g_tune.panel_rotate);
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug | (g_tune.panel_dma ? 8 : 0), wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride, g_tune.panel_rotate);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }

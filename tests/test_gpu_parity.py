@@ -579,6 +579,9 @@ def test_edge_variant_gf_matches_reference_golden(path):
     dict(N=500, B=5, G=4, F=12, K=4, M=200, directed=True),         # odd batch, hybrid pattern
     dict(N=300, B=70, G=3, F=5, K=2, M=300, directed=False),        # batch > one wavefront
     dict(N=2000, B=16, G=32, F=32, K=3, M=2000, directed=False),    # config-5 widths
+    dict(N=400, B=12, G=4, F=6, K=3, M=150, directed=True),         # 16-byte gathers, 3 of 4 lanes per row active, hybrid
+    dict(N=300, B=64, G=4, F=4, K=4, M=300, directed=True),         # 16 lanes per row
+    dict(N=200, B=132, G=2, F=3, K=2, M=200, directed=False),       # 33 quads per row: 64-lane groups, partly idle
 ], ids=lambda c: "_".join(f"{k}{v}" for k, v in c.items()))
 def test_evgf_per_edge_storage_vs_oracle(cfg):
     N, B, G, F, K, M = (cfg[k] for k in "NBGFKM")
