@@ -153,14 +153,19 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds_kernel(const int32_t* __r
                                                               const int32_t* __restrict__ vidx, const float* __restrict__ wedge,
                                                               const float* __restrict__ in, const float* __restrict__ add,
                                                               float* __restrict__ out, int N, int B, int G, int K1, int kidx,
-                                                              int64_t nnzp, int in_div, int add_div, int nRowBlocks) {
+                                                              int64_t nnzp, int in_div, int add_div, int nRowBlocks, int nChains) {
     constexpr int RPP = kThreads / LB;  // rows per pass
     constexpr int RPW = RPP > kRowsPerWG ? RPP : kRowsPerWG;  // rows per workgroup
     __shared__ int32_t s_col[kEvChunk];
     __shared__ float s_w[kEvChunk];
     const int64_t NB = (int64_t)N * B;
-    const int c = blockIdx.x / nRowBlocks;            // chain-major: the workgroups in flight share a gather panel in L2
-    const int rb = blockIdx.x - c * nRowBlocks;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own 4 MB L2: chain c lives on XCD
+    // c % 8, whose workgroups walk its row blocks in order -- one gather panel (N*B*4 bytes) per L2 at a time instead of the
+    // panels of all chains in flight in every L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int c = (slot / nRowBlocks) * 8 + xcd;
+    const int rb = slot % nRowBlocks;
+    if (c >= nChains) return;
     const int r0 = rb * RPW, r1 = min(N, r0 + RPW);
     const int f = c / G, g = c - f * G;
     const float* W = wedge + ((int64_t)(f * K1 + kidx) * G + g) * nnzp;
@@ -219,14 +224,16 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __
                                                                const int32_t* __restrict__ vidx, const float* __restrict__ wedge,
                                                                const float* __restrict__ in, const float* __restrict__ add,
                                                                float* __restrict__ out, int N, int B, int G, int K1, int kidx,
-                                                               int64_t nnzp, int in_div, int add_div, int nRowBlocks) {
+                                                               int64_t nnzp, int in_div, int add_div, int nRowBlocks, int nChains) {
     constexpr int RPP = kThreads / LQ;
     constexpr int RPW = RPP > kRowsPerWG ? RPP : kRowsPerWG;
     __shared__ int32_t s_col[kEvChunk];
     __shared__ float s_w[kEvChunk];
     const int64_t NB = (int64_t)N * B;
-    const int c = blockIdx.x / nRowBlocks;
-    const int rb = blockIdx.x - c * nRowBlocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;  // chain c on XCD c % 8 (see ev_hop_lds_kernel)
+    const int c = (slot / nRowBlocks) * 8 + xcd;
+    const int rb = slot % nRowBlocks;
+    if (c >= nChains) return;
     const int r0 = rb * RPW, r1 = min(N, r0 + RPW);
     const int f = c / G, g = c - f * G;
     const float* W = wedge + ((int64_t)(f * K1 + kidx) * G + g) * nnzp;
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __
         if (base != seg_lo) __syncthreads();
         for (int i = tid; i < cnt; i += kThreads) {
             s_col[i] = col[base + i];
-            s_w[i] = W[vidx ? vidx[base + i] : base + i];
+            s_w[i] = W[vidx ? vidx[base + i] : base + i];  // (non-temporal loads / stores of the streams: measured slower)
         }
         __syncthreads();
         if (b < B) {
@@ -317,17 +324,24 @@ template <int LB>
 __global__ __launch_bounds__(kThreads) void ev_sddmm_kernel(const int32_t* __restrict__ row, const int32_t* __restrict__ col,
                                                             const float* __restrict__ U, const float* __restrict__ V,
                                                             float* __restrict__ dwedge, int N, int B, int G, int K1, int kidx,
-                                                            int64_t nnzp, int u_div, int64_t groups) {
+                                                            int64_t nnzp, int u_div, int64_t nChains) {
     const int64_t NB = (int64_t)N * B;
     const int lane = threadIdx.x % LB;
-    const int64_t g0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LB;
-    const int64_t gstep = (int64_t)gridDim.x * kThreads / LB;
-    // EPG consecutive pattern entries of one chain per lane group and round: their (row, col) pairs are loaded first, then
-    // the 2*EPG gathers, then the fixed-order reductions -- one entry per round is three dependent L2 round trips.
-    constexpr int EPG = 4;
+    constexpr int EPG = 4;   // consecutive pattern entries of one chain per lane group and round: their (row, col) pairs are loaded
+                             // first, then the 2*EPG gathers, then the fixed-order reductions
+    constexpr int GPB = kThreads / LB, ROUNDS = 4;   // lane groups per workgroup, entry quads per lane group
     const int64_t epc = (nnzp + EPG - 1) / EPG;  // entry quads per chain
-    for (int64_t grp = g0; grp < groups; grp += gstep) {  // whole LB-lane groups leave the loop together
-        const int64_t c = grp / epc, p0 = (grp - c * epc) * EPG;
+    const int64_t bpc = (epc + GPB * ROUNDS - 1) / (GPB * ROUNDS);  // workgroups per chain
+    // chain c on XCD c % 8 (blockIdx % 8), its entry quads in order: one gather panel V[c] per L2 at a time (see ev_hop_lds_kernel)
+    const int xcd = blockIdx.x & 7;
+    const int64_t slot = blockIdx.x >> 3;
+    const int64_t c = (slot / bpc) * 8 + xcd;
+    if (c >= nChains) return;
+    const int64_t q0 = (slot % bpc) * (GPB * ROUNDS) + threadIdx.x / LB;
+    for (int r = 0; r < ROUNDS; ++r) {  // whole lane groups leave the loop together
+        const int64_t quad = q0 + (int64_t)r * GPB;
+        if (quad >= epc) break;
+        const int64_t p0 = quad * EPG;
         const float* ub = U + (c / u_div) * NB;
         const float* vb = V + c * NB;
         int ri[EPG], ci[EPG];
@@ -366,15 +380,24 @@ template <int LQ>
 __global__ __launch_bounds__(kThreads) void ev_sddmm4_kernel(const int32_t* __restrict__ row, const int32_t* __restrict__ col,
                                                              const float* __restrict__ U, const float* __restrict__ V,
                                                              float* __restrict__ dwedge, int N, int B, int G, int K1, int kidx,
-                                                             int64_t nnzp, int u_div, int64_t groups) {
+                                                             int64_t nnzp, int u_div, int64_t nChains) {
     const int64_t NB = (int64_t)N * B;
     const int lane = threadIdx.x % LQ;
-    const int64_t g0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LQ;
-    const int64_t gstep = (int64_t)gridDim.x * kThreads / LQ;
-    constexpr int EPG = 4;
-    const int64_t epc = (nnzp + EPG - 1) / EPG;
-    for (int64_t grp = g0; grp < groups; grp += gstep) {
-        const int64_t c = grp / epc, p0 = (grp - c * epc) * EPG;
+    constexpr int EPG = 4;   // consecutive pattern entries of one chain per lane group and round: their (row, col) pairs are loaded
+                             // first, then the 2*EPG gathers, then the fixed-order reductions
+    constexpr int GPB = kThreads / LQ, ROUNDS = 4;   // lane groups per workgroup, entry quads per lane group
+    const int64_t epc = (nnzp + EPG - 1) / EPG;  // entry quads per chain
+    const int64_t bpc = (epc + GPB * ROUNDS - 1) / (GPB * ROUNDS);  // workgroups per chain
+    // chain c on XCD c % 8 (blockIdx % 8), its entry quads in order: one gather panel V[c] per L2 at a time (see ev_hop_lds_kernel)
+    const int xcd = blockIdx.x & 7;
+    const int64_t slot = blockIdx.x >> 3;
+    const int64_t c = (slot / bpc) * 8 + xcd;
+    if (c >= nChains) return;
+    const int64_t q0 = (slot % bpc) * (GPB * ROUNDS) + threadIdx.x / LQ;
+    for (int r = 0; r < ROUNDS; ++r) {  // whole lane groups leave the loop together
+        const int64_t quad = q0 + (int64_t)r * GPB;
+        if (quad >= epc) break;
+        const int64_t p0 = quad * EPG;
         const float* ub = U + (c / u_div) * NB;
         const float* vb = V + c * NB;
         int ri[EPG], ci[EPG];
@@ -477,17 +500,17 @@ int launch_ev_hop(const int32_t* rowptr, const int32_t* col, const int32_t* vidx
     const int lbw = lanes_for_batch(B);
     const int rpw = std::max(kRowsPerWG, kThreads / lbw);  // rows per workgroup (RPW of ev_hop_lds_kernel)
     const int nRowBlocks = (N + rpw - 1) / rpw;
-    const int64_t nblk = (int64_t)C * nRowBlocks;
+    const int64_t nblk = (int64_t)((C + 7) / 8) * 8 * nRowBlocks;
     static const int env_generic = getenv("GFHIP_EVGF_GENERIC") ? atoi(getenv("GFHIP_EVGF_GENERIC")) : 0;
     if (B % 4 == 0 && B <= 256 && env_generic == 0) {  // 16-byte gathers: 4 batch entries per thread
         const int lq = lanes_for_batch(B / 4);
         const int rpw4 = std::max(kRowsPerWG, kThreads / lq);
         const int nrb4 = (N + rpw4 - 1) / rpw4;
-        const int64_t nblk4 = (int64_t)C * nrb4;
+        const int64_t nblk4 = (int64_t)((C + 7) / 8) * 8 * nrb4;
         if (nblk4 < (int64_t)INT32_MAX) {
 #define GF_EVHOP4(LQV)                                                                                                        \
     hipLaunchKernelGGL((ev_hop_lds4_kernel<LQV>), dim3((unsigned)nblk4), dim3(kThreads), 0, st, rowptr, col, vidx, wedge, in, add, out, \
-                       N, B, G, K1, kidx, nnzp, in_div, add_div, nrb4)
+                       N, B, G, K1, kidx, nnzp, in_div, add_div, nrb4, C)
             switch (lq) {
                 case 1: GF_EVHOP4(1); break;
                 case 2: GF_EVHOP4(2); break;
@@ -506,7 +529,7 @@ int launch_ev_hop(const int32_t* rowptr, const int32_t* col, const int32_t* vidx
         const int lb = lanes_for_batch(B);
 #define GF_EVHOP(LBV)                                                                                                         \
     hipLaunchKernelGGL((ev_hop_lds_kernel<LBV>), dim3((unsigned)nblk), dim3(kThreads), 0, st, rowptr, col, vidx, wedge, in, add, out, \
-                       N, B, G, K1, kidx, nnzp, in_div, add_div, nRowBlocks)
+                       N, B, G, K1, kidx, nnzp, in_div, add_div, nRowBlocks, C)
         switch (lb) {
             case 1: GF_EVHOP(1); break;
             case 2: GF_EVHOP(2); break;
@@ -677,14 +700,21 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
     const int lb = lanes_for_batch(B);
     for (int k = K - 1; k >= 1; --k) {
         if (dwedge) {
-            const int64_t groups = (int64_t)C * ((plan->nnzp + 3) / 4);  // entry quads (EPG = 4 in ev_sddmm_kernel)
+            const int64_t epc = (plan->nnzp + 3) / 4;  // entry quads per chain (EPG = 4 in ev_sddmm_kernel)
+            const int64_t chainSlots = (int64_t)((C + 7) / 8) * 8;  // chain c runs on XCD c % 8
+            auto sddmm_grid = [&](int lanes) {  // lane groups of `lanes` lanes, 4 quads each (ROUNDS)
+                const int64_t perWG = (int64_t)(kThreads / lanes) * 4;
+                return (unsigned)(chainSlots * ((epc + perWG - 1) / perWG));
+            };
+            GF_REQUIRE_SHAPE(chainSlots * ((epc + 3) / 4) < (int64_t)INT32_MAX, "gf_evgf_backward: %lld chains x %lld entries exceed the launch grid",
+                             (long long)C, (long long)plan->nnzp);
             static const int env_scalar = getenv("GFHIP_EVGF_GENERIC") ? atoi(getenv("GFHIP_EVGF_GENERIC")) : 0;
             if (B % 4 == 0 && B <= 256 && env_scalar == 0) {
                 const int lq = lanes_for_batch(B / 4);
-                const unsigned grid4 = grid_for(groups * lq);
+                const unsigned grid4 = sddmm_grid(lq);
 #define GF_SDDMM4(LQV)                                                                                                        \
     hipLaunchKernelGGL((ev_sddmm4_kernel<LQV>), dim3(grid4), dim3(kThreads), 0, st, plan->row, plan->col, Ucur,                \
-                       V + (int64_t)(k - 1) * CNB, dwedge, N, B, G, K - 1, k - 1, plan->nnzp, udiv, groups)
+                       V + (int64_t)(k - 1) * CNB, dwedge, N, B, G, K - 1, k - 1, plan->nnzp, udiv, (int64_t)C)
                 switch (lq) {
                     case 1: GF_SDDMM4(1); break;
                     case 2: GF_SDDMM4(2); break;
@@ -697,10 +727,10 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
 #undef GF_SDDMM4
                 GF_LAUNCH_CHECK("ev_sddmm4_kernel");
             } else {
-            const unsigned grid = grid_for(groups * lb);
+            const unsigned grid = sddmm_grid(lb);
 #define GF_SDDMM(LBV)                                                                                                         \
     hipLaunchKernelGGL((ev_sddmm_kernel<LBV>), dim3(grid), dim3(kThreads), 0, st, plan->row, plan->col, Ucur,                  \
-                       V + (int64_t)(k - 1) * CNB, dwedge, N, B, G, K - 1, k - 1, plan->nnzp, udiv, groups)
+                       V + (int64_t)(k - 1) * CNB, dwedge, N, B, G, K - 1, k - 1, plan->nnzp, udiv, (int64_t)C)
             switch (lb) {
                 case 1: GF_SDDMM(1); break;
                 case 2: GF_SDDMM(2); break;
