@@ -96,6 +96,20 @@ __global__ __launch_bounds__(kThreads) void ev_tap0_kernel(const float* __restri
     }
 }
 
+// 4 batch entries per thread (B % 4 == 0): one 64-bit index split per 16 bytes instead of per 4
+__global__ __launch_bounds__(kThreads) void ev_tap0_v4_kernel(const float* __restrict__ wdiag, const float* __restrict__ Xt,
+                                                              float* __restrict__ V0, int G, int64_t NB4, int B4, int64_t total4) {
+    const float4* X4 = reinterpret_cast<const float4*>(Xt);
+    float4* V4 = reinterpret_cast<float4*>(V0);
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * kThreads) {
+        const int64_t c = idx / NB4, nb = idx - c * NB4;
+        const int g = (int)(c % G);
+        const float w = wdiag[c * (NB4 / B4) + nb / B4];
+        const float4 x = X4[(int64_t)g * NB4 + nb];
+        V4[idx] = make_float4(w * x.x, w * x.y, w * x.z, w * x.w);
+    }
+}
+
 // ---- one tap of every chain: out[c][i][b] = add[c/add_div][i][b] + sum_{q in row i} W_c[vidx ? vidx[q] : q] * in[c/in_div][col[q]][b]
 // W_c = wedge + ((f*K1 + kidx)*G + g)*nnzp for c = f*G + g.  Forward: (rowptr, col) = pattern, vidx = NULL.
 // Backward: (rowptr, col, vidx) = transposed pattern, add = dy (chain-broadcast via add_div = G).
@@ -455,6 +469,32 @@ __global__ __launch_bounds__(kThreads) void ev_dwdiag_kernel(const float* __rest
     }
 }
 
+// 16-byte loads, LQ = B/4 lanes per output (B % 4 == 0)
+template <int LQ>
+__global__ __launch_bounds__(kThreads) void ev_dwdiag4_kernel(const float* __restrict__ U0, const float* __restrict__ Xt,
+                                                              float* __restrict__ dwdiag, int N, int B, int G, int u_div,
+                                                              int64_t groups) {
+    const int64_t NB = (int64_t)N * B;
+    const int lane = threadIdx.x % LQ;
+    const int64_t g0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LQ;
+    const int64_t gstep = (int64_t)gridDim.x * kThreads / LQ;
+    for (int64_t grp = g0; grp < groups; grp += gstep) {
+        const int64_t c = grp / N, n = grp - c * N;
+        const float* u = U0 + (c / u_div) * NB + n * B;
+        const float* x = Xt + (c % G) * NB + n * B;
+        float acc = 0.f;
+        for (int b = lane * 4; b < B; b += LQ * 4) {
+            const float4 uu = *reinterpret_cast<const float4*>(u + b), xx = *reinterpret_cast<const float4*>(x + b);
+            acc = fmaf(uu.x, xx.x, acc);
+            acc = fmaf(uu.y, xx.y, acc);
+            acc = fmaf(uu.z, xx.z, acc);
+            acc = fmaf(uu.w, xx.w, acc);
+        }
+        acc = group_sum<LQ>(acc);
+        if (lane == 0) dwdiag[grp] = acc;
+    }
+}
+
 // dXt[g][n][b] = sum_f wdiag[f*G+g][n] * U0[(f*G+g)/u_div][n][b]
 __global__ __launch_bounds__(kThreads) void ev_dxt_kernel(const float* __restrict__ wdiag, const float* __restrict__ U0,
                                                           float* __restrict__ dXt, int N, int B, int G, int F, int u_div,
@@ -662,7 +702,10 @@ extern "C" int gf_evgf_forward(const gf_ev_plan* plan, const float* x, const flo
     float* Xt = scratch;
     float* Yt = scratch + (int64_t)G * NB;
     if ((rc = to_nodebatch(x, Xt, B, G, Nin, N, st)) != GF_OK) return rc;
-    hipLaunchKernelGGL(ev_tap0_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, wdiag, Xt, V, G, NB, B, CNB);
+    if (B % 4 == 0)
+        hipLaunchKernelGGL(ev_tap0_v4_kernel, dim3(grid_for(CNB / 4)), dim3(kThreads), 0, st, wdiag, Xt, V, G, NB / 4, B / 4, CNB / 4);
+    else
+        hipLaunchKernelGGL(ev_tap0_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, wdiag, Xt, V, G, NB, B, CNB);
     GF_LAUNCH_CHECK("ev_tap0_kernel");
     for (int k = 1; k < K; ++k) {
         rc = launch_ev_hop(plan->rowptr, plan->col, nullptr, wedge, V + (int64_t)(k - 1) * CNB, nullptr, V + (int64_t)k * CNB, N, B,
@@ -755,6 +798,23 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
     }
     if (dwdiag) {
         const int64_t groups = (int64_t)C * N;
+        if (B % 4 == 0 && B <= 256) {
+            const int lq = lanes_for_batch(B / 4);
+            const unsigned grid4 = grid_for(groups * lq);
+#define GF_DWD4(LQV) \
+    hipLaunchKernelGGL((ev_dwdiag4_kernel<LQV>), dim3(grid4), dim3(kThreads), 0, st, Ucur, Xt, dwdiag, N, B, G, udiv, groups)
+            switch (lq) {
+                case 1: GF_DWD4(1); break;
+                case 2: GF_DWD4(2); break;
+                case 4: GF_DWD4(4); break;
+                case 8: GF_DWD4(8); break;
+                case 16: GF_DWD4(16); break;
+                case 32: GF_DWD4(32); break;
+                default: GF_DWD4(64); break;
+            }
+#undef GF_DWD4
+            GF_LAUNCH_CHECK("ev_dwdiag4_kernel");
+        } else {
         const unsigned grid = grid_for(groups * lb);
 #define GF_DWD(LBV) \
     hipLaunchKernelGGL((ev_dwdiag_kernel<LBV>), dim3(grid), dim3(kThreads), 0, st, Ucur, Xt, dwdiag, N, B, G, udiv, groups)
@@ -769,6 +829,7 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
         }
 #undef GF_DWD
         GF_LAUNCH_CHECK("ev_dwdiag_kernel");
+        }
     }
     if (dx) {
         const int64_t GNB = (int64_t)G * NB;

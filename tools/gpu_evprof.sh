@@ -3,7 +3,7 @@ cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 O=gpurun_out/r33; rm -rf $O; mkdir -p $O
 B=${1:-16}
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ev -- python tools/evgf_bench.py 50000 $B > $O/ev.log 2>&1
-tail -1 $O/ev.log
+grep workload $O/ev.log | tee $O/evgf_cfg5.json
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1)
 test -n "$f" && python - "$f" <<'PY'
 import csv, sys
