@@ -514,6 +514,31 @@ def test_full_size_properties(cfg2):
         assert relerr(lin.cpu().numpy(), ((y1 - bias) + (layer(x2) - bias)).cpu().numpy()) < 1e-5   # additivity
 
 
+def test_config4_size_node_major_vs_oracle():
+    """BASELINE configs[3] graph (ER N = 1e5, nnz ~ 1e6: beyond the LDS panel limit, node-major pipeline through L2) at a small
+    batch: forward and all gradients against the sparse oracle, and run-to-run determinism."""
+    N, B, G, F, K = 100_000, 6, 32, 32, 5
+    A = graphgen.er(N, seed=0)
+    torch.manual_seed(1)
+    layer = gml.GraphFilter(G, F, K, 1, True)
+    layer.addGSO(A)
+    layer.to(DEV)
+    assert _lib.lib().gf_lsigf_pipeline(layer._gso.plans(DEV), 1, G, F) == 1
+    x = torch.randn(B, G, N, device=DEV, requires_grad=True)
+    y = layer(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    w, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+    want = orc.lsigf_sparse(w, A, x.detach().cpu().numpy(), b)
+    dx, dh, db = orc.lsigf_sparse_grads(w, A, x.detach().cpu().numpy(), b, dy.cpu().numpy())
+    assert relerr(y.detach().cpu().numpy(), want) < FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), dx) < GRAD_RTOL
+    assert relerr(layer.weight.grad.cpu().numpy(), dh) < GRAD_RTOL
+    assert relerr(layer.bias.grad.cpu().numpy(), db) < GRAD_RTOL
+    with torch.no_grad():
+        assert torch.equal(layer(x), y)
+
+
 def test_gradients_are_deterministic(cfg2):
     layer, x = cfg2["layer"], cfg2["x"][:64]
     grads = []
