@@ -122,6 +122,7 @@ struct gf_tuning {
                                 // (20 = 8 phases x 2 us, the measured optimum at N = 1e4); 0 = start together
     int panel_rotate = 1;       // 1 = each workgroup walks the slice list from its own starting offset
     int panel_grid = 0;         // experiments: cap on the panel kernel's grid (0 = one workgroup per LDS-full)
+    int panel_split = 0;        // workgroups per pass when there are fewer passes than CUs: 0 = as many as fit (<= 8), 1 = off
     int panel_dma = 0;          // panel load phase: 0 = through registers (global_load + ds_write), 1 = LDS-DMA (global_load_lds_dwordx4)
     int panel_debug = 0;        // timing experiments only (WRONG RESULTS): 1 = panel loads only, 2 = compute only, 3 = compute only with
                                 // every entry load redirected to the L1-resident sentinel rows, 4 = compute only without stores

@@ -44,14 +44,17 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                                                           const void* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
                                                           int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug,
-                                                          int stagger, int ush, int nHops, int64_t tapStride, int rotate) {
+                                                          int stagger, int ush, int nHops, int64_t tapStride, int rotate, int split) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int CW = (int)(blockDim.x >> 6);
     const int64_t pstride = (int64_t)N * 4;  // floats per panel
     const int nGroups = (nPanels + NP - 1) / NP;  // passes: NP panels each
-    int p = blockIdx.x;
+    // split > 1 (fewer passes than CUs): `split` workgroups share a pass -- each loads the panel (the second copy comes from L2) and
+    // computes every split-th slice, so a small batch still occupies every CU in the compute phase (2/3 of the time)
+    const int part = (int)(blockIdx.x % (unsigned)split);
+    int p = (int)(blockIdx.x / (unsigned)split);
     if (p >= nGroups) return;  // whole workgroup
     const int dbg = debug & 7;       // timing experiments (see gf_common.h)
     const bool dma = (debug & 8) != 0;  // panel load phase through LDS-DMA
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     // then drives NP gathers -- the (column, value) stream and its bookkeeping are amortised over NP x 16 bytes per edge.
     const unsigned regionB = (unsigned)(N + 1) * 16u;
     if (tid < NP) lds4[tid * (N + 1) + N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slots empty ELL slots gather from
-    const int rot = rotate ? (int)((blockIdx.x * 41u) % (unsigned)nSlices) : 0;
+    const int rot = rotate ? (int)(((blockIdx.x / (unsigned)split) * 41u) % (unsigned)nSlices) : 0;  // the same for the workgroups sharing a pass
     {
         // De-synchronise the workgroups once (see the header comment).
         // stagger = 16 * (log2 of the number of phases - 2) + sleep quanta of 16 * 64 cycles (~0.5 us) per phase step
@@ -135,14 +138,15 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
             }
         }
         __syncthreads();  // B1: panel p is in LDS
-        if (wave < nSlices && dbg != 1) {
-            int s = wave;                       // slice in hand
+        if (wave + part * CW < nSlices && dbg != 1) {
+            const int CWS = CW * split;         // slice stride of this wave
+            int s = wave + part * CW;           // slice in hand
             // Workgroups walk the slice list rotated by a workgroup-specific offset: at any moment the 256 CUs read different parts
             // of the (shared, L2-resident) entry arrays instead of queueing on the same L2 channels.
             auto rs = [&](int q) { const int t = q + rot; return t >= nSlices ? t - nSlices : t; };
             int2 si = slice[rs(s)];             // {group-row offset, group-rows}
             int oc = octs[(rs(s) << (6 - ush)) + (lane >> ush)];
-            int sn = s + CW;                    // next slice of this wave (its header is fetched one slice ahead)
+            int sn = s + CWS;                   // next slice of this wave (its header is fetched one slice ahead)
             int2 sin = make_int2(sentinel, 0);
             int ocn = -1;
             if (sn < nSlices) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 si = sin;
                 oc = ocn;
                 j0 = 0;
-                sn = s + CW;
+                sn = s + CWS;
                 sin = make_int2(sentinel, 0);
                 ocn = -1;
                 if (sn < nSlices) {
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
         if (nHops > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows have reached L2 before anyone reloads them
         __syncthreads();  // B2: every wave is done reading panel p
       }
-        p += (int)gridDim.x;
+        p += (int)(gridDim.x / (unsigned)split);
         if (p >= nGroups) break;
     }
 }
@@ -345,15 +349,27 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     if (wgPerCU < 1) wgPerCU = 1;
     const int nGroups = (nPanels + np - 1) / np;
     int64_t grid = (int64_t)num_cus() * wgPerCU;
-    if (grid > nGroups) grid = nGroups;
-    if (g_tune.panel_grid > 0 && grid > g_tune.panel_grid) grid = g_tune.panel_grid;  // experiments: fewer workgroups than CUs
+    int split = 1;
+    if (grid > nGroups) {
+        // fewer passes than workgroup slots: several workgroups per pass, each taking every split-th slice (knob panel_split: 1 = off)
+        const int waves = thr / 64;
+        // (measured, tools/gpu_split.sh: 8-32 passes 1.1-2.1x faster, from ~128 passes on the duplicated panel loads cost more than the
+        // idle CUs)
+        split = nGroups * 4 <= num_cus() ? (int)(grid / nGroups) : 1;
+        while (split > 1 && (split * waves > m.pn_slices || split > 8)) --split;
+        if (g_tune.panel_split > 0 && split > g_tune.panel_split) split = g_tune.panel_split;
+        if (nHops > 1) split = 1;  // fused hops reload what the same workgroup stored
+        grid = (int64_t)nGroups * split;
+    }
+    if (g_tune.panel_grid > 0 && grid > g_tune.panel_grid) grid = g_tune.panel_grid / split * split;  // experiments: fewer workgroups than CUs
+    const bool multipass = nGroups * split > grid;  // staggered starts only pay when a workgroup walks several passes
     typedef void (*kern_t)(const int2*, const int32_t*, const void*, const float4*, float, const float*, float*, int, int, int, int, int,
-                           int, int, int, int, int64_t, int);
+                           int, int, int, int, int64_t, int, int);
     kern_t kern = np == 2 ? (uniform ? (kern_t)spmm_panel_kernel<1, 2> : (kern_t)spmm_panel_kernel<0, 2>)
                           : (uniform ? (kern_t)spmm_panel_kernel<1, 1> : (kern_t)spmm_panel_kernel<0, 1>);
     if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug | (g_tune.panel_dma ? 8 : 0), wgPerCU > 1 ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride, g_tune.panel_rotate);
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug | (g_tune.panel_dma ? 8 : 0), (wgPerCU > 1 || !multipass) ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride, g_tune.panel_rotate, split);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }

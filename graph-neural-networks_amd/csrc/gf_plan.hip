@@ -46,6 +46,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_unit")) g_tune.panel_unit = value;
     else if (!strcmp(key, "panel_debug")) g_tune.panel_debug = value;
     else if (!strcmp(key, "panel_dma")) g_tune.panel_dma = value;
+    else if (!strcmp(key, "panel_split")) g_tune.panel_split = value;
     else if (!strcmp(key, "panel_grid")) g_tune.panel_grid = value;
     else if (!strcmp(key, "panel_rotate")) g_tune.panel_rotate = value;
     else if (!strcmp(key, "panel_stagger")) g_tune.panel_stagger = value;
