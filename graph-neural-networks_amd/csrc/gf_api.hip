@@ -101,6 +101,13 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
     if (pipe == 2) {
         int rc = gf_pack_panels_launch(dy, P, B, F, Nin, N, gf_stream(stream), y_relu);  // P[0] = dy (masked by y > 0) as panels, rows >= Nin zero
         if (rc != GF_OK) return rc;
+        if (dx && dh && g_tune.bwd_fuse && gf_bwd_fused_supported(G, F, E, K)) {
+            // dh_t = X0^T P_t: the tap gradient reads the adjoint stack the data path builds anyway (and tap 0 of the saved stack)
+            GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
+            rc = khop_panel(plans, E, GF_OP_BWD, P, B, F, K, gf_stream(stream));
+            if (rc != GF_OK) return rc;
+            return gf_bwd_fused_panel_launch(P, Z, h, dx, dh, dbias, workspace, workspace_bytes, B, N, Nin, G, F, E, K, gf_stream(stream));
+        }
         if (dh || dbias) {
             GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
             rc = gf_grad_taps_panel(Z, P, dh, dbias, workspace, workspace_bytes, B, N, G, F, E, K, stream);

@@ -122,6 +122,7 @@ struct gf_tuning {
                                 // (20 = 8 phases x 2 us, the measured optimum at N = 1e4); 0 = start together
     int panel_rotate = 1;       // 1 = each workgroup walks the slice list from its own starting offset
     int panel_grid = 0;         // experiments: cap on the panel kernel's grid (0 = one workgroup per LDS-full)
+    int bwd_fuse = 1;           // panel pipeline backward: 1 = dx and dh from the adjoint stack in one kernel (G, F <= 32), 0 = separate
     int panel_split = 0;        // workgroups per pass when there are fewer passes than CUs: 0 = as many as fit (<= 8), 1 = off
     int panel_dma = 0;          // panel load phase: 0 = through registers (global_load + ds_write), 1 = LDS-DMA (global_load_lds_dwordx4)
     int panel_debug = 0;        // timing experiments only (WRONG RESULTS): 1 = panel loads only, 2 = compute only, 3 = compute only with
@@ -137,6 +138,9 @@ extern gf_tuning g_tune;
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
                        int F, int E, int K, int transpose_bank, hipStream_t st);
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)
+bool gf_bwd_fused_supported(int G, int F, int E, int K);
+int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
+                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st);
 bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F);
 int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st, const float* mask);
 int gf_layout_masked_launch(const float* dy, const float* y, float* X, int B, int G, int Nin, int N, hipStream_t st);

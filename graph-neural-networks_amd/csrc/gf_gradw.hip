@@ -362,6 +362,129 @@ void launch_stage1_panel(const Geo& g, const float* Zp, const float* P0p, float*
                            ws + g.off_partial_b, (int)g.R, N, B, G, F, g.numGI, g.numCT, g.numFT, g.passes, g.rowsPerWave);
 }
 
+// ---- backward of the panel pipeline in one pass over the adjoint tap stack -----------------------------------------------------
+// With P_t = (adjoint hop)^t dY (the stack the data path already builds) the tap gradient is  dh_t[g][f] = sum_rows X0[row][g] *
+// P_t[row][f]  (= Z_t^T dY, moved through the adjoint), so BOTH outputs of the backward read the same P tiles:
+//     dx[row][g]   = sum_{t,f} P_t[row][f] * h[f, t, g]        (the transposed-bank contraction of gf_contract.hip)
+//     dh_t[g][f]  += X0[row][g] * P_t[row][f]                   (a reduction over rows)
+// One wave owns a strip of rows (the Geo of the tap-gradient kernels) and walks it in 32-row tiles: per tap it loads the P tile once
+// (16 bytes per lane, the contraction's B-operand layout: lane = row, 4 consecutive f), feeds the contraction MFMAs from registers,
+// drops the tile into a wave-private LDS buffer [row][f] and reads it back with lane = f for the reduction MFMAs against the X0
+// tile staged the same way.  HBM: the P stack + X0 once, dx once -- the separate tap-gradient kernel re-read the whole
+// forward stack Z (T*R*G*4 bytes).  G, F <= 32 (one 32x32 accumulator tile per tap), T <= 6.
+template <int T, int GIN8, int FIN8>
+__global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* __restrict__ Pp, const float* __restrict__ X0p,
+                                                                   const float* __restrict__ h, float* __restrict__ dx,
+                                                                   float* __restrict__ partial, float* __restrict__ partial_b, int R,
+                                                                   int N, int Nout, int B, int E, int K, int rowsPerWave) {
+    constexpr int G = GIN8 * 8, F = FIN8 * 8, QG = G / 4, QF = F / 4;
+    constexpr int TS = 36;  // padded row stride of the wave-private tiles (floats): 16-byte aligned rows, conflict-free column reads
+    __shared__ __attribute__((aligned(16))) float s_w[T * F * 32];           // Hm[t*F + f][g], g padded to 32
+    __shared__ __attribute__((aligned(16))) float s_t[kWaves][2][32 * TS];    // per wave: X0 tile, P tile
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < T * F * 32; idx += kThreads) {
+        const int g = idx & 31, c = idx >> 5, t = c / F, f = c - t * F;
+        float v = 0.f;
+        if (g < G) {
+            if (t == 0) {
+                for (int e = 0; e < E; ++e) v += h[((int64_t)(f * E + e) * K) * G + g];   // tap 0 is shared by the edge features
+            } else {
+                const int e = (t - 1) / (K - 1), k = (t - 1) % (K - 1) + 1;
+                v = h[((int64_t)(f * E + e) * K + k) * G + g];
+            }
+        }
+        s_w[idx] = v;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wg = blockIdx.x * kWaves + wave;
+    const int r_begin = wg * rowsPerWave, r_end = min(R, r_begin + rowsPerWave);
+    const int64_t N4 = (int64_t)N * 4;
+    const int64_t tapStride = (int64_t)B * QF * N4;
+    float* xs = s_t[wave][0];
+    float* ps = s_t[wave][1];
+
+    f32x16 acc_h[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_h[t][r] = 0.f;
+    float bsum = 0.f;
+
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+        const int r = r0 + l31;
+        const bool rv = r < r_end;
+        const int b = rv ? r / N : 0;
+        const int n = rv ? r - b * N : 0;
+        const float* pb = Pp + ((int64_t)b * QF + half) * N4 + (int64_t)n * 4;   // + (2u) panels, + t taps
+        float4 x0[GIN8], cur[FIN8], nxt[FIN8];
+#pragma unroll
+        for (int u = 0; u < GIN8; ++u)
+            x0[u] = rv ? *reinterpret_cast<const float4*>(X0p + ((int64_t)b * QG + 2 * u + half) * N4 + (int64_t)n * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < FIN8; ++u)
+            cur[u] = rv ? *reinterpret_cast<const float4*>(pb + (int64_t)(2 * u) * N4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < GIN8; ++u) *reinterpret_cast<float4*>(xs + l31 * TS + 8 * u + 4 * half) = x0[u];
+
+        f32x16 acc_x;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_x[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) {
+#pragma unroll
+                for (int u = 0; u < FIN8; ++u)
+                    nxt[u] = rv ? *reinterpret_cast<const float4*>(pb + (int64_t)(t + 1) * tapStride + (int64_t)(2 * u) * N4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // P tile -> LDS [row][f] for the reduction (the previous tap's reads are complete: same wave, program order)
+#pragma unroll
+            for (int u = 0; u < FIN8; ++u) *reinterpret_cast<float4*>(ps + l31 * TS + 8 * u + 4 * half) = cur[u];
+            // data path: acc_x[g][row] += Hm[t*F + f][g] * P_t[row][f]
+            const float* wt = s_w + t * F * 32;
+#pragma unroll
+            for (int u = 0; u < FIN8; ++u) {
+                const float bs[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc_x = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(u * 8 + half * 4 + s) * 32 + l31], bs[s], acc_x, 0, 0, 0);
+            }
+            // tap gradient: acc_h[t][g][f] += X0[row][g] * P_t[row][f], two rows per MFMA (k = half)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float a = xs[(2 * s + half) * TS + l31];  // (held in registers across the taps instead: measured slower)
+                const float p = ps[(2 * s + half) * TS + l31];
+                if (t == 0) bsum += p;
+                acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p, acc_h[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < FIN8; ++u) cur[u] = nxt[u];
+        }
+        if (rv && n < Nout) {
+            float* ob = dx + (int64_t)b * G * Nout + n;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
+                if (g < G) ob[(int64_t)g * Nout] = acc_x[i];
+            }
+        }
+    }
+
+    float* pt = partial + (int64_t)wg * T * 1024;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
+            pt[t * 1024 + g * 32 + l31] = acc_h[t][i];
+        }
+    const float other = __shfl_xor(bsum, 32, 64);
+    if (half == 0) partial_b[(int64_t)wg * 32 + l31] = bsum + other;  // even rows + odd rows
+}
+
 int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, int E, int K, hipStream_t st) {
     const int wavesPadded = g.strips * kWaves;
     const int slices = wavesPadded < kSlices ? wavesPadded : kSlices;
@@ -380,6 +503,51 @@ int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, 
 }
 
 }  // namespace
+
+// dx and (dh, dbias) from the adjoint tap stack in one kernel; false if the shape is not covered (the caller then runs the
+// contraction and the tap-gradient kernel separately)
+bool gf_bwd_fused_supported(int G, int F, int E, int K) {
+    const int T = gf_num_taps(E, K);
+    auto ok = [](int w) { return w == 8 || w == 16 || w == 32; };
+    return ok(G) && ok(F) && T >= 1 && T <= 6;  // static LDS: the bank (T*F*32 floats) + the wave tiles stay under 64 KiB
+}
+
+int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
+                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st) {
+    const Geo g = make_geo(B, N, G, F, E, K);
+    GF_REQUIRE_SHAPE(g.R < (int64_t)INT32_MAX - 4096, "gf_lsigf_backward: B*N = %lld too large", (long long)g.R);
+    GF_REQUIRE_ARG(workspace && workspace_bytes >= g.bytes, "gf_lsigf_backward: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
+    GF_REQUIRE_SHAPE(g.passes == 1 && g.ctp == g.T, "gf_lsigf_backward: fused backward geometry");
+    float* ws = (float*)workspace;
+#define GF_BF(TT, GG, FF)                                                                                                      \
+    hipLaunchKernelGGL((bwd_fused_panel_kernel<TT, GG, FF>), dim3(g.strips), dim3(kThreads), 0, st, Pp, X0p, h, dx, ws,         \
+                       ws + g.off_partial_b, (int)g.R, N, Nout, B, E, K, g.rowsPerWave)
+#define GF_BF_F(TT, GG)                                                                                                         \
+    switch (F / 8) {                                                                                                            \
+        case 1: GF_BF(TT, GG, 1); break;                                                                                        \
+        case 2: GF_BF(TT, GG, 2); break;                                                                                        \
+        default: GF_BF(TT, GG, 4); break;                                                                                       \
+    }
+#define GF_BF_G(TT)                                                                                                             \
+    switch (G / 8) {                                                                                                            \
+        case 1: GF_BF_F(TT, 1); break;                                                                                          \
+        case 2: GF_BF_F(TT, 2); break;                                                                                          \
+        default: GF_BF_F(TT, 4); break;                                                                                         \
+    }
+    switch (g.T) {
+        case 1: GF_BF_G(1); break;
+        case 2: GF_BF_G(2); break;
+        case 3: GF_BF_G(3); break;
+        case 4: GF_BF_G(4); break;
+        case 5: GF_BF_G(5); break;
+        default: GF_BF_G(6); break;
+    }
+#undef GF_BF_G
+#undef GF_BF_F
+#undef GF_BF
+    GF_LAUNCH_CHECK("bwd_fused_panel_kernel");
+    return finish_taps(g, ws, dh, dbias, G, F, E, K, st);
+}
 
 extern "C" int gf_grad_taps_panel(const float* Zp, const float* P0p, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
                                   int32_t B, int32_t N, int32_t G, int32_t F, int32_t E, int32_t K, void* stream) {

@@ -47,6 +47,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_debug")) g_tune.panel_debug = value;
     else if (!strcmp(key, "panel_dma")) g_tune.panel_dma = value;
     else if (!strcmp(key, "panel_split")) g_tune.panel_split = value;
+    else if (!strcmp(key, "bwd_fuse")) g_tune.bwd_fuse = value;
     else if (!strcmp(key, "panel_grid")) g_tune.panel_grid = value;
     else if (!strcmp(key, "panel_rotate")) g_tune.panel_rotate = value;
     else if (!strcmp(key, "panel_stagger")) g_tune.panel_stagger = value;
