@@ -8,6 +8,8 @@ libgfhip.so.  S gets no gradient (it is not a Parameter in the reference either,
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -25,6 +27,13 @@ def _require_f32_cuda(name, t):
     if t.dtype != torch.float32:
         raise TypeError(f"alegnn_amd.LSIGF: `{name}` has dtype {t.dtype}; the gfx950 kernels compute in float32 "
                         "(cast the module / data with .float()).")
+
+
+_PAD_WIDTHS = os.environ.get("GFHIP_PAD_WIDTHS", "1") != "0"
+
+
+def _padded_width(w):
+    return w if (not _PAD_WIDTHS or w % 8 == 0 or w > 128) else 8 * ((w + 7) // 8)
 
 
 class _LSIGFFunction(torch.autograd.Function):
@@ -114,9 +123,23 @@ def LSIGF(h, S, x, b=None, activation=None):
             late_bias = b
     assert activation in (None, "relu")
     relu = activation == "relu"
+    # Feature counts that are not multiples of 8 (the 1-feature input of every example architecture, a 5-class output) are
+    # zero-padded to the next multiple of 8: the padded channels carry zeros through the filter (zero taps, zero signals) and
+    # are cut off again, autograd of pad / slice returns the exact gradients -- and the layer runs on the MFMA / 16-byte paths
+    # instead of the scalar generic kernels (config-3 first layer, G = 1: 0.51 -> 0.2 ms).  GFHIP_PAD_WIDTHS=0 disables it.
+    Gp, Fp = _padded_width(G), _padded_width(F_)
+    if Gp != G or Fp != F_:
+        if Gp != G:
+            x = torch.nn.functional.pad(x, (0, 0, 0, Gp - G))
+        h = torch.nn.functional.pad(h, (0, Gp - G, 0, 0, 0, 0, 0, Fp - F_))
+        if fused_bias is not None and Fp != F_:
+            fused_bias = torch.nn.functional.pad(fused_bias, (0, 0, 0, Fp - F_))
     if relu and late_bias is not None:                         # the activation must see the bias: apply both outside
-        return torch.relu(_LSIGFFunction.apply(x, h, None, gso, False) + late_bias[:, : x.shape[2]])
+        y = _LSIGFFunction.apply(x, h, None, gso, False)
+        return torch.relu((y[:, :F_] if Fp != F_ else y) + late_bias[:, : x.shape[2]])
     y = _LSIGFFunction.apply(x, h, fused_bias, gso, relu)
+    if Fp != F_:
+        y = y[:, :F_].contiguous()
     if late_bias is not None:
         y = y + late_bias[:, : y.shape[2]]
     return y
