@@ -15,6 +15,13 @@ identical replica.  Per step
     * the two reported scalars (loss, cost) ride in the bucket's tail, no second collective.
 Validation is computed by every rank on the full validation set (identical replicas -> identical decisions, no exchange);
 checkpoints are written by rank 0 (model.py).
+
+``hipGraph=True`` (superset option, GPU only): zero-grad + forward + loss + backward of a training step are captured once per
+batch size as a HIP graph and replayed; the samples are copied into the graph's static input buffers, the (all-reduce and)
+optimizer step stay eager.  The reference's own configurations (N = 100 nodes, batch 20-100) are launch-bound -- about forty
+small kernels per step -- and replay halves the step time; the arithmetic is the same kernels in the same
+order, so the trajectory is bit-identical to the eager one.  The C library underneath only launches on the stream it is handed,
+allocates nothing and never synchronises, which is what makes the step capturable.
 """
 from __future__ import annotations
 
@@ -87,6 +94,8 @@ class Trainer:
             self.trainingOptions['learningRateDecayRate'] = kwargs['learningRateDecayRate']
             self.trainingOptions['learningRateDecayPeriod'] = kwargs['learningRateDecayPeriod']
 
+        self.useGraph = bool(kwargs.get('hipGraph', False))
+        self._graphs = {}                                           # batch size -> captured step
         self.bucket = None
         if self.world > 1:
             broadcast_parameters(self.model.archit)                 # identical replicas from step 0
@@ -103,9 +112,69 @@ class Trainer:
     def _forward(self, x, samplesType, indices):
         return self.model.archit(x)
 
+    # ---- the step as a HIP graph (hipGraph=True) ---------------------------------------------------------------------
+    def _graph_step(self, xTrain, yTrain, samplesType, indices, weight):
+        """zero-grad + forward + loss + backward for this batch shape, captured on first use and replayed afterwards.
+        Returns (loss tensor, output tensor): the graph's static outputs, valid until the next replay."""
+        key = (tuple(xTrain.shape), tuple(yTrain.shape), xTrain.dtype, yTrain.dtype)
+        g = self._graphs.get(key)
+        if g is None:
+            dev = self.model.device
+            sx = torch.empty(xTrain.shape, dtype=xTrain.dtype, device=dev)
+            sy = torch.empty(yTrain.shape, dtype=yTrain.dtype, device=dev)
+            sx.copy_(xTrain)
+            sy.copy_(yTrain)
+            params = [p for p in self.model.archit.parameters() if p.requires_grad]
+
+            def body():
+                if self.bucket is None:
+                    for p in params:
+                        p.grad = None                               # the captured backward then writes (not accumulates) the grads
+                else:
+                    self.bucket.zero_()
+                yHat = self._forward(sx, samplesType, indices)
+                lossValue = self.model.loss(yHat, sy)
+                (lossValue * weight if self.world > 1 else lossValue).backward()
+                return lossValue, yHat
+
+            side = torch.cuda.Stream(device=dev)                    # warm-up off the capture: plans, LDS attributes, allocator pools
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = body()
+            g = self._graphs[key] = dict(graph=graph, x=sx, y=sy, out=out, weight=weight,
+                                         grads=[p.grad for p in params], params=params)
+        assert g["weight"] == weight, "hipGraph: the per-rank share of this batch size changed"
+        g["x"].copy_(xTrain, non_blocking=True)
+        g["y"].copy_(yTrain, non_blocking=True)
+        g["graph"].replay()
+        if self.bucket is None:
+            for p, gr in zip(g["params"], g["grads"]):
+                p.grad = gr                                         # an eager step in between may have re-pointed .grad
+        return g["out"]
+
     def trainBatch(self, thisBatchIndices):
         mine = self._share(thisBatchIndices)
         startTime = time.perf_counter()
+        if self.useGraph and len(mine) > 0 and torch.device(self.model.device).type == "cuda":
+            xTrain, yTrain = self.data.getSamples('train', mine)
+            weight = len(mine) * self.world / len(thisBatchIndices)
+            # single-node trainers look the target nodes up per batch: their ids are baked into a captured step, so those stay eager
+            if type(self)._forward is Trainer._forward:
+                lossValueTrain, yHatTrain = self._graph_step(xTrain, yTrain, 'train', mine, weight)
+                lossValue = lossValueTrain.item() * weight
+                costValue = float(self.data.evaluate(yHatTrain.data, yTrain.to(self.model.device))) * weight
+                if self.bucket is not None:
+                    tail = self.bucket.extra
+                    tail[0], tail[1] = lossValue, costValue
+                    self.bucket.allreduce_mean()
+                    lossValue, costValue = float(tail[0]), float(tail[1])
+                self.model.optim.step()
+                return lossValue, costValue, time.perf_counter() - startTime
         if self.bucket is None:
             self.model.archit.zero_grad()                           # :241
         else:

@@ -314,6 +314,33 @@ def test_trainer_on_gpu_follows_reference_training_run(tmp_path):
         assert relerr(last[k].cpu().numpy(), ref[k].numpy()) < 2e-3, k
 
 
+def test_trainer_hip_graph_replay_is_bit_identical_to_eager(tmp_path):
+    """Trainer(hipGraph=True): the captured step (zero-grad + forward + loss + backward, one graph per batch size: 32 and the
+    uneven last batch) must retrace the eager run exactly -- same kernels, same order."""
+    import ast
+    from _util import ArrayData
+    from alegnn_amd.modules import evaluation, loss, model, training
+    d = load(os.path.join(GOLDEN, "trainer_selgnn.npz"))
+
+    def run(tag, **kw):
+        net = SelectionGNN([1, 8, 8], [3, 3], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [5], d["S"][0])
+        net.load_state_dict({k[5:]: torch.tensor(v) for k, v in d.items() if k.startswith("init:")})
+        net = net.float()
+        optim = torch.optim.Adam(net.parameters(), lr=0.005, betas=(0.9, 0.999))
+        m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim, training.Trainer, evaluation.evaluate,
+                        DEV, tag, str(tmp_path))
+        np.random.seed(5)
+        tv = m.train(ArrayData(d, torch.float32), 3, 40, printInterval=0, validationInterval=2, doSaveVars=False, **kw)   # 40 + 40 + 16
+        return tv, {k: v.detach().clone() for k, v in net.state_dict().items()}, m
+
+    tv_e, sd_e, _ = run("eager")
+    tv_g, sd_g, m = run("graph", hipGraph=True)
+    assert len(m.trainer._graphs) == 2                               # batch sizes 40 and 16
+    assert np.array_equal(tv_e["lossTrain"], tv_g["lossTrain"]) and np.array_equal(tv_e["costValid"], tv_g["costValid"])
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+
+
 # ---- callers that reuse the K-hop kernel (SURVEY.md section 8 f-3) ---------------------------------------------------------
 @pytest.mark.parametrize("path", golden_files("nvgf"), ids=case_id)
 def test_node_variant_gf_matches_reference(path):

@@ -86,7 +86,7 @@ def grnn(N, B, T, F, H, K):
     print(json.dumps(out), flush=True)
 
 
-def trainer(N, nTrain, batchSize, epochs):
+def trainer(N, nTrain, batchSize, epochs, hipGraph=False, F=(1, 32, 32)):
     class Data:
         def __init__(self):
             g = torch.Generator().manual_seed(0)
@@ -99,18 +99,23 @@ def trainer(N, nTrain, batchSize, epochs):
         def evaluate(self, yHat, y, tol=1e-9):
             return (torch.argmax(yHat, dim=1) != y).float().mean()
     A = graphgen.sbm(N, avg_degree=10.0, seed=0)
-    net = SelectionGNN([1, 32, 32], [5, 5], True, torch.nn.ReLU, [N, N], gml.NoPool, [1, 1], [5], A)
+    net = SelectionGNN(list(F), [5, 5], True, torch.nn.ReLU, [N, N], gml.NoPool, [1, 1], [5], A)
     optim = torch.optim.Adam(net.parameters(), lr=1e-3)
     with tempfile.TemporaryDirectory() as tmp:
         m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim, training.Trainer, evaluation.evaluate,
                         dev, "bench", tmp)
         np.random.seed(0)
-        m.train(Data(), 1, batchSize, printInterval=0, doSaveVars=False)            # warm-up epoch (plans, allocator)
+        m.train(Data(), 1, batchSize, printInterval=0, doSaveVars=False, hipGraph=hipGraph)   # warm-up epoch (plans, allocator, capture)
+        graphs = m.trainer._graphs
         m.trainer = training.Trainer
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        tv = m.train(Data(), epochs, batchSize, printInterval=0, doSaveVars=False)
+        tv = None
+        trainer_obj = training.Trainer(m, Data(), epochs, batchSize, printInterval=0, doSaveVars=False, hipGraph=hipGraph)
+        trainer_obj._graphs = graphs                                  # keep the captured steps of the warm-up
+        m.trainer = trainer_obj
+        tv = trainer_obj.train()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps(dict(item="trainer", arch="SelectionGNN F=[1,32,32] K=[5,5] NoPool MLP[5]", N=N, nnz=int(A.nnz), nTrain=nTrain,
+    print(json.dumps(dict(item="trainer", hipGraph=hipGraph, arch="SelectionGNN F=%s K=[5,5] NoPool MLP[5]" % list(F), N=N, nnz=int(A.nnz), nTrain=nTrain,
                           batchSize=batchSize, epochs=epochs, steps=len(tv["lossTrain"]), wall_s=round(dt, 3),
                           samples_per_s=round(epochs * nTrain / dt, 1), loss_first_last=[round(float(tv["lossTrain"][0]), 4),
                                                                                        round(float(tv["lossTrain"][-1]), 4)])), flush=True)
@@ -122,3 +127,5 @@ if __name__ == "__main__":
     grnn(N=1000, B=16, T=10, F=8, H=32, K=4)
     grnn(N=10000, B=16, T=10, F=8, H=32, K=4)
     trainer(N=10000, nTrain=2048, batchSize=256, epochs=2)
+    trainer(N=100, nTrain=2000, batchSize=20, epochs=2)                       # the reference's own scale (sourceLocGNN.py): launch-bound
+    trainer(N=100, nTrain=2000, batchSize=20, epochs=2, hipGraph=True)
