@@ -213,6 +213,12 @@ def kernel_breakdown(L, layer, plans, x, dy, B, N, G, F, K, dev):
             "grad_taps": lambda: L.gf_grad_taps_panel(Z.data_ptr(), P.data_ptr(), dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, N, G, F, 1, K, st),
             "khop_bwd(K-1 panel hops)": lambda: khop(P, 1, F),
             "contract_bwd": lambda: L.gf_contract_panel(P.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, N, N, G, F, 1, K, 1, st),
+            # what the layer actually runs: for G, F <= 32 the backward produces dx and dh in ONE pass over the adjoint stack
+            # (bwd_fused_panel_kernel) instead of grad_taps + contract_bwd above
+            "lsigf_forward(whole)": lambda: L.gf_lsigf_forward(plans, 1, x.data_ptr(), w.data_ptr(), b.data_ptr(), Z.data_ptr(), y.data_ptr(),
+                                                              B, G, F, K, N, st),
+            "lsigf_backward(whole)": lambda: L.gf_lsigf_backward(plans, 1, dy.data_ptr(), Z.data_ptr(), w.data_ptr(), P.data_ptr(), dx.data_ptr(),
+                                                                dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, G, F, K, N, st),
         }
     else:
       calls = {
