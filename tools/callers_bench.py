@@ -1,20 +1,19 @@
 #!/usr/bin/env python3
 """Callers of the K-hop kernel on the HIP path, next to the reference's formulation run with plain
 torch ops on the same GPU (dense S; the "no-rewrite" comparator of SURVEY.md 8d).  One JSON line per item:
-  nvgf     NodeVariantGF fwd+bwd                    (oracle/nvgf_oracle.nvgf_dense = graphML.py:341-387 restated)
+  nvgf     NodeVariantGF fwd+bwd                    (comparator: tools/_dense_torch.py, graphML.py:341-387 in torch ops)
   grnn     HiddenState / GatedGRNN fwd+bwd, T steps (comparator: the same recursion on lsigf_dense)
   trainer  Model + Trainer epochs on SelectionGNN (samples/s through getSamples -> forward -> loss -> backward -> Adam)
 """
 import json, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-neural-networks_amd"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-neural-networks_amd"), os.path.join(ROOT, "tools")]
 import numpy as np, torch
 from alegnn_amd import graphgen
 from alegnn_amd.modules import evaluation, loss, model, training
 from alegnn_amd.modules.architectures import SelectionGNN
 from alegnn_amd.utils import graphML as gml
-from oracle import lsigf_oracle as orc
-from oracle import nvgf_oracle as nvo
+from _dense_torch import dense_lsigf, dense_nvgf
 
 dev = torch.device("cuda:0")
 
@@ -50,7 +49,7 @@ def nvgf(N, B, G, F, K, M):
         cn = layer.copyNodes.to(dev)
         def ref():
             w.grad = None; x.grad = None
-            nvo.nvgf_dense(torch.index_select(w, 4, cn), S, x, layer.bias.detach()).square().sum().backward()
+            dense_nvgf(torch.index_select(w, 4, cn), S, x, layer.bias.detach()).square().sum().backward()
         out["torch_dense_same_gpu_ms"] = round(timeit(ref, n=5, warm=1), 3)
         out["speedup"] = round(out["torch_dense_same_gpu_ms"] / ms, 2)
     print(json.dumps(out), flush=True)
@@ -75,10 +74,10 @@ def grnn(N, B, T, F, H, K):
         def ref():
             for p in ps: p.grad = None
             x.grad = None
-            Ax = orc.lsigf_dense(ps[0], S, x.reshape(B * T, F, N), ps[2]).reshape(B, T, H, N)
+            Ax = dense_lsigf(ps[0], S, x.reshape(B * T, F, N), ps[2]).reshape(B, T, H, N)
             zt, acc = z0, 0.0
             for t in range(T):
-                zt = torch.tanh(Ax[:, t] + orc.lsigf_dense(ps[1], S, zt, ps[3]))
+                zt = torch.tanh(Ax[:, t] + dense_lsigf(ps[1], S, zt, ps[3]))
                 acc = acc + zt.square().sum()
             acc.backward()
         out["torch_dense_same_gpu_ms"] = round(timeit(ref, n=5, warm=1), 3)

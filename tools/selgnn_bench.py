@@ -9,7 +9,8 @@ import numpy as np, torch
 from alegnn_amd import graphgen
 from alegnn_amd.modules.architectures import SelectionGNN
 from alegnn_amd.utils import graphML as gml
-from oracle import lsigf_oracle as orc
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _dense_torch import dense_lsigf
 
 dev = torch.device("cuda:0")
 CFG = {
@@ -59,7 +60,7 @@ for name in (sys.argv[1:] or list(CFG)):
             Nin = y.shape[2]
             if Nin < c["N"]:
                 y = torch.cat((y, torch.zeros(y.shape[0], y.shape[1], c["N"] - Nin, device=dev)), dim=2)
-            y = torch.relu(orc.lsigf_dense(w, S, y, b)[:, :, :Nin])
+            y = torch.relu(dense_lsigf(w, S, y, b)[:, :, :Nin])
             if nbhs[l] is not None:
                 y, _ = torch.max(y[:, :, nbhs[l].long()], dim=3)
             else:
