@@ -51,6 +51,16 @@ def test_c_abi_error_convention_without_gpu():
     assert rc == _lib.GF_ERR_SHAPE and b"column index" in L.gf_last_error()
     assert L.gf_grad_taps_workspace_bytes(256, 10000, 32, 32, 1, 5) > 0
     assert L.gf_spmm_hop(None, 0, None, None, 1, 32, None) == -2
+    # node-variant entry points: scratch sizes follow the header's formula, NULL arguments are refused before any launch
+    B, N, G, F, E, K = 7, 100, 3, 5, 2, 4
+    T = 1 + E * (K - 1)
+    assert L.gf_nvgf_scratch_floats(B, N, G, F, E, K, 0) == N * T * G * F + B * N * F
+    assert L.gf_nvgf_scratch_floats(B, N, G, F, E, K, 1) == 2 * N * T * G * F + B * N * F + T * B * N * G + B * N * G
+    assert L.gf_nvgf_scratch_floats(0, N, G, F, E, K, 0) == 0
+    assert L.gf_nvgf_forward(None, 1, None, None, None, None, None, None, 0, B, G, F, K, N, None) == -2
+    assert L.gf_nvgf_backward(None, 1, None, None, None, None, None, None, 0, B, G, F, K, N, None) == -2
+    assert L.gf_nvgf_fold_taps(None, None, None, None, 10, 5, 2, None) == -2
+    assert L.gf_tune(b"bwd_fuse", 1) == 0 and L.gf_tune(b"panel_split", 0) == 0 and L.gf_tune(b"no_such_knob", 1) != 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
