@@ -371,7 +371,7 @@ void launch_stage1_panel(const Geo& g, const float* Zp, const float* P0p, float*
 // (16 bytes per lane, the contraction's B-operand layout: lane = row, 4 consecutive f), feeds the contraction MFMAs from registers,
 // drops the tile into a wave-private LDS buffer [row][f] and reads it back with lane = f for the reduction MFMAs against the X0
 // tile staged the same way.  HBM: the P stack + X0 once, dx once -- the separate tap-gradient kernel re-read the whole
-// forward stack Z (T*R*G*4 bytes).  G, F <= 32 (one 32x32 accumulator tile per tap), T <= 6.
+// forward stack Z (T*R*G*4 bytes).  G, F <= 32 (one 32x32 accumulator tile per tap), T <= 6 (the dispatcher's limit).
 template <int T, int GIN8, int FIN8>
 __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* __restrict__ Pp, const float* __restrict__ X0p,
                                                                    const float* __restrict__ h, float* __restrict__ dx,
@@ -379,8 +379,9 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
                                                                    int N, int Nout, int B, int E, int K, int rowsPerWave) {
     constexpr int G = GIN8 * 8, F = FIN8 * 8, QG = G / 4, QF = F / 4;
     constexpr int TS = 36;  // padded row stride of the wave-private tiles (floats): 16-byte aligned rows, conflict-free column reads
-    __shared__ __attribute__((aligned(16))) float s_w[T * F * 32];           // Hm[t*F + f][g], g padded to 32
-    __shared__ __attribute__((aligned(16))) float s_t[kWaves][2][32 * TS];    // per wave: X0 tile, P tile
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_w = s_dyn;                                   // Hm[t*F + f][g], g padded to 32: T*F*32 floats
+    float (*s_t)[2][32 * TS] = reinterpret_cast<float (*)[2][32 * TS]>(s_dyn + T * F * 32);   // per wave: X0 tile, P tile
     const int tid = threadIdx.x;
     for (int idx = tid; idx < T * F * 32; idx += kThreads) {
         const int g = idx & 31, c = idx >> 5, t = c / F, f = c - t * F;
@@ -509,7 +510,7 @@ int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, 
 bool gf_bwd_fused_supported(int G, int F, int E, int K) {
     const int T = gf_num_taps(E, K);
     auto ok = [](int w) { return w == 8 || w == 16 || w == 32; };
-    return ok(G) && ok(F) && T >= 1 && T <= 6;  // static LDS: the bank (T*F*32 floats) + the wave tiles stay under 64 KiB
+    return ok(G) && ok(F) && T >= 1 && T <= 6;  // 16 accumulator registers per tap: T = 7, 8 need > 256 VGPRs (one wave per SIMD)
 }
 
 int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
@@ -519,9 +520,15 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
     GF_REQUIRE_ARG(workspace && workspace_bytes >= g.bytes, "gf_lsigf_backward: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
     GF_REQUIRE_SHAPE(g.passes == 1 && g.ctp == g.T, "gf_lsigf_backward: fused backward geometry");
     float* ws = (float*)workspace;
+    const size_t lds = ((size_t)g.T * F * 32 + (size_t)kWaves * 2 * 32 * 36) * sizeof(float);  // bank + wave tiles (TS = 36)
+    hipError_t attr = hipSuccess;
 #define GF_BF(TT, GG, FF)                                                                                                      \
-    hipLaunchKernelGGL((bwd_fused_panel_kernel<TT, GG, FF>), dim3(g.strips), dim3(kThreads), 0, st, Pp, X0p, h, dx, ws,         \
-                       ws + g.off_partial_b, (int)g.R, N, Nout, B, E, K, g.rowsPerWave)
+    do {                                                                                                                        \
+        auto kern = bwd_fused_panel_kernel<TT, GG, FF>;                                                                         \
+        if (lds > 64 * 1024) attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, dim3(g.strips), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
+                           Nout, B, E, K, g.rowsPerWave);                                                                       \
+    } while (0)
 #define GF_BF_F(TT, GG)                                                                                                         \
     switch (F / 8) {                                                                                                            \
         case 1: GF_BF(TT, GG, 1); break;                                                                                        \
@@ -540,8 +547,11 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
         case 3: GF_BF_G(3); break;
         case 4: GF_BF_G(4); break;
         case 5: GF_BF_G(5); break;
-        default: GF_BF_G(6); break;
+        case 6: GF_BF_G(6); break;
+        case 7: GF_BF_G(7); break;
+        default: GF_BF_G(8); break;
     }
+    GF_HIP(attr);
 #undef GF_BF_G
 #undef GF_BF_F
 #undef GF_BF
