@@ -561,3 +561,17 @@ def test_trainer_single_node_uses_label_ids(tmp_path):
     assert ev["costBest"] < 0.2 and set(ev) == {"costBest", "costLast"}
     with pytest.raises(AssertionError):                              # an architecture without singleNodeForward is refused
         training.TrainerSingleNode(types.SimpleNamespace(archit=torch.nn.Linear(1, 1)), data, 1, 5)
+
+
+def test_trainer_hip_graph_option_is_inert_off_gpu(tmp_path):
+    """hipGraph=True only changes how the step is launched on a HIP device; on the CPU (the gloo tests, this container) the trainer
+    runs the eager step and retraces the reference run all the same."""
+    import ast
+    from _util import ArrayData
+    d = load(os.path.join(GOLDEN, "trainer_mlp.npz"))
+    m = _trainer_model(d, _mlp(d["S"].shape[1]).double(), str(tmp_path), "mlp")
+    np.random.seed(int(d["seed"]) + 1)
+    tv = m.train(ArrayData(d, torch.float64), int(d["nEpochs"]), int(d["batchSize"]), doSaveVars=False, printInterval=0,
+                 hipGraph=True, **ast.literal_eval(str(d["trainKw"])))
+    assert m.trainer.useGraph and len(m.trainer._graphs) == 0
+    assert np.allclose(tv["lossTrain"], d["lossTrain"], rtol=1e-9, atol=1e-12)
