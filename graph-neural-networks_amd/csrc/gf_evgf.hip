@@ -11,7 +11,9 @@
 // [B,C,N] and are transposed once ([C][N][B] "node-batch" layout) by a tiled kernel.
 //
 // HBM-bound: per tap the algorithmic traffic is the weight stream F*G*nnzp*4 (read once) + the state 2*B*F*G*N*4.
-// Chains are processed chain-major so that the gather panel of the chains in flight (N*B*4 bytes each) is L2-resident.
+// What limits a tap in practice is the gather (every state row is fetched once per incident edge): chain c runs on XCD c % 8
+// (workgroups are dealt to the XCDs round-robin) so that each 4 MB L2 holds ONE gather panel (N*B*4 bytes) at a time, and the
+// gathers are 16 bytes per lane when B % 4 == 0.
 // Everything is deterministic: reductions over b use fixed-order wave shuffles, sums over g/k/f are sequential loops.
 #include <algorithm>
 #include <new>
