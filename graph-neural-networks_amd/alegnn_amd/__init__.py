@@ -8,7 +8,8 @@ Layout mirrors the reference package so that call sites read the same:
     alegnn.utils.graphML.HiddenState / GatedGRNN->  alegnn_amd.utils.graphML.HiddenState / GatedGRNN
     alegnn.modules.architectures.SelectionGNN   ->  alegnn_amd.modules.architectures.SelectionGNN   (+ LocalGNN, NodeVariantGNN,
                                                                                                      GraphRecurrentNN)
-    alegnn.modules.{model,training,evaluation,loss} ->  alegnn_amd.modules.{model,training,evaluation,loss}  (Trainer with batch DP)
+    alegnn.modules.{model,training,evaluation}  ->  alegnn_amd.modules.{model,training,evaluation}  (Trainer with batch DP;
+                                                    losses: any torch loss or the reference's own alegnn.modules.loss wrapper)
 `install(reference_gml)` rebinds the reference's own symbols.
 """
 from .functional import EVGF_edges, LSIGF

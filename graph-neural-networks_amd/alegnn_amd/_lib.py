@@ -33,7 +33,9 @@ _SIGNATURES = {
     "gf_lsigf_forward": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_lsigf_backward": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _i32, _i32, _i32, _i32, _i32, _vp]),
-    "gf_lsigf_pipeline": (_c.c_int, [_c.POINTER(_vp), _i32, _i32, _i32]),
+    "gf_lsigf_pipeline": (_c.c_int, [_c.POINTER(_vp), _i32, _i32, _i32, _i32]),
+    "gf_khop_panel": (_c.c_int, [_c.POINTER(_vp), _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "gf_time_khop_panel": (_c.c_int, [_c.POINTER(_vp), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _c.POINTER(_c.c_float)]),
     "gf_pack_panels": (_c.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gf_unpack_panels": (_c.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gf_spmm_hop_panel": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp]),

@@ -22,19 +22,7 @@ def _rank_world():
 
 
 class Model:
-    def __init__(self,
-                 # Architecture (nn.Module)
-                 architecture,
-                 # Loss Function (nn.modules.loss._Loss)
-                 loss,
-                 # Optimization Algorithm (nn.optim)
-                 optimizer,
-                 # Training Algorithm (modules.training)
-                 trainer,
-                 # Evaluating Algorithm (modules.evaluation)
-                 evaluator,
-                 # Other
-                 device, name, saveDir):
+    def __init__(self, architecture, loss, optimizer, trainer, evaluator, device, name, saveDir):
         self.archit = architecture
         self.archit.to(device)                                      # model.py:69
         self.nParameters = sum(p.numel() for p in self.archit.parameters() if p.dim() > 0)      # :71-79

@@ -11,17 +11,17 @@
 // Two interchangeable pipelines produce bit-for-bit the same interface (x, dy, y, dx in the reference layout; Z / P opaque):
 //   node-major  Z[T][B][N][G]        gathers served by L2            (gf_spmm.hip)     any N, any widths
 //   panels      Z[T][B*G/4][N][4]    gathers served by LDS           (gf_panel.hip)    N <= 10239, G and F in {8,16,32,64,128}
-// gf_lsigf_pipeline() tells which one a (plans, G, F) combination runs; forward and backward always agree because the rule
-// depends only on those arguments (and the process-global tuning knob "pipeline").
+// gf_lsigf_pipeline() tells which one a (plans, G, F, K) combination runs; forward and backward always agree because the rule
+// depends only on those arguments (the experiment knob "pipeline" is refused outside GFHIP_EXPERIMENTS=1 processes).
 #include "gf_common.h"
 
 namespace {
 
-int pick_pipeline(const gf_plan* const* plans, int E, int G, int F) {  // 1 = node-major, 2 = panels, < 0 = error
-    const bool ok = gf_panel_supported(plans, E, G, F);
+int pick_pipeline(const gf_plan* const* plans, int E, int G, int F, int K) {  // 1 = node-major, 2 = panels, < 0 = error
+    const bool ok = gf_panel_supported(plans, E, G, F, K);
     if (g_tune.pipeline == 2 && !ok) {
-        gf_set_error("pipeline 2 (column panels) forced but unsupported here: needs N in [8, %d], G and F in {8, 16, 32, 64, 128}",
-                     kPanelMaxNodes);
+        gf_set_error("pipeline 2 (column panels) forced but unsupported here: needs N in [8, %d], G and F in {8, 16, 32, 64, 128}, "
+                     "and the filter bank (T * G * F floats, both orientations) in LDS", kPanelMaxNodes);
         return GF_ERR_UNSUPPORTED;
     }
     if (g_tune.pipeline == 1) return 1;
@@ -34,25 +34,70 @@ int khop_panel(const gf_plan* const* plans, int E, int op, float* Zp, int B, int
     if (K < 2) return GF_OK;
     for (int e = 0; e < E; ++e) {
         float* first = Zp + (int64_t)(1 + e * (K - 1)) * tap;  // taps 1 + e(K-1) ... of this edge feature are consecutive
-        if (g_tune.panel_fuse_hops) {  // one launch: every workgroup walks its panels through all K-1 hops (zigzag-free, cache-hot reloads)
-            const int rc = gf_spmm_panel_launch(plans[e], op, Zp, first, nPanels, st, K - 1, tap);
+        // the K-1 hops of a panel inside LDS (one launch per edge feature) -- unless there are so few panels that most CUs would
+        // idle: the per-hop kernel can put several workgroups on one panel, the chain cannot (its panel lives in one CU's LDS)
+        if (gf_chain_available(plans[e], op) && (g_tune.panel_chain == 2 || (g_tune.panel_chain == 1 && nPanels * 4 > 256))) {
+            const int rc = gf_spmm_chain_launch(plans[e], op, Zp, first, nPanels, K - 1, tap, st);
             if (rc != GF_OK) return rc;
             continue;
         }
         for (int k = 1; k < K; ++k) {
             const float* src = (k == 1) ? Zp : first + (int64_t)(k - 2) * tap;
-            const int rc = gf_spmm_panel_launch(plans[e], op, src, first + (int64_t)(k - 1) * tap, nPanels, st, 1, 0);
+            const int rc = gf_spmm_panel_launch(plans[e], op, src, first + (int64_t)(k - 1) * tap, nPanels, st);
             if (rc != GF_OK) return rc;
         }
     }
     return GF_OK;
 }
 
+int check_khop_panel_args(const gf_plan* const* plans, int32_t E, int32_t op, const float* Zp, int32_t B, int32_t W, int32_t K) {
+    GF_REQUIRE_ARG(plans && Zp, "gf_khop_panel: NULL argument");
+    GF_REQUIRE_ARG(op == GF_OP_FWD || op == GF_OP_BWD, "gf_khop_panel: op = %d", op);
+    GF_REQUIRE_SHAPE(E > 0 && K > 0 && B > 0 && W > 0 && W % 4 == 0, "gf_khop_panel: bad shape E=%d K=%d B=%d W=%d (W %% 4 == 0)", E, K, B, W);
+    for (int e = 0; e < E; ++e) {
+        GF_REQUIRE_ARG(plans[e] != nullptr, "gf_khop_panel: plan %d is NULL", e);
+        GF_REQUIRE_SHAPE(plans[e]->n == plans[0]->n, "gf_khop_panel: plan %d has %d nodes, plan 0 has %d", e, plans[e]->n, plans[0]->n);
+        GF_REQUIRE_SHAPE(plans[e]->n <= kPanelMaxNodes && plans[e]->mat[op].pn_slices > 0,
+                         "gf_khop_panel: N = %d has no panel image (limit %d)", plans[e]->n, kPanelMaxNodes);
+    }
+    return GF_OK;
+}
+
 }  // namespace
 
-extern "C" int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t G, int32_t F) {
+extern "C" int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t G, int32_t F, int32_t K) {
     GF_REQUIRE_ARG(plans && E > 0 && plans[0], "gf_lsigf_pipeline: NULL plans");
-    return pick_pipeline(plans, E, G, F);
+    GF_REQUIRE_SHAPE(K > 0, "gf_lsigf_pipeline: K = %d", K);
+    return pick_pipeline(plans, E, G, F, K);
+}
+
+extern "C" int gf_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, void* stream) {
+    const int rc = check_khop_panel_args(plans, E, op, Zp, B, W, K);
+    return rc != GF_OK ? rc : khop_panel(plans, E, op, Zp, B, W, K, gf_stream(stream));
+}
+
+extern "C" int gf_time_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K,
+                                  int32_t iters, void* stream, float* avg_ms) {
+    GF_REQUIRE_ARG(avg_ms && iters > 0, "gf_time_khop_panel: bad iters / NULL avg_ms");
+    int rc = check_khop_panel_args(plans, E, op, Zp, B, W, K);
+    if (rc != GF_OK) return rc;
+    hipStream_t st = gf_stream(stream);
+    hipEvent_t e0, e1;
+    GF_HIP(hipEventCreate(&e0));
+    GF_HIP(hipEventCreate(&e1));
+    rc = khop_panel(plans, E, op, Zp, B, W, K, st);  // warm-up
+    if (rc == GF_OK) {
+        GF_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < iters && rc == GF_OK; ++i) rc = khop_panel(plans, E, op, Zp, B, W, K, st);
+        GF_HIP(hipEventRecord(e1, st));
+        GF_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        GF_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z,
@@ -67,7 +112,7 @@ static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const floa
         GF_REQUIRE_ARG(plans[e] != nullptr, "gf_lsigf_forward: plan %d is NULL", e);
         GF_REQUIRE_SHAPE(plans[e]->n == N, "gf_lsigf_forward: plan %d has %d nodes, plan 0 has %d", e, plans[e]->n, N);
     }
-    const int pipe = pick_pipeline(plans, E, G, F);
+    const int pipe = pick_pipeline(plans, E, G, F, K);
     if (pipe < 0) return pipe;
     if (pipe == 2) {
         int rc = gf_pack_panels_launch(x, Z, B, G, Nin, N, gf_stream(stream), nullptr);
@@ -96,7 +141,7 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
         GF_REQUIRE_ARG(plans[e] != nullptr, "gf_lsigf_backward: plan %d is NULL", e);
         GF_REQUIRE_SHAPE(plans[e]->n == N, "gf_lsigf_backward: plan %d has %d nodes, plan 0 has %d", e, plans[e]->n, N);
     }
-    const int pipe = pick_pipeline(plans, E, G, F);
+    const int pipe = pick_pipeline(plans, E, G, F, K);
     if (pipe < 0) return pipe;
     if (pipe == 2) {
         int rc = gf_pack_panels_launch(dy, P, B, F, Nin, N, gf_stream(stream), y_relu);  // P[0] = dy (masked by y > 0) as panels, rows >= Nin zero

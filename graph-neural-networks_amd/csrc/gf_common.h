@@ -85,7 +85,24 @@ struct gf_csr_dev {
     int32_t pn_uniform = 0;
     float pn_uval = 0.f;
     double pn_conflict = 0.0;       // expected LDS cycles per ds_read_b128 step after the bank-aware ordering (diagnostic)
+    // Chain image (gf_chain.hip): the K-1 hops of one panel run inside LDS, outputs are held in registers until every wave has
+    // finished gathering and are then written over the panel.  Because outputs pass through registers, rows need not be
+    // computed in natural order: rows are sorted by degree, chunk c (64 consecutive sorted rows) goes to wave c % cn_waves as its
+    // set c / cn_waves (<= kChainSets sets per wave), so the 64 rows a wave walks together have (almost) equal length -- the ELL
+    // fill that lane = row lockstep wastes in the natural-order octets above (0.61 on the SBM of config 2) goes to ~0.9.
+    // A wave's blocks are stored back to back: group-row g of the stream lives at cn_col*[g * 64 + lane] (same entry words as the
+    // panel image); cn_gtab[w * 16 + 0] = first group-row of wave w, [w * 16 + 1 + r] = end of its block r.
+    int32_t cn_waves = 0;           // waves per workgroup (1, 2, 4, 8, 16); 0 = no chain image
+    int32_t cn_sets = 0;            // row sets per wave
+    uint32_t* cn_rowoff = nullptr;  // [cn_sets][cn_waves * 64]  LDS byte offset (row * 16) of the row of (set, thread); 0xffffffff = none
+    int32_t* cn_gtab = nullptr;     // [cn_waves * 16]
+    uint4* cn_col4 = nullptr;       // value-free stream (uniform plans)
+    uint2* cn_col2 = nullptr;       // weighted stream
+    float4* cn_val4 = nullptr;
+    double cn_fill = 1.0;
+    double cn_conflict = 0.0;
 };
+constexpr int kChainSets = 10;      // 16 waves x 10 sets x 64 rows = 10240 >= kPanelMaxNodes
 constexpr int32_t kPanelMaxNodes = 10239;   // 16 bytes per node + one zero slot in 160 KiB of LDS
 constexpr int32_t kPanelMaxDeg = 65535;
 
@@ -117,16 +134,14 @@ struct gf_tuning {
     int pipeline = 0;           // 0 = auto, 1 = node-major (gather through L2), 2 = column panels through LDS (needs N <= 10239, G%8 == F%8 == 0)
     int panel_uniform = 1;      // 1 = use the value-free stream when the plan detected uniform values
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
-    int panel_fuse_hops = 0;    // 1 = the K-1 hops of a chain are one launch (each workgroup walks its panels through all hops); measured: no gain
+    int panel_chain = 1;        // the K-1 hops of a panel inside LDS (gf_chain.hip): 1 = when there are enough panels to fill the CUs,
+                                // 2 = always, 0 = never (one launch per hop, gf_panel.hip)
     int panel_stagger = 20;     // start delay between workgroup phases: low 4 bits = ~0.5 us quanta per phase step, bits 4+ = log2(phases) - 2
                                 // (20 = 8 phases x 2 us, the measured optimum at N = 1e4); 0 = start together
     int panel_rotate = 1;       // 1 = each workgroup walks the slice list from its own starting offset
     int panel_grid = 0;         // experiments: cap on the panel kernel's grid (0 = one workgroup per LDS-full)
     int bwd_fuse = 1;           // panel pipeline backward: 1 = dx and dh from the adjoint stack in one kernel (G, F <= 32), 0 = separate
     int panel_split = 0;        // workgroups per pass when there are fewer passes than CUs: 0 = as many as fit (<= 8), 1 = off
-    int panel_dma = 0;          // panel load phase: 0 = through registers (global_load + ds_write), 1 = LDS-DMA (global_load_lds_dwordx4)
-    int panel_debug = 0;        // timing experiments only (WRONG RESULTS): 1 = panel loads only, 2 = compute only, 3 = compute only with
-                                // every entry load redirected to the L1-resident sentinel rows, 4 = compute only without stores
     int panel_unit = 8;         // rows per work unit of the panel image: 8 | 4 | 2 (set BEFORE gf_plan_create)
     int panel_np = 0;           // panels per workgroup pass: 0 = heuristic (2 while two workgroups still fit a CU's LDS), 1, 2
     int panel_even = 0;         // 1 = pad every slice to an even number of group-rows (set BEFORE gf_plan_create)
@@ -141,10 +156,15 @@ int gf_contract_launch(const float* Z, const float* h, const float* bias, float*
 bool gf_bwd_fused_supported(int G, int F, int E, int K);
 int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
                               size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st);
-bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F);
+bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F, int K);
+bool gf_contract_panel_fits(int Cin, int Cout, int T);
+bool gf_chain_available(const gf_plan* plan, int op);
+int gf_spmm_chain_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, int nHops, int64_t tapStride,
+                         hipStream_t st);
+// kernels that need more than 64 KiB of dynamic LDS: raise the limit once per (device, kernel), not on every launch
+hipError_t gf_grant_lds(const void* kernel, size_t lds_bytes);
 int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st, const float* mask);
 int gf_layout_masked_launch(const float* dy, const float* y, float* X, int B, int G, int Nin, int N, hipStream_t st);
-int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st, int nHops,
-                         int64_t tapStride);
+int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st);
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
                              int F, int E, int K, int transpose_bank, hipStream_t st);

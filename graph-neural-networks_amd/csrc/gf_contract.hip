@@ -164,7 +164,7 @@ int launch_mfma(const float* Z, const BankView& bank, const float* bias, float* 
     int64_t nblk = (totalTiles + kWaves - 1) / kWaves;
     if (nblk > 256 * wgPerCU) nblk = 256 * wgPerCU;  // persistent: the bank is staged once per workgroup
     auto kern = contract_mfma_kernel<NT, CIN8>;
-    if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, st, Z, bank, bias, out, B, N, Nout, Cout, T,
                        tilesPerB, totalTiles);
     GF_LAUNCH_CHECK("contract_mfma_kernel");
@@ -273,7 +273,7 @@ int launch_panel(const float* Zp, const BankView& bank, const float* bias, float
     int64_t nblk = (totalTiles + kWaves - 1) / kWaves;
     if (nblk > 256 * wgPerCU) nblk = 256 * wgPerCU;
     auto kern = contract_panel_kernel<NT, CIN8>;
-    if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, st, Zp, bank, bias, out, B, N, Nout, Cout, T, tilesPerB,
                        totalTiles);
     GF_LAUNCH_CHECK("contract_panel_kernel");
@@ -293,6 +293,11 @@ int dispatch_cin_panel(int cin8, const float* Zp, const BankView& bank, const fl
 }
 
 }  // namespace
+
+bool gf_contract_panel_fits(int Cin, int Cout, int T) {
+    const int nt = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4);
+    return Cout <= 128 && (size_t)T * Cin * nt * 32 * sizeof(float) <= 160 * 1024;
+}
 
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G, int F,
                              int E, int K, int transpose_bank, hipStream_t st) {

@@ -525,7 +525,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
 #define GF_BF(TT, GG, FF)                                                                                                      \
     do {                                                                                                                        \
         auto kern = bwd_fused_panel_kernel<TT, GG, FF>;                                                                         \
-        if (lds > 64 * 1024) attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024) attr = gf_grant_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, dim3(g.strips), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
                            Nout, B, E, K, g.rowsPerWave);                                                                       \
     } while (0)

@@ -43,8 +43,8 @@ template <int UNIFORM, int NP>
 __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict__ slice, const int32_t* __restrict__ octs,
                                                           const void* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
-                                                          int N, int nSlices, int nPanels, int sentinel, int store_mode, int debug,
-                                                          int stagger, int ush, int nHops, int64_t tapStride, int rotate, int split) {
+                                                          int N, int nSlices, int nPanels, int sentinel, int store_mode,
+                                                          int stagger, int ush, int rotate, int split) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,8 +56,6 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     const int part = (int)(blockIdx.x % (unsigned)split);
     int p = (int)(blockIdx.x / (unsigned)split);
     if (p >= nGroups) return;  // whole workgroup
-    const int dbg = debug & 7;       // timing experiments (see gf_common.h)
-    const bool dma = (debug & 8) != 0;  // panel load phase through LDS-DMA
     f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
     typedef typename ColWord<UNIFORM>::type colw;
     const colw* col4 = reinterpret_cast<const colw*>(cols) + lane;
@@ -98,14 +96,10 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     };
 
     for (;;) {
-      // nHops successive hops of the SAME panel (hops of different panels are independent): hop h reads what hop h-1 of this
-      // workgroup just stored (tap stride tapStride), i.e. from L2 / Infinity Cache instead of an HBM-latency-bound reload,
-      // and the K-1 hops of a chain are one launch.
-      for (int h = 0; h < nHops; ++h) {
-        const float* srcp = (h == 0 ? Xin : Xout + (int64_t)(h - 1) * tapStride) + (int64_t)p * NP * pstride;
-        float* outp = Xout + (int64_t)h * tapStride + (int64_t)p * NP * pstride;
+        const float* srcp = Xin + (int64_t)p * NP * pstride;
+        float* outp = Xout + (int64_t)p * NP * pstride;
         const int nvalid = min(NP, nPanels - p * NP);  // panels of this pass (the last pass may be short)
-        if (dbg != 2 && dbg != 3 && dbg != 4) {
+        {
             // HBM-bound phase: every wave loads its share of the panel (N <= kNVU * blockDim.x rows of 16 bytes).
             // (Requesting the NEXT panel from inside the compute phase instead -- registers, one HBM-latency stall per wave
             // and panel -- was measured and gave nothing: 184 vs 181 us; a CU pulls at most ~22 GB/s from HBM and the
@@ -116,19 +110,6 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
             for (int k = 0; k < NP; ++k) {
                 if (k >= nvalid) break;
                 const f32x4* src = reinterpret_cast<const f32x4*>(srcp + (int64_t)k * pstride);
-                if (dma) {
-                    // LDS-DMA: the wave's 64 rows land as 1 KiB at a wave-uniform LDS base (+ lane * 16), no staging registers and
-                    // no ds_write pass
-                    typedef __attribute__((address_space(3))) void lds_void;
-#pragma unroll
-                    for (int j = 0; j < kNVU; ++j) {
-                        const int row0 = wave * 64 + j * nthr;  // wave-uniform
-                        if (row0 + lane < N)
-                            __builtin_amdgcn_global_load_lds(src + row0 + lane,
-                                                             (lds_void*)(uintptr_t)((unsigned)(k * (N + 1) + row0) * 16u), 16, 0, 0);
-                    }
-                    continue;
-                }
                 f32x4 tmp[kNVU];
 #pragma unroll
                 for (int j = 0; j < kNVU; ++j) tmp[j] = src[min(tid + j * nthr, N - 1)];  // (a non-temporal hint here: no effect)
@@ -138,7 +119,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
             }
         }
         __syncthreads();  // B1: panel p is in LDS
-        if (wave + part * CW < nSlices && dbg != 1) {
+        if (wave + part * CW < nSlices) {
             const int CWS = CW * split;         // slice stride of this wave
             int s = wave + part * CW;           // slice in hand
             // Workgroups walk the slice list rotated by a workgroup-specific offset: at any moment the 256 CUs read different parts
@@ -167,8 +148,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 const bool same = (j0 + kGC) < si.y;  // wave-uniform: the next chunk belongs to the same slice
                 // next chunk: same slice (group-rows per slice are even: a chunk never straddles two blocks), or the head of
                 // the next slice (the sentinel rows when it is empty / absent)
-                int gnext = same ? si.x + j0 + kGC : (sin.y > 0 ? sin.x : sentinel);
-                if (dbg == 3) gnext = sentinel;  // timing experiment: every entry load hits the same (L1-resident) sentinel rows
+                const int gnext = same ? si.x + j0 + kGC : (sin.y > 0 ? sin.x : sentinel);
                 load_chunk(cn, vn, gnext);
 #pragma unroll
                 for (int g = 0; g < kGC; ++g) {
@@ -207,7 +187,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                     return false;
                 }
                 const int row = (oc << ush) + (lane & ((1 << ush) - 1));
-                if (oc >= 0 && row < N && !(dbg == 4 && acc0[0].x != 12345.678f)) {  // debug 4: no stores (timing experiment)
+                if (oc >= 0 && row < N) {
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         if (k >= nvalid) break;
@@ -241,9 +221,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                 if (process(cB, vB, cA, vA)) break;
             }
         }
-        if (nHops > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows have reached L2 before anyone reloads them
         __syncthreads();  // B2: every wave is done reading panel p
-      }
         p += (int)(gridDim.x / (unsigned)split);
         if (p >= nGroups) break;
     }
@@ -309,9 +287,13 @@ unsigned grid_for(int64_t items) {
 
 }  // namespace
 
-bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F) {
+bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F, int K) {
     auto ok = [](int w) { return w == 8 || w == 16 || w == 32 || w == 64 || w == 128; };  // the MFMA contraction's Cin tiles
     if (!ok(G) || !ok(F)) return false;
+    // the panel contraction keeps its whole bank in LDS: both the forward bank (Cin = G) and the transposed one the backward
+    // uses (Cin = F) must fit, otherwise the layer runs node-major (whose contraction has a generic fallback)
+    const int T = gf_num_taps(E, K);
+    if (!gf_contract_panel_fits(G, F, T) || !gf_contract_panel_fits(F, G, T)) return false;
     for (int e = 0; e < E; ++e) {
         if (!plans[e] || plans[e]->n > kPanelMaxNodes || plans[e]->n < 8) return false;
         if (plans[e]->mat[0].pn_slices == 0 || plans[e]->mat[1].pn_slices == 0) return false;
@@ -326,8 +308,7 @@ int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int 
     return GF_OK;
 }
 
-int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st, int nHops,
-                         int64_t tapStride) {
+int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st) {
     const gf_csr_dev& m = plan->mat[op];
     const int N = plan->n;
     GF_REQUIRE_ARG(m.pn_slices > 0, "gf_spmm_hop_panel: the plan has no panel image (N = %d > %d?)", N, kPanelMaxNodes);
@@ -358,18 +339,18 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
         split = nGroups * 4 <= num_cus() ? (int)(grid / nGroups) : 1;
         while (split > 1 && (split * waves > m.pn_slices || split > 8)) --split;
         if (g_tune.panel_split > 0 && split > g_tune.panel_split) split = g_tune.panel_split;
-        if (nHops > 1) split = 1;  // fused hops reload what the same workgroup stored
         grid = (int64_t)nGroups * split;
     }
     if (g_tune.panel_grid > 0 && grid > g_tune.panel_grid) grid = g_tune.panel_grid / split * split;  // experiments: fewer workgroups than CUs
     const bool multipass = nGroups * split > grid;  // staggered starts only pay when a workgroup walks several passes
     typedef void (*kern_t)(const int2*, const int32_t*, const void*, const float4*, float, const float*, float*, int, int, int, int, int,
-                           int, int, int, int, int64_t, int, int);
+                           int, int, int, int);
     kern_t kern = np == 2 ? (uniform ? (kern_t)spmm_panel_kernel<1, 2> : (kern_t)spmm_panel_kernel<0, 2>)
                           : (uniform ? (kern_t)spmm_panel_kernel<1, 1> : (kern_t)spmm_panel_kernel<0, 1>);
-    if (lds > 64 * 1024) GF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, g_tune.panel_debug | (g_tune.panel_dma ? 8 : 0), (wgPerCU > 1 || !multipass) ? 0 : g_tune.panel_stagger, m.pn_ushift, nHops, tapStride, g_tune.panel_rotate, split);
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, (wgPerCU > 1 || !multipass) ? 0 : g_tune.panel_stagger,
+                       m.pn_ushift, g_tune.panel_rotate, split);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }
@@ -397,7 +378,7 @@ extern "C" int gf_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* X
     GF_REQUIRE_ARG(Xin != Xout, "gf_spmm_hop_panel: in-place hop is not supported");
     GF_REQUIRE_SHAPE(n_panels > 0, "gf_spmm_hop_panel: n_panels = %d", n_panels);
     GF_REQUIRE_SHAPE(plan->n <= kPanelMaxNodes, "gf_spmm_hop_panel: N = %d exceeds the LDS panel limit %d", plan->n, kPanelMaxNodes);
-    return gf_spmm_panel_launch(plan, op, Xin, Xout, n_panels, gf_stream(stream), 1, 0);
+    return gf_spmm_panel_launch(plan, op, Xin, Xout, n_panels, gf_stream(stream));
 }
 
 extern "C" int gf_time_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, float* Xout, int32_t n_panels, int32_t iters,

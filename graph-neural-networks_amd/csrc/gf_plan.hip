@@ -3,7 +3,11 @@
 // at N = 1e5 that tensor is 40 GB, the plan is ~25 MB.
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <new>
 #include <numeric>
 #include <vector>
@@ -24,8 +28,34 @@ extern "C" const char* gf_last_error(void) { return g_err; }
 
 gf_tuning g_tune;
 
+// The knobs exist for experiments (A/B timing, forcing a pipeline in tests).  They are process-global, so they are refused unless
+// the process opted in through the environment BEFORE the library was loaded: without GFHIP_EXPERIMENTS=1 g_tune is the built-in
+// default for the life of the process and the product path reads no mutable global state.
+static const bool g_experiments = [] {
+    const char* e = getenv("GFHIP_EXPERIMENTS");
+    return e != nullptr && atoi(e) != 0;
+}();
+
+hipError_t gf_grant_lds(const void* kernel, size_t lds_bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> granted;
+    if (lds_bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (granted.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) granted.insert({dev, kernel});
+    return e;
+}
+
 extern "C" int gf_tune(const char* key, int32_t value) {
     GF_REQUIRE_ARG(key != nullptr, "gf_tune: key is NULL");
+    if (!g_experiments) {
+        gf_set_error("gf_tune('%s'): tuning knobs are for experiments only; set GFHIP_EXPERIMENTS=1 before loading libgfhip.so", key);
+        return GF_ERR_UNSUPPORTED;
+    }
     if (!strcmp(key, "spmm_bt")) g_tune.spmm_bt = value;
     else if (!strcmp(key, "spmm_spw")) g_tune.spmm_spw = value;
     else if (!strcmp(key, "spmm_generic")) g_tune.spmm_generic = value;
@@ -44,14 +74,12 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_even")) g_tune.panel_even = value;
     else if (!strcmp(key, "panel_np")) g_tune.panel_np = value;
     else if (!strcmp(key, "panel_unit")) g_tune.panel_unit = value;
-    else if (!strcmp(key, "panel_debug")) g_tune.panel_debug = value;
-    else if (!strcmp(key, "panel_dma")) g_tune.panel_dma = value;
     else if (!strcmp(key, "panel_split")) g_tune.panel_split = value;
     else if (!strcmp(key, "bwd_fuse")) g_tune.bwd_fuse = value;
     else if (!strcmp(key, "panel_grid")) g_tune.panel_grid = value;
     else if (!strcmp(key, "panel_rotate")) g_tune.panel_rotate = value;
     else if (!strcmp(key, "panel_stagger")) g_tune.panel_stagger = value;
-    else if (!strcmp(key, "panel_fuse_hops")) g_tune.panel_fuse_hops = value;
+    else if (!strcmp(key, "panel_chain")) g_tune.panel_chain = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);
         return GF_ERR_ARG;
@@ -202,6 +230,102 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, gf_csr_dev& d, int64_t&
 const int kB128Group[64] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
                             2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3};
 
+// ELL block of up to 64 rows (lane l walks row rows[l]; rows[l] >= n: no row): appends gmax = max(min_groups, ceil(longest / 4))
+// group-rows of 64 lanes to the three entry streams; empty slots = {column N = the LDS zero slot, value 0}.
+struct EllStreams {
+    std::vector<uint4> col4;   // [group-row][lane] -> 4 LDS byte offsets (column * 16) of steps 4j .. 4j+3 (value-free stream)
+    std::vector<uint2> col2;   // the same as 4 x 16-bit columns (weighted stream: 8 + 16 bytes per group instead of 16 + 16)
+    std::vector<float4> val4;
+    double cycles = 0.0;       // modelled LDS cycles of the ds_read_b128 steps
+    int64_t steps = 0, slots = 0;
+    int32_t group_rows() const { return (int32_t)(col4.size() / 64); }
+    void sentinel_rows(int32_t n, int count) {
+        const uint32_t nn = (uint32_t)n * 16u;
+        for (int i = 0; i < count * 64; ++i) {
+            col4.push_back(make_uint4(nn, nn, nn, nn));
+            col2.push_back(make_uint2((uint32_t)n | ((uint32_t)n << 16), (uint32_t)n | ((uint32_t)n << 16)));
+            val4.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+};
+
+int32_t emit_ell_block(int32_t n, const HostCsr& a, const int32_t* rows, bool reorder, bool even, int32_t min_groups, EllStreams& o) {
+    std::vector<int32_t> rest[64];  // remaining entry indices (into a.col / a.val) per lane
+    int32_t w = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int32_t r = rows[l];
+        if (r >= 0 && r < n) {
+            for (int32_t q = a.rowptr[r]; q < a.rowptr[r + 1]; ++q) rest[l].push_back(q);
+            w = std::max<int32_t>(w, (int32_t)rest[l].size());
+        }
+    }
+    int32_t gmax = even ? ((((w + 3) / 4) + 1) & ~1) : (w + 3) / 4;  // (even: a two-group round never straddles blocks)
+    gmax = std::max(gmax, min_groups);
+    std::vector<int32_t> picks((size_t)gmax * 4 * 64, -1);  // [step][lane] chosen entry (-1 = row exhausted)
+    for (int32_t k = 0; k < w; ++k) {
+        int quadCols[4][16][4];  // per service group, per bank quad: distinct columns already read (up to 4 tracked)
+        int quadCnt[4][16];
+        for (int g = 0; g < 4; ++g)
+            for (int qd = 0; qd < 16; ++qd) quadCnt[g][qd] = 0;
+        int order[64], no = 0;
+        for (int l = 0; l < 64; ++l)
+            if (!rest[l].empty()) order[no++] = l;
+        if (reorder)  // most-constrained first: lanes with the fewest remaining neighbours choose first
+            std::stable_sort(order, order + no, [&](int x, int y) { return rest[x].size() < rest[y].size(); });
+        for (int oi = 0; oi < no; ++oi) {
+            const int l = order[oi], g = kB128Group[l];
+            size_t best = 0;
+            if (reorder) {
+                int bestCost = 1 << 30;
+                for (size_t j = 0; j < rest[l].size(); ++j) {
+                    const int c = a.col[rest[l][j]], qd = c & 15;
+                    int cost = quadCnt[g][qd];
+                    for (int t = 0; t < quadCnt[g][qd] && t < 4; ++t)
+                        if (quadCols[g][qd][t] == c) cost = 0;  // same address: broadcast
+                    if (cost < bestCost) {
+                        bestCost = cost;
+                        best = j;
+                        if (cost == 0) break;
+                    }
+                }
+            }
+            const int32_t q = rest[l][best];
+            rest[l].erase(rest[l].begin() + best);
+            picks[(size_t)k * 64 + l] = q;
+            const int c = a.col[q], qd = c & 15;
+            bool seen = false;
+            for (int t = 0; t < quadCnt[g][qd] && t < 4; ++t) seen = seen || quadCols[g][qd][t] == c;
+            if (!seen) {
+                if (quadCnt[g][qd] < 4) quadCols[g][qd][quadCnt[g][qd]] = c;
+                quadCnt[g][qd]++;
+            }
+        }
+        for (int g = 0; g < 4; ++g) {
+            int mx = 1;
+            for (int qd = 0; qd < 16; ++qd) mx = std::max(mx, quadCnt[g][qd]);
+            o.cycles += mx;
+        }
+        o.steps++;
+    }
+    for (int32_t j = 0; j < gmax; ++j)
+        for (int l = 0; l < 64; ++l) {
+            uint32_t c[4];
+            float v[4];
+            for (int i = 0; i < 4; ++i) {
+                const int32_t q = picks[(size_t)(4 * j + i) * 64 + l];
+                c[i] = (uint32_t)(q >= 0 ? a.col[q] : n) * 16u;
+                v[i] = q >= 0 ? a.val[q] : 0.f;
+            }
+            o.col4.push_back(make_uint4(c[0], c[1], c[2], c[3]));
+            o.col2.push_back(make_uint2((c[0] >> 4) | ((c[1] >> 4) << 16), (c[2] >> 4) | ((c[3] >> 4) << 16)));
+            o.val4.push_back(make_float4(v[0], v[1], v[2], v[3]));
+        }
+    o.slots += (int64_t)gmax * 4 * 64;
+    return gmax;
+}
+
+int upload_chain(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes);
+
 int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     if (n > kPanelMaxNodes) return GF_OK;
     for (int32_t i = 0; i < n; ++i)
@@ -221,89 +345,17 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     if (g_tune.panel_sort)
         std::stable_sort(oct.begin(), oct.begin() + noct, [&](int32_t x, int32_t y) { return omax[x] > omax[y]; });
     std::vector<int2> slice(ns);
-    std::vector<uint4> col4;   // ELL: [slice][group j][lane] -> 4 LDS byte offsets (column * 16) of steps 4j .. 4j+3 (value-free stream)
-    std::vector<uint2> col2;   // the same as 4 x 16-bit columns (weighted stream: 8 + 16 bytes per group instead of 16 + 16)
-    std::vector<float4> val4;
+    EllStreams ell;
     const bool reorder = g_tune.panel_order != 0;
-    double cycles = 0.0;
-    int64_t steps = 0, slots = 0;
-    std::vector<std::vector<int32_t>> rest(64);  // remaining entry indices (into a.col / a.val) per lane
-    std::vector<int32_t> picks;                  // [step][lane] chosen entry (-1 = row exhausted)
-    const uint32_t nn = (uint32_t)n * 16u;
     for (int32_t sl = 0; sl < ns; ++sl) {
-        int32_t w = 0;
+        int32_t rows[64];
         for (int l = 0; l < 64; ++l) {
-            rest[l].clear();
             const int32_t o = oct[(size_t)sl * UPS + (l >> ush)];
-            const int32_t r = o >= 0 ? o * U + (l & (U - 1)) : n;
-            if (r < n) {
-                for (int32_t q = a.rowptr[r]; q < a.rowptr[r + 1]; ++q) rest[l].push_back(q);
-                w = std::max<int32_t>(w, (int32_t)rest[l].size());
-            }
+            rows[l] = o >= 0 ? o * U + (l & (U - 1)) : n;
         }
-        const int32_t gmax = g_tune.panel_even ? ((((w + 3) / 4) + 1) & ~1) : (w + 3) / 4;  // (even: a two-group round never straddles blocks)
-        slice[sl] = make_int2((int32_t)(col4.size() / 64), gmax);   // group-row offset (x 64 lanes), group-steps
-        picks.assign((size_t)gmax * 4 * 64, -1);
-        for (int32_t k = 0; k < w; ++k) {
-            int quadCols[4][16][4];  // per service group, per bank quad: distinct columns already read (up to 4 tracked)
-            int quadCnt[4][16];
-            for (int g = 0; g < 4; ++g)
-                for (int qd = 0; qd < 16; ++qd) quadCnt[g][qd] = 0;
-            int order[64], no = 0;
-            for (int l = 0; l < 64; ++l)
-                if (!rest[l].empty()) order[no++] = l;
-            if (reorder)  // most-constrained first: lanes with the fewest remaining neighbours choose first
-                std::stable_sort(order, order + no, [&](int x, int y) { return rest[x].size() < rest[y].size(); });
-            for (int oi = 0; oi < no; ++oi) {
-                const int l = order[oi], g = kB128Group[l];
-                size_t best = 0;
-                if (reorder) {
-                    int bestCost = 1 << 30;
-                    for (size_t j = 0; j < rest[l].size(); ++j) {
-                        const int c = a.col[rest[l][j]], qd = c & 15;
-                        int cost = quadCnt[g][qd];
-                        for (int t = 0; t < quadCnt[g][qd] && t < 4; ++t)
-                            if (quadCols[g][qd][t] == c) cost = 0;  // same address: broadcast
-                        if (cost < bestCost) {
-                            bestCost = cost;
-                            best = j;
-                            if (cost == 0) break;
-                        }
-                    }
-                }
-                const int32_t q = rest[l][best];
-                rest[l].erase(rest[l].begin() + best);
-                picks[(size_t)k * 64 + l] = q;
-                const int c = a.col[q], qd = c & 15;
-                bool seen = false;
-                for (int t = 0; t < quadCnt[g][qd] && t < 4; ++t) seen = seen || quadCols[g][qd][t] == c;
-                if (!seen) {
-                    if (quadCnt[g][qd] < 4) quadCols[g][qd][quadCnt[g][qd]] = c;
-                    quadCnt[g][qd]++;
-                }
-            }
-            for (int g = 0; g < 4; ++g) {
-                int mx = 1;
-                for (int qd = 0; qd < 16; ++qd) mx = std::max(mx, quadCnt[g][qd]);
-                cycles += mx;
-            }
-            steps++;
-        }
-        // emit the slice's ELL block: gmax group-rows of 64 lanes; empty slots = {column N = the LDS zero slot, value 0}
-        for (int32_t j = 0; j < gmax; ++j)
-            for (int l = 0; l < 64; ++l) {
-                uint32_t c[4];
-                float v[4];
-                for (int i = 0; i < 4; ++i) {
-                    const int32_t q = picks[(size_t)(4 * j + i) * 64 + l];
-                    c[i] = (uint32_t)(q >= 0 ? a.col[q] : n) * 16u;
-                    v[i] = q >= 0 ? a.val[q] : 0.f;
-                }
-                col4.push_back(make_uint4(c[0], c[1], c[2], c[3]));
-                col2.push_back(make_uint2((c[0] >> 4) | ((c[1] >> 4) << 16), (c[2] >> 4) | ((c[3] >> 4) << 16)));
-                val4.push_back(make_float4(v[0], v[1], v[2], v[3]));
-            }
-        slots += (int64_t)gmax * 4 * 64;
+        const int32_t g0 = ell.group_rows();
+        const int32_t gmax = emit_ell_block(n, a, rows, reorder, g_tune.panel_even != 0, 0, ell);
+        slice[sl] = make_int2(g0, gmax);   // group-row offset (x 64 lanes), group-steps
     }
     d.pn_uniform = 0;
     d.pn_uval = 0.f;
@@ -313,22 +365,65 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
         d.pn_uniform = uni ? 1 : 0;
         d.pn_uval = a.val[0];
     }
-    d.pn_conflict = steps ? cycles / (double)steps : 0.0;
-    d.pn_fill = slots ? (double)a.col.size() / (double)slots : 1.0;
-    d.pn_sentinel = (int32_t)(col4.size() / 64);   // two all-sentinel group-rows: what a wave without further work requests
-    for (int i = 0; i < 128; ++i) {
-        col4.push_back(make_uint4(nn, nn, nn, nn));
-        col2.push_back(make_uint2((uint32_t)n | ((uint32_t)n << 16), (uint32_t)n | ((uint32_t)n << 16)));
-        val4.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
-    }
+    d.pn_conflict = ell.steps ? ell.cycles / (double)ell.steps : 0.0;
+    d.pn_fill = ell.slots ? (double)a.col.size() / (double)ell.slots : 1.0;
+    d.pn_sentinel = ell.group_rows();   // two all-sentinel group-rows: what a wave without further work requests
+    ell.sentinel_rows(n, 2);
     int rc;
     if ((rc = upload(slice, &d.pn_slice, bytes))) return rc;
     if ((rc = upload(oct, &d.pn_oct, bytes))) return rc;
-    if (d.pn_uniform && (rc = upload(col4, &d.pn_col4, bytes))) return rc;
-    if ((rc = upload(col2, &d.pn_col2, bytes))) return rc;   // kept for uniform plans too (knob panel_uniform = 0)
-    if ((rc = upload(val4, &d.pn_val4, bytes))) return rc;
+    if (d.pn_uniform && (rc = upload(ell.col4, &d.pn_col4, bytes))) return rc;
+    if ((rc = upload(ell.col2, &d.pn_col2, bytes))) return rc;   // kept for uniform plans too (knob panel_uniform = 0)
+    if ((rc = upload(ell.val4, &d.pn_val4, bytes))) return rc;
     d.pn_slices = ns;
     d.pn_ushift = ush;
+    return upload_chain(n, a, d, bytes);
+}
+
+// ---- chain image (gf_chain.hip; layout described at gf_csr_dev::cn_*) --------------------------------------------------
+int upload_chain(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
+    const int32_t nChunks = (n + 63) / 64;
+    int W = 1;
+    while (W < 16 && (nChunks + W - 1) / W > kChainSets) W <<= 1;
+    const int R = (nChunks + W - 1) / W;
+    if (R > kChainSets) return GF_OK;  // cannot happen for n <= kPanelMaxNodes
+    std::vector<int32_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        return (a.rowptr[x + 1] - a.rowptr[x]) > (a.rowptr[y + 1] - a.rowptr[y]);
+    });
+    const int T = W * 64;
+    std::vector<uint32_t> rowoff((size_t)R * T, 0xffffffffu);
+    std::vector<int32_t> gtab((size_t)W * 16, 0);
+    EllStreams ell;
+    const bool reorder = g_tune.panel_order != 0;
+    for (int w = 0; w < W; ++w) {
+        gtab[(size_t)w * 16] = ell.group_rows();
+        for (int r = 0; r < R; ++r) {
+            const int32_t c = r * W + w;  // chunk: sorted rows 64c .. 64c+63; the waves take the chunks round-robin, so each wave
+                                          // gets the same mix of long and short rows
+            int32_t rows[64];
+            for (int l = 0; l < 64; ++l) {
+                const int64_t pos = (int64_t)c * 64 + l;
+                rows[l] = (c < nChunks && pos < n) ? order[pos] : n;
+                if (rows[l] < n) rowoff[(size_t)r * T + w * 64 + l] = (uint32_t)rows[l] * 16u;
+            }
+            // every block has at least one group-row: the kernel commits a set when its stream position reaches the block's end
+            emit_ell_block(n, a, rows, reorder, false, 1, ell);
+            gtab[(size_t)w * 16 + 1 + r] = ell.group_rows();
+        }
+    }
+    ell.sentinel_rows(n, 2);  // the two-deep prefetch of the last wave runs past its stream
+    d.cn_fill = ell.slots ? (double)a.col.size() / (double)ell.slots : 1.0;
+    d.cn_conflict = ell.steps ? ell.cycles / (double)ell.steps : 0.0;
+    int rc;
+    if ((rc = upload(rowoff, &d.cn_rowoff, bytes))) return rc;
+    if ((rc = upload(gtab, &d.cn_gtab, bytes))) return rc;
+    if (d.pn_uniform && (rc = upload(ell.col4, &d.cn_col4, bytes))) return rc;
+    if ((rc = upload(ell.col2, &d.cn_col2, bytes))) return rc;
+    if ((rc = upload(ell.val4, &d.cn_val4, bytes))) return rc;
+    d.cn_waves = W;
+    d.cn_sets = R;
     return GF_OK;
 }
 
@@ -345,6 +440,11 @@ void free_csr(gf_csr_dev& d) {
     if (d.pn_col4) (void)hipFree(d.pn_col4);
     if (d.pn_col2) (void)hipFree(d.pn_col2);
     if (d.pn_val4) (void)hipFree(d.pn_val4);
+    if (d.cn_rowoff) (void)hipFree(d.cn_rowoff);
+    if (d.cn_gtab) (void)hipFree(d.cn_gtab);
+    if (d.cn_col4) (void)hipFree(d.cn_col4);
+    if (d.cn_col2) (void)hipFree(d.cn_col2);
+    if (d.cn_val4) (void)hipFree(d.cn_val4);
     d = gf_csr_dev{};
 }
 

@@ -111,7 +111,7 @@ int gf_lsigf_backward(const gf_plan* const* plans, int32_t E, const float* dy, c
  * at most 160 KiB = one CU's LDS.  Tap stack Zp[T][B*C/4][N][4] (same size as the node-major stack).
  * gf_lsigf_forward / _backward pick this pipeline by themselves (gf_lsigf_pipeline tells which: 1 node-major, 2 panels);
  * the entry points below expose its stages for tests and profiling. */
-int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t G, int32_t F);
+int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t G, int32_t F, int32_t K);
 /* x [B,C,Nin] -> Xp [B*C/4][N][4], nodes n >= Nin zero (GraphFilter.forward's padding, graphML.py:2131-2135); C % 4 == 0 */
 int gf_pack_panels(const float* x, float* Xp, int32_t B, int32_t C, int32_t Nin, int32_t N, void* stream);
 /* Xp [B*C/4][N][4] -> x [B,C,Nout], nodes n < Nout (graphML.py:2142-2143) */
@@ -120,6 +120,13 @@ int gf_unpack_panels(const float* Xp, float* x, int32_t B, int32_t C, int32_t N,
 int gf_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, float* Xout, int32_t n_panels, void* stream);
 int gf_time_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, float* Xout, int32_t n_panels, int32_t iters,
                            void* stream, float* avg_ms);
+/* the whole tap stack in panel layout, Zp [T][B*W/4][N][4]: tap 0 is the caller's (gf_pack_panels), taps 1 + e(K-1) + (k-1) =
+ * op(S_e)^k tap 0 are written -- the loop at graphML.py:158-161 (matmul per tap + cat).  Each panel is loaded once and walks
+ * its K-1 hops inside LDS (gf_chain.hip); W % 4 == 0.  gf_time_khop_panel: the same call `iters` times between two HIP
+ * events on `stream`, average milliseconds per call (per K-1 hops of every edge feature). */
+int gf_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, void* stream);
+int gf_time_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, int32_t iters,
+                       void* stream, float* avg_ms);
 /* as gf_contract / gf_grad_taps with Z (and P0) in panel layout */
 int gf_contract_panel(const float* Zp, const float* h, const float* bias, float* out, int32_t B, int32_t N, int32_t Nout,
                       int32_t G, int32_t F, int32_t E, int32_t K, int32_t transpose_bank, void* stream);
@@ -201,9 +208,11 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * "pipeline" (0 = auto | 1 = node-major | 2 = column panels), "panel_uniform" (0/1 use the value-free stream),
  * "panel_order" (0/1 bank-aware neighbour order; read by gf_plan_create), "panel_sort" (0/1 octets sorted by longest row; read by gf_plan_create), "panel_stagger" (start delay step between workgroup phases, ~2 us units),
  * "panel_rotate" (0/1 per-workgroup rotated slice walk), "panel_np" (0 = heuristic | 1 | 2 panels per pass), "panel_split" (workgroups per pass
- * for small batches: 0 = as many as fit, 1 = off), "panel_dma" (0/1 panel load through LDS-DMA), "panel_fuse_hops" (0/1 the K-1 hops of a
- * chain in one launch), "panel_debug" (timing experiments, WRONG results when non-zero), "gradw_lds" (0/1), "bwd_fuse" (0/1 dx and dh of the
- * panel pipeline in one pass over the adjoint stack when G, F <= 32).  Process-global, not thread-safe: for benchmarks and tests only. */
+ * for small batches: 0 = as many as fit, 1 = off), "panel_chain" (0/1 the K-1 hops of a panel inside LDS, gf_chain.hip), "gradw_lds" (0/1),
+ * "bwd_fuse" (0/1 dx and dh of the panel pipeline in one pass over the adjoint stack when G, F <= 32).
+ * EXPERIMENTS ONLY: the knobs are process-global and not thread-safe, so gf_tune is refused (GF_ERR_UNSUPPORTED) unless the
+ * environment variable GFHIP_EXPERIMENTS=1 was set when the library was loaded; without it the tuning state is the built-in
+ * default and immutable, i.e. the product path reads no mutable global state.  Every setting gives identical results. */
 int gf_tune(const char* key, int32_t value);
 
 #ifdef __cplusplus

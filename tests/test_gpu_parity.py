@@ -290,13 +290,13 @@ def test_trainer_on_gpu_follows_reference_training_run(tmp_path):
     (tests/golden/make_golden.py trainer_case 'selgnn'; reference on CPU in float64, here float32 on the GPU)."""
     import ast
     from _util import ArrayData
-    from alegnn_amd.modules import evaluation, loss, model, training
+    from alegnn_amd.modules import evaluation, model, training
     d = load(os.path.join(GOLDEN, "trainer_selgnn.npz"))
     net = SelectionGNN([1, 8, 8], [3, 3], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [5], d["S"][0])
     net.load_state_dict({k[5:]: torch.tensor(v) for k, v in d.items() if k.startswith("init:")})
     net = net.float()
     optim = torch.optim.Adam(net.parameters(), lr=0.005, betas=(0.9, 0.999))
-    m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim, training.Trainer,
+    m = model.Model(net, torch.nn.CrossEntropyLoss(), optim, training.Trainer,
                     evaluation.evaluate, DEV, "selgnn", str(tmp_path))
     data = ArrayData(d, torch.float32)
     np.random.seed(int(d["seed"]) + 1)
@@ -319,7 +319,7 @@ def test_trainer_hip_graph_replay_is_bit_identical_to_eager(tmp_path):
     uneven last batch) must retrace the eager run exactly -- same kernels, same order."""
     import ast
     from _util import ArrayData
-    from alegnn_amd.modules import evaluation, loss, model, training
+    from alegnn_amd.modules import evaluation, model, training
     d = load(os.path.join(GOLDEN, "trainer_selgnn.npz"))
 
     def run(tag, **kw):
@@ -327,7 +327,7 @@ def test_trainer_hip_graph_replay_is_bit_identical_to_eager(tmp_path):
         net.load_state_dict({k[5:]: torch.tensor(v) for k, v in d.items() if k.startswith("init:")})
         net = net.float()
         optim = torch.optim.Adam(net.parameters(), lr=0.005, betas=(0.9, 0.999))
-        m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim, training.Trainer, evaluation.evaluate,
+        m = model.Model(net, torch.nn.CrossEntropyLoss(), optim, training.Trainer, evaluation.evaluate,
                         DEV, tag, str(tmp_path))
         np.random.seed(5)
         tv = m.train(ArrayData(d, torch.float32), 3, 40, printInterval=0, validationInterval=2, doSaveVars=False, **kw)   # 40 + 40 + 16
@@ -550,7 +550,7 @@ def test_config4_size_node_major_vs_oracle():
     layer = gml.GraphFilter(G, F, K, 1, True)
     layer.addGSO(A)
     layer.to(DEV)
-    assert _lib.lib().gf_lsigf_pipeline(layer._gso.plans(DEV), 1, G, F) == 1
+    assert _lib.lib().gf_lsigf_pipeline(layer._gso.plans(DEV), 1, G, F, K) == 1
     x = torch.randn(B, G, N, device=DEV, requires_grad=True)
     y = layer(x)
     dy = torch.randn_like(y)
@@ -704,7 +704,7 @@ def tune(**kw):
 @pytest.fixture
 def pipeline_knob():
     yield tune
-    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_fuse_hops=0, panel_np=0)
+    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_chain=1, panel_np=0)
 
 
 def to_panels(x, N):
@@ -772,6 +772,79 @@ def test_spmm_hop_panel_against_scipy(N, P, kind, pipeline_knob):
             _lib.check(L.gf_spmm_hop_panel(plans[0], op, Xt.data_ptr(), out2.data_ptr(), P, stream()))
             pipeline_knob(panel_np=0)
             assert torch.equal(out, out2)                    # bitwise deterministic, whatever the pass width
+
+
+@pytest.mark.parametrize("N,B,W,K,kind", [
+    (37, 3, 8, 3, "weighted"), (64, 2, 4, 2, "uniform"), (100, 5, 8, 5, "weighted"), (641, 7, 8, 4, "uniform"),
+    (1300, 3, 32, 5, "weighted"), (2600, 9, 16, 3, "uniform"), (5200, 40, 8, 3, "weighted"), (5121, 33, 32, 5, "uniform"),
+    (10000, 30, 32, 5, "uniform"), (10239, 70, 8, 4, "weighted"), (9000, 1, 4, 6, "weighted"),
+], ids=lambda v: str(v))
+def test_khop_panel_chain_against_scipy(N, B, W, K, kind, pipeline_knob):
+    """The K-1 hops of a panel inside LDS (gf_chain.hip) against scipy, tap by tap and for both operators: 1 .. 16 waves per
+    workgroup, 1 .. 10 row sets per wave, more panels than workgroups and fewer, empty rows / columns, a hub row, value-free
+    and weighted streams; the per-hop kernel must agree to round-off (different summation order), two runs bitwise."""
+    L = _lib.lib()
+    rng = np.random.RandomState(N + K)
+    A = sp.random(N, N, density=min(0.5, 9.0 / N), format="lil", random_state=rng, data_rvs=rng.randn)
+    A[N // 2, :] = 0                                        # empty row
+    A[:, N // 3] = 0                                        # empty column
+    hub = rng.choice(N, size=min(N, 300), replace=False)    # one long row and one long column
+    A[1, hub] = rng.randn(len(hub))
+    A[hub, 2] = rng.randn(len(hub))
+    A = sp.csr_matrix(A)
+    A = A * (1.0 / max(1.0, abs(A).sum(axis=1).max(), abs(A).sum(axis=0).max()))   # powers stay O(1)
+    if kind == "uniform":
+        A.data[:] = 0.5 / max(1, np.diff(A.indptr).max(), np.diff(A.tocsc().indptr).max())
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    x = rng.randn(B, W, N).astype(np.float32)
+    P = B * W // 4
+    for op, M in ((0, A.T.tocsr().astype(np.float64)), (1, A.astype(np.float64))):
+        Zs = {}
+        for chain in (2, 0):
+            pipeline_knob(panel_chain=chain)
+            Z = torch.full((K, P, N, 4), float("nan"), device=DEV)
+            Z[0] = cu(to_panels(x, N))
+            _lib.check(L.gf_khop_panel(plans, 1, op, Z.data_ptr(), B, W, K, stream()))
+            Zs[chain] = Z
+        again = Zs[2].clone()
+        again[1:] = float("nan")
+        pipeline_knob(panel_chain=2)
+        _lib.check(L.gf_khop_panel(plans, 1, op, again.data_ptr(), B, W, K, stream()))
+        assert torch.equal(again, Zs[2])                                       # bitwise run-to-run
+        tap = x.astype(np.float64)
+        got = Zs[2].cpu().numpy()
+        for k in range(1, K):
+            tap = np.stack([(M @ tap[b].T).T for b in range(B)])               # [B, W, N]
+            want = to_panels(tap, N)
+            scale = max(np.abs(want).max(), 1e-30)
+            assert np.abs(got[k] - want).max() < 2e-6 * scale * k, (op, k)
+            assert np.abs(Zs[0][k].cpu().numpy() - want).max() < 2e-6 * scale * k, (op, k, "per-hop")
+
+
+def test_khop_panel_chain_keeps_nonfinite_values_local():
+    """A NaN in one node's signal reaches exactly the nodes within k hops of it (padding slots gather from the zero slot)."""
+    L = _lib.lib()
+    N, B, W, K = 700, 2, 8, 3
+    A = graphgen.sbm(N, seed=3, directed=True)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    x = np.random.RandomState(0).randn(B, W, N).astype(np.float32)
+    x[:, :, 0] = np.nan
+    Z = torch.zeros((K, B * W // 4, N, 4), device=DEV)
+    Z[0] = cu(to_panels(x, N))
+    tune(panel_chain=2)
+    try:
+        _lib.check(L.gf_khop_panel(plans, 1, 1, Z.data_ptr(), B, W, K, stream()))
+    finally:
+        tune(panel_chain=1)
+    reach = np.zeros(N, dtype=bool)
+    reach[0] = True
+    pat = (A != 0).astype(np.int8).tocsr()
+    for k in range(1, K):
+        reach = np.asarray(pat @ reach.astype(np.int8)).ravel() > 0
+        bad = np.isnan(Z[k].cpu().numpy()).any(axis=(0, 2))
+        assert np.array_equal(bad, reach), k
 
 
 def test_spmm_hop_panel_does_not_spread_nonfinite_values():
@@ -848,7 +921,7 @@ def test_lsigf_golden_under_both_pipelines(path, pipe, pipeline_knob):
     pipeline_knob(pipeline=pipe)
     gso = SparseGSO.from_any(d["S"])
     F, E, K, G = d["h"].shape
-    assert _lib.lib().gf_lsigf_pipeline(gso.plans(DEV), E, G, F) == pipe
+    assert _lib.lib().gf_lsigf_pipeline(gso.plans(DEV), E, G, F, K) == pipe
     h, x = cu(d["h"], True), cu(d["x"], True)
     b = cu(d["b"], True) if "b" in d else None
     y = LSIGF(h, gso, x, b)
@@ -866,20 +939,19 @@ def test_pipelines_agree_at_full_size(cfg2, pipeline_knob):
     layer, x = cfg2["layer"], cfg2["x"]
     dy = torch.randn(x.shape[0], layer.F, x.shape[2], device=DEV)
     res = {}
-    for pipe in (1, 2, 3):                                  # 3 = panels with the K-1 hops of a chain fused into one launch
-        pipeline_knob(pipeline=min(pipe, 2), panel_fuse_hops=int(pipe == 3))
+    for pipe in (1, 2, 3):                                  # 2 = panels, K-1 hops of a panel inside LDS (default); 3 = one launch per hop
+        pipeline_knob(pipeline=min(pipe, 2), panel_chain=int(pipe == 2))
         xx = x.detach().clone().requires_grad_(True)
         for p_ in layer.parameters():
             p_.grad = None
         y = layer(xx)
         y.backward(dy)
         res[pipe] = (y.detach().clone(), xx.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone())
-    pipeline_knob(pipeline=0, panel_fuse_hops=0)
-    assert _lib.lib().gf_lsigf_pipeline(layer._gso.plans(DEV), 1, layer.G, layer.F) == 2
-    for a, b_ in zip(res[1], res[2]):
-        assert float((a - b_).abs().max()) <= 2e-6 * float(a.abs().max())
-    for a, b_ in zip(res[2], res[3]):
-        assert torch.equal(a, b_)                            # same kernel, same order: bitwise
+    pipeline_knob(pipeline=0, panel_chain=1)
+    assert _lib.lib().gf_lsigf_pipeline(layer._gso.plans(DEV), 1, layer.G, layer.F, layer.K) == 2
+    for other in (2, 3):                                     # three kernels, three summation orders: fp32 round-off apart
+        for a, b_ in zip(res[1], res[other]):
+            assert float((a - b_).abs().max()) <= 2e-6 * float(a.abs().max())
 
 
 @pytest.mark.parametrize("cfg", [
@@ -889,7 +961,7 @@ def test_pipelines_agree_at_full_size(cfg2, pipeline_knob):
     dict(N=64, B=2, G=8, F=8, K=3, E=1, nin=64, density=0.0),            # empty GSO: y = h_0 x + b
     dict(N=5200, B=9, G=8, F=8, K=3, E=1, nin=5200, density=0.002),      # 1024-thread panel workgroups, ragged last slice
 ], ids=lambda c: "N%d_G%d_F%d_K%d_E%d_Nin%d" % (c["N"], c["G"], c["F"], c["K"], c["E"], c["nin"]))
-@pytest.mark.parametrize("pipe", [1, 2, 3], ids=["node_major", "panels", "panels_fused_hops"])
+@pytest.mark.parametrize("pipe", [1, 2, 3], ids=["node_major", "panels_chain", "panels_per_hop"])
 def test_lsigf_edge_cases_under_both_pipelines(cfg, pipe, pipeline_knob):
     N, B, G, F, K, E, nin = (cfg[k] for k in ("N", "B", "G", "F", "K", "E", "nin"))
     rng = np.random.RandomState(N + K)
@@ -897,9 +969,9 @@ def test_lsigf_edge_cases_under_both_pipelines(cfg, pipe, pipeline_knob):
     for e in range(E):
         A = sp.random(N, N, density=cfg["density"], format="csr", random_state=rng, data_rvs=rng.randn)
         mats.append(A * (0.5 / max(1.0, abs(A).sum(axis=1).max())) if A.nnz else A)
-    pipeline_knob(pipeline=min(pipe, 2), panel_fuse_hops=int(pipe == 3))
+    pipeline_knob(pipeline=min(pipe, 2), panel_chain=2 if pipe == 2 else 0)       # 2 = chain kernel whatever the panel count
     gso = SparseGSO(mats)
-    assert _lib.lib().gf_lsigf_pipeline(gso.plans(DEV), E, G, F) == min(pipe, 2)
+    assert _lib.lib().gf_lsigf_pipeline(gso.plans(DEV), E, G, F, K) == min(pipe, 2)
     h = (rng.uniform(-1, 1, (F, E, K, G)) / np.sqrt(G * K)).astype(np.float32)
     x = rng.randn(B, G, nin).astype(np.float32)
     b = rng.uniform(-1, 1, (F, 1)).astype(np.float32)

@@ -1,6 +1,7 @@
 """CPU-only tests: host-side logic of the package and the C-ABI surface (no compute calls -- no GPU here)."""
 import ctypes
 import os
+import sys
 import re
 import types
 
@@ -61,6 +62,20 @@ def test_c_abi_error_convention_without_gpu():
     assert L.gf_nvgf_backward(None, 1, None, None, None, None, None, None, 0, B, G, F, K, N, None) == -2
     assert L.gf_nvgf_fold_taps(None, None, None, None, 10, 5, 2, None) == -2
     assert L.gf_tune(b"bwd_fuse", 1) == 0 and L.gf_tune(b"panel_split", 0) == 0 and L.gf_tune(b"no_such_knob", 1) != 0
+
+
+def test_tuning_knobs_are_refused_outside_experiment_processes():
+    """gf_tune is process-global state; a process that did not set GFHIP_EXPERIMENTS=1 before loading the library cannot change it
+    (GF_ERR_UNSUPPORTED = -4), so the product path never reads mutable global state."""
+    import subprocess
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.gf_last_error.restype = ctypes.c_char_p; "
+            "rc = L.gf_tune(b'pipeline', 1); print(rc, L.gf_last_error().decode())")
+    env = {k: v for k, v in os.environ.items() if k != "GFHIP_EXPERIMENTS"}
+    out = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.startswith("-4 ") and "GFHIP_EXPERIMENTS" in out
+    env["GFHIP_EXPERIMENTS"] = "1"
+    out = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.startswith("0 ")
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -334,10 +349,10 @@ def _mlp(N, nClasses=5):
 
 
 def _trainer_model(d, archit, saveDir, name, trainer=None):
-    from alegnn_amd.modules import evaluation, loss, model, training
+    from alegnn_amd.modules import evaluation, model, training
     archit.load_state_dict({k[5:]: torch.tensor(v) for k, v in d.items() if k.startswith("init:")})
     optim = torch.optim.Adam(archit.parameters(), lr=0.005, betas=(0.9, 0.999))
-    return model.Model(archit, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim,
+    return model.Model(archit, torch.nn.CrossEntropyLoss(), optim,
                        trainer or training.Trainer, evaluation.evaluate, 'cpu', name, saveDir)
 
 
@@ -519,7 +534,7 @@ print("OK")
 def test_trainer_single_node_uses_label_ids(tmp_path):
     """TrainerSingleNode / evaluateSingleNode (training.py:580-714, evaluation.py:91-168): the loss is taken at one target node
     per sample, looked up through data.getLabelID(split[, indices]) and archit.singleNodeForward(x, ids)."""
-    from alegnn_amd.modules import evaluation, loss, model, training
+    from alegnn_amd.modules import evaluation, model, training
 
     class Net(torch.nn.Module):
         def __init__(self):
@@ -552,7 +567,7 @@ def test_trainer_single_node_uses_label_ids(tmp_path):
 
     net, data = Net(), Data()
     optim = torch.optim.SGD(net.parameters(), lr=0.05)
-    m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.MSELoss), optim, training.TrainerSingleNode,
+    m = model.Model(net, lambda est, tgt: torch.nn.functional.mse_loss(est.squeeze(1), tgt), optim, training.TrainerSingleNode,
                     evaluation.evaluateSingleNode, 'cpu', 'sn', str(tmp_path))
     np.random.seed(0)
     tv = m.train(data, 40, 5, printInterval=0, doSaveVars=False)

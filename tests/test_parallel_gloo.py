@@ -81,7 +81,7 @@ def _trainer_worker(rank, world, port, saveDir, ret):
     import ast
     import numpy as np
     from _util import GOLDEN, ArrayData, load
-    from alegnn_amd.modules import evaluation, loss, model, training
+    from alegnn_amd.modules import evaluation, model, training
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -91,7 +91,7 @@ def _trainer_worker(rank, world, port, saveDir, ret):
         if rank == 0:                                   # only rank 0 starts from the reference's weights: Trainer broadcasts
             net.load_state_dict({k[5:]: torch.tensor(v) for k, v in d.items() if k.startswith("init:")})
         optim = torch.optim.Adam(net.parameters(), lr=0.005, betas=(0.9, 0.999))
-        m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim, training.Trainer,
+        m = model.Model(net, torch.nn.CrossEntropyLoss(), optim, training.Trainer,
                         evaluation.evaluate, 'cpu', 'mlp', saveDir)
         np.random.seed(int(d["seed"]) + 1 if rank == 0 else 12345)      # rank 0's permutation is the one used
         data = ArrayData(d, torch.float64)
