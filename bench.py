@@ -129,7 +129,7 @@ def main():
     #      launch stream (gf_time_spmm_hop*: hipEventRecord on that stream around `iters` back-to-back launches) -----------
     L = _lib.lib()
     plans = layer._gso.plans(dev)
-    pipe = L.gf_lsigf_pipeline(plans, 1, G, F)
+    pipe = L.gf_lsigf_pipeline(plans, 1, G, F, K)
     ms = np.zeros(1, dtype=np.float32)
     stream = torch.cuda.current_stream().cuda_stream
     msp = ms.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
@@ -196,7 +196,7 @@ def kernel_breakdown(L, layer, plans, x, dy, B, N, G, F, K, dev):
     ws = torch.empty(nb // 4 + 1, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     w, b = layer.weight.detach(), layer.bias.detach()
-    if L.gf_lsigf_pipeline(plans, 1, G, F) == 2:
+    if L.gf_lsigf_pipeline(plans, 1, G, F, K) == 2:
         def khop(buf, op, width):                            # as separate launches (the layer fuses the K-1 hops of a chain)
             tap = B * N * width
             for k in range(1, K):

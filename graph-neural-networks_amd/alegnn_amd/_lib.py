@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgfhip.so")
+if os.environ.get("GFHIP_EXPERIMENTS") == "1" and os.environ.get("GFHIP_LIB"):   # A/B builds of the library (Makefile `variant`)
+    LIB_PATH = os.environ["GFHIP_LIB"]
 
 GF_OK, GF_ERR_SHAPE = 0, -1
 GF_OP_FWD, GF_OP_BWD = 0, 1

@@ -3,16 +3,21 @@
 // concatenated at :161); same column-panel layout Xp[P][N][4] (gf_panel.hip).
 //
 // What changes against the per-hop panel kernel:
-//   * A workgroup loads a panel ONCE (N*16 bytes, coalesced), runs hop 1 .. K-1 on it inside LDS and stores every tap with
-//     coalesced full-line stores.  HBM traffic per chain = (1 + (K-1)) * panel instead of 2 * (K-1) * panel: the K-2 re-reads
-//     of the algorithmic count (SURVEY.md 8d counts a read and a write per hop) never happen.
+//   * A workgroup loads a panel ONCE (N*16 bytes, coalesced, LDS-DMA), runs hop 1 .. K-1 on it inside LDS and stores every tap
+//     with coalesced full-line stores.  HBM traffic per chain = (1 + (K-1)) * panel instead of 2 * (K-1) * panel: the K-2
+//     re-reads of the algorithmic count (SURVEY.md 8d counts a read and a write per hop) never happen.
 //   * A hop's outputs stay in registers (4 floats per row per lane, <= kChainSets rows per lane) until every wave has finished
 //     gathering from the panel; then they are written over the panel in natural row order and the panel is the next hop's
 //     source.  Because outputs pass through registers, the rows a wave computes together need not be neighbours in memory:
-//     the plan sorts rows by degree (gf_plan.hip, upload_chain) and lane = row lockstep wastes ~10 % of the gathers on
+//     the plan sorts rows by degree (gf_plan.hip, upload_chain) and lane = row lockstep wastes ~10-15 % of the gathers on
 //     padding instead of the 39 % of natural-order octets.
-//   * per hop two workgroup barriers (gathers done | panel rewritten); the tap's HBM store reads the rewritten panel and runs
-//     under the next hop's gathers; the next panel is requested by LDS-DMA chunk by chunk inside the last tap's store sweep.
+//   * Roles: waves 0 .. Wc-1 gather; the LAST wave(s) are storers: during hop h+1 they stream the panel (= tap h, which the
+//     gatherers are reading) to HBM.  The gatherers never have a store in flight (loads and stores share vmcnt and complete out
+//     of order with each other -- a wave with both pending can only wait for vmcnt(0), i.e. for the stores), and the tap stores
+//     (160 KB per hop, ~8 us of a CU's store path) run under the gathers instead of between them.  First version without the storer: every wave stored its share after the rewrite, 250 us per hop at
+//     config 2 against 150 us for the per-hop kernel.
+//   * per hop two workgroup barriers (gathers done | panel rewritten).  After the last hop every wave takes part in one sweep
+//     that stores the last tap and requests the next panel chunk by chunk (a wave overwrites only what it has just read back).
 // Determinism: each row's sum runs in the plan's fixed neighbour order in one lane; no atomics.
 #include "gf_common.h"
 
@@ -22,87 +27,149 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-template <int UNIFORM> struct ChainCol { typedef u32x2 type; };   // weighted stream: 4 x 16-bit columns (+ 4 values)
-template <> struct ChainCol<1> { typedef u32x4 type; };            // value-free stream: 4 LDS byte offsets
-
+typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned kNoRow = 0xffffffffu;
+
+#ifdef GF_CHAIN_TRACE  // experiment builds only (make variant EXTRA=-DGF_CHAIN_TRACE): per-phase s_memtime stamps of the first workgroups
+__device__ unsigned long long* g_chain_trace = nullptr;
+#define GF_STAMP(ev)                                                                                                  \
+    do {                                                                                                              \
+        if (g_chain_trace && blockIdx.x < 8 && p == (int)blockIdx.x + (int)gridDim.x && lane == 0 && (wave == 0 || !gatherer)) \
+            g_chain_trace[((blockIdx.x * 8 + h) * 2 + (gatherer ? 0 : 1)) * 8 + (ev)] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
+#else
+#define GF_STAMP(ev) do { } while (0)
+#endif
+constexpr int kWaitVm0 = 0x0F70;  // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields at their maxima) in the gfx9 encoding
 
 template <int UNIFORM>
 __global__ __launch_bounds__(1024) void spmm_chain_kernel(const int32_t* __restrict__ gtab, const uint32_t* __restrict__ rowoff,
                                                           const void* __restrict__ cols, const float4* __restrict__ vals, float uval,
                                                           const float* __restrict__ Xin, float* __restrict__ Xout, int N, int nPanels,
-                                                          int R, int nHops, int64_t tapStride, int store_mode) {
+                                                          int R, int nHops, int64_t tapStride, int store_mode, int nStorers) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = (int)blockDim.x;
+    const int nW = (int)(blockDim.x >> 6);          // waves of the workgroup
+    const int Wc = nW - nStorers;                   // gatherers; the last nStorers waves store
+    const int Tc = Wc * 64;
+    const bool gatherer = wave < Wc;
     f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
     // gathers address LDS absolutely (see gf_panel.hip): the dynamic panel is the only LDS object, so it starts at address 0
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
-    typedef typename ChainCol<UNIFORM>::type colw;
-    const colw* col4 = reinterpret_cast<const colw*>(cols) + lane;
+    const u32x4* col4 = reinterpret_cast<const u32x4*>(cols) + lane;  // [word][lane]: 8 x 16-bit columns = two group-rows
     const f32x4* val4 = reinterpret_cast<const f32x4*>(vals) + lane;
 
-    unsigned ro[kChainSets];  // LDS byte offset of the row this lane computes in set r
+    // the row this lane computes in set r, two 16-bit row indices per register (0xffff = none); kept in registers: re-deriving them
+    // per hop made the compiler hoist a dozen 64-bit addresses out of the loops and spill them
+    unsigned ro2[kChainSets / 2];
 #pragma unroll
-    for (int r = 0; r < kChainSets; ++r) ro[r] = r < R ? rowoff[(int64_t)r * T + tid] : kNoRow;
-    const int gv = gtab[wave * 16 + (lane & 15)];          // lane i (< 16) holds entry i of this wave's table
+    for (int r = 0; r < kChainSets; r += 2) {
+        const unsigned lo = (gatherer && r < R) ? rowoff[(int64_t)r * Tc + tid] : kNoRow;
+        const unsigned hi = (gatherer && r + 1 < R) ? rowoff[(int64_t)(r + 1) * Tc + tid] : kNoRow;
+        ro2[r / 2] = (lo == kNoRow ? 0xffffu : lo >> 4) | ((hi == kNoRow ? 0xffffu : hi >> 4) << 16);
+    }
+    static_assert(kChainSets % 2 == 0, "row indices are packed in pairs");
+    // lane i < 16 holds entry i of this wave's table (0: first word, 1 + r: end of block r), lane 16 + r: block r has an odd number of group-rows
+    const int gv = gatherer ? gtab[wave * 32 + (lane & 31)] : 0;
     const int gbeg = __builtin_amdgcn_readlane(gv, 0);
     if (tid == 0) lds4[N] = (f32x4){0.f, 0.f, 0.f, 0.f};   // the zero slot empty ELL slots gather from
-    const int nj = (N + T - 1) / T;                        // rows per thread in the load / store phases (<= kChainSets)
+    const int nChunks = (N + 63) >> 6;                     // 64-row chunks = 1 KiB of the panel
     const int64_t pstride4 = (int64_t)N;                   // float4 per panel
 
     // Panel loads go through LDS-DMA (global_load_lds_dwordx4): a wave's 64 rows land as 1 KiB at a wave-uniform LDS base
-    // (+ lane * 16) without passing through registers, so the NEXT panel can be requested while the last tap of the current one
-    // is still being stored -- chunk by chunk, each wave overwriting only the rows it has just read back itself.
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto dma_chunk = [&](const f32x4* src, int j) {  // rows wave*64 + j*T ... + 63 of the panel at src
-        const int row0 = wave * 64 + j * T;          // wave-uniform
+    // (+ lane * 16) without passing through registers.
+    auto dma_chunk = [&](const f32x4* src, int c) {  // rows 64c .. 64c+63 of the panel at src
+        const int row0 = c * 64;                     // wave-uniform
         if (row0 + lane < N)
             __builtin_amdgcn_global_load_lds(src + row0 + lane, (lds_void*)(uintptr_t)((unsigned)row0 * 16u), 16, 0, 0);
     };
+
+    // Barrier for the LDS hand-offs inside a panel: LDS operations complete, global stores stay in flight (__syncthreads() would
+    // wait for vmcnt(0): the storers would sit out the HBM latency of their last stores at every barrier; nobody in this kernel
+    // reads what they store).
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     int p = (int)blockIdx.x;
     if (p >= nPanels) return;
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(Xin) + (int64_t)p * pstride4;
-        for (int j = 0; j < nj; ++j) dma_chunk(src, j);
+        for (int c = wave; c < nChunks; c += nW) dma_chunk(src, c);
     }
     for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the panel has landed
-        __syncthreads();                                   // ... and everybody else's
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);  // this wave's share of the panel has landed (and its stores of the last sweep are out)
+        __syncthreads();                       // ... and everybody else's
         const int pn = p + (int)gridDim.x;
+        f32x4* outp = reinterpret_cast<f32x4*>(Xout) + (int64_t)p * pstride4;
         for (int h = 0; h < nHops; ++h) {
-            // The wave's stream of group-rows, two in flight in two register sets (A, B) that alternate strictly per group-row --
-            // also across block boundaries, so a block starts on A or on B (`par`, wave-uniform) and exists in both variants.
-            // Each block is its own loop and assigns its set's accumulators exactly once, outside any loop: the accumulators of
-            // the other sets are merely live across it (a single stream loop that commits into acc[r] through a switch made the
-            // register allocator shuffle all 40 accumulator registers on every iteration).
             f32x4 acc[kChainSets];
-            {
-                int g = gbeg;
+            GF_STAMP(0);
+            if (!gatherer) {
+                // storer: the panel holds tap h (h >= 1: the output of the previous hop; tap 0 is the caller's) -- stream it out
+                // while the gatherers read it
+                if (h > 0) {
+                    // One wave has to push 160 KB per hop.  An LDS read takes several hundred cycles to come back while 15 waves gather,
+                    // so the reads run one round (kSt chunks = kSt KiB) ahead of the stores in a second register set: stage 1 of the
+                    // trace (4 chunks per round, read - wait - store) moved 12 GB/s per CU, 8 per round 15.5 GB/s (10.3 us per hop,
+                    // the gatherers done after 6.7 us and waiting).
+                    f32x4* out = outp + (int64_t)(h - 1) * (tapStride / 4);
+                    constexpr int kSt = 4;
+                    const int sw = wave - Wc;                        // which storer this is
+                    const int cPer = (nChunks + nStorers - 1) / nStorers;
+                    const int cLo = sw * cPer, cHi = min(nChunks, cLo + cPer);  // its contiguous share of the chunks
+                    f32x4 v0[kSt], v1[kSt];
+                    auto rd = [&](f32x4 (&v)[kSt], int c0) {
+#pragma unroll
+                        for (int u = 0; u < kSt; ++u) v[u] = lds4[min((c0 + u) * 64 + lane, N)];  // N = the zero slot (reads past the share are dropped)
+                    };
+                    auto wr = [&](const f32x4 (&v)[kSt], int c0) {
+#pragma unroll
+                        for (int u = 0; u < kSt; ++u) {
+                            const int idx = (c0 + u) * 64 + lane;
+                            if (c0 + u < cHi && idx < N) {
+                                if (store_mode == 2)
+                                    __builtin_nontemporal_store(v[u], out + idx);
+                                else
+                                    out[idx] = v[u];
+                            }
+                        }
+                    };
+                    rd(v0, cLo);
+                    for (int c0 = cLo; c0 < cHi; c0 += 2 * kSt) {
+                        rd(v1, c0 + kSt);
+                        wr(v0, c0);
+                        rd(v0, c0 + 2 * kSt);
+                        wr(v1, c0 + kSt);
+                    }
+                }
+            } else {
+                // The wave's entry stream, block by block (block r = the 64 rows of set r).  One 16-byte word per lane = the columns
+                // of TWO group-rows (8 neighbours, 16 bits each): a CU's vector-memory pipe takes ~46 cycles per wave instruction
+                // here whatever its width (measured: hop time follows the instruction count -- 157 tap stores + the entry loads --
+                // not the bytes), so the entry stream uses the fewest, widest loads.  Two words are in flight in two register sets
+                // (A, B) that alternate per word, also across block boundaries: a block starts on A or on B (`par`, wave-uniform)
+                // and exists in both variants; each block is its own loop and assigns its set's accumulators once, outside any
+                // loop.  Blocks are padded to an even number of group-rows in storage only: the odd half is skipped, not gathered.
+                // (Measured alternatives: sums committed through a switch inside one stream loop -- the register allocator shuffles
+                // all accumulator registers on every iteration; a static goto state machine over the blocks -- 440 bytes of scratch
+                // per lane; register banks holding a whole block, prefetched one block ahead with exact vmcnt waits -- 2-4 narrow
+                // loads per block, slower for the reason above.)
+                __builtin_amdgcn_s_waitcnt(kWaitVm0);  // nothing of this wave is pending here (tells the waitcnt pass so)
+                int u = gbeg;   // word index in the stream
                 int par = 0;
-                colw cA = col4[(int64_t)g * 64], cB = col4[(int64_t)(g + 1) * 64];
-                f32x4 vA, vB;
+                u32x4 cA = col4[(int64_t)u * 64], cB = col4[(int64_t)(u + 1) * 64];
+                f32x4 vA[UNIFORM ? 1 : 2], vB[UNIFORM ? 1 : 2];
                 if (!UNIFORM) {
-                    vA = val4[(int64_t)g * 64];
-                    vB = val4[(int64_t)(g + 1) * 64];
+                    vA[0] = val4[(int64_t)(2 * u) * 64], vA[1] = val4[(int64_t)(2 * u + 1) * 64];
+                    vB[0] = val4[(int64_t)(2 * u + 2) * 64], vB[1] = val4[(int64_t)(2 * u + 3) * 64];
                 }
                 f32x4 a0, a1;
-                auto step = [&](colw& cc, f32x4& vv) {
-                    unsigned o0, o1, o2, o3;
-                    if constexpr (UNIFORM) {
-                        o0 = cc.x, o1 = cc.y, o2 = cc.z, o3 = cc.w;
-                    } else {
-                        o0 = (cc.x & 0xffffu) << 4, o1 = (cc.x >> 16) << 4, o2 = (cc.y & 0xffffu) << 4, o3 = (cc.y >> 16) << 4;
-                    }
+                auto gather4 = [&](unsigned lo, unsigned hi, const f32x4& w) {
+                    const unsigned o0 = (lo & 0xffffu) << 4, o1 = (lo >> 16) << 4, o2 = (hi & 0xffffu) << 4, o3 = (hi >> 16) << 4;
                     const f32x4 x0 = *reinterpret_cast<lds_f32x4*>(o0);
                     const f32x4 x1 = *reinterpret_cast<lds_f32x4*>(o1);
                     const f32x4 x2 = *reinterpret_cast<lds_f32x4*>(o2);
                     const f32x4 x3 = *reinterpret_cast<lds_f32x4*>(o3);
-                    const f32x4 w = vv;
-                    cc = col4[(int64_t)(g + 2) * 64];  // refill this register set (the stream ends with two sentinel group-rows)
-                    if (!UNIFORM) vv = val4[(int64_t)(g + 2) * 64];
                     if (UNIFORM) {
                         a0 += x0;
                         a1 += x1;
@@ -114,23 +181,33 @@ __global__ __launch_bounds__(1024) void spmm_chain_kernel(const int32_t* __restr
                         a0 += w.z * x2;
                         a1 += w.w * x3;
                     }
-                    ++g;
                 };
-                auto block = [&](int ge) -> f32x4 {  // group-rows [g, ge) of the stream, ge > g
+                // one word: its first group-row always exists, its second unless the block has an odd count and this is its last word
+                auto step = [&](u32x4& cc, f32x4 (&vv)[UNIFORM ? 1 : 2], bool both) {
+                    const u32x4 c = cc;
+                    f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+                    if (!UNIFORM) w0 = vv[0], w1 = vv[1];
+                    gather4(c.x, c.y, w0);
+                    cc = col4[(int64_t)(u + 2) * 64];  // refill this register set (the stream ends with two sentinel words)
+                    if (!UNIFORM) vv[0] = val4[(int64_t)(2 * u + 4) * 64], vv[1] = val4[(int64_t)(2 * u + 5) * 64];
+                    if (both) gather4(c.z, c.w, w1);
+                    ++u;
+                };
+                auto block = [&](int ue, int odd) -> f32x4 {  // words [u, ue) of the stream, ue > u; odd: the last word is half empty
                     a0 = a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (par == 0) {
                         for (;;) {
-                            step(cA, vA);
-                            if (g == ge) { par = 1; break; }
-                            step(cB, vB);
-                            if (g == ge) { par = 0; break; }
+                            step(cA, vA, !(odd && u + 1 == ue));
+                            if (u == ue) { par = 1; break; }
+                            step(cB, vB, !(odd && u + 1 == ue));
+                            if (u == ue) { par = 0; break; }
                         }
                     } else {
                         for (;;) {
-                            step(cB, vB);
-                            if (g == ge) { par = 0; break; }
-                            step(cA, vA);
-                            if (g == ge) { par = 1; break; }
+                            step(cB, vB, !(odd && u + 1 == ue));
+                            if (u == ue) { par = 0; break; }
+                            step(cA, vA, !(odd && u + 1 == ue));
+                            if (u == ue) { par = 1; break; }
                         }
                     }
                     return a0 + a1;
@@ -138,36 +215,48 @@ __global__ __launch_bounds__(1024) void spmm_chain_kernel(const int32_t* __restr
 #pragma unroll
                 for (int r = 0; r < kChainSets; ++r) {
                     acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (r < R) acc[r] = block(__builtin_amdgcn_readlane(gv, r + 1));
+                    if (r < R) acc[r] = block(__builtin_amdgcn_readlane(gv, r + 1), __builtin_amdgcn_readlane(gv, 16 + r));
                 }
             }
-            __syncthreads();  // every wave has finished gathering from the panel
+            GF_STAMP(1);
+            lds_barrier();  // every gatherer has finished reading the panel, the storers have read tap h out of it
+            GF_STAMP(2);
+            if (gatherer) {
 #pragma unroll
-            for (int r = 0; r < kChainSets; ++r)
-                if (ro[r] != kNoRow) {
-                    f32x4 v = acc[r];
-                    if (UNIFORM) v *= uval;
-                    *reinterpret_cast<lds_f32x4*>(ro[r]) = v;
+                for (int r = 0; r < kChainSets; ++r) {
+                    const unsigned row = (r & 1) ? ro2[r / 2] >> 16 : ro2[r / 2] & 0xffffu;
+                    if (row != 0xffffu) {
+                        f32x4 v = acc[r];
+                        if (UNIFORM) v *= uval;
+                        *reinterpret_cast<lds_f32x4*>(row << 4) = v;
+                    }
                 }
-            __syncthreads();  // the panel now holds tap h + 1
-            // store tap h + 1 from the rewritten panel (full lines, natural order).  After the chain's last hop the same sweep
-            // requests the next panel: each 64-row chunk is overwritten by the wave that has just read it back (no barrier).
-            const bool next = (h + 1 == nHops) && pn < nPanels;
-            f32x4* out = reinterpret_cast<f32x4*>(Xout + (int64_t)h * tapStride) + (int64_t)p * pstride4;
+            }
+            GF_STAMP(3);
+            lds_barrier();  // the panel now holds tap h + 1
+            GF_STAMP(4);
+        }
+        // last tap: every wave stores its chunks and, right behind each, requests the same chunk of the next panel
+        {
+            f32x4* out = outp + (int64_t)(nHops - 1) * (tapStride / 4);
             const f32x4* nsrc = reinterpret_cast<const f32x4*>(Xin) + (int64_t)pn * pstride4;
-#pragma unroll 2
-            for (int j = 0; j < nj; ++j) {
-                const int idx = tid + j * T;
-                if (idx < N) {
-                    const f32x4 v = lds4[idx];
-                    if (store_mode == 2)
-                        __builtin_nontemporal_store(v, out + idx);
-                    else
-                        out[idx] = v;
-                }
-                if (next) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk is in registers before the DMA may overwrite it
-                    dma_chunk(nsrc, j);
+            const bool next = pn < nPanels;
+            for (int j0 = 0; wave + j0 * nW < nChunks; j0 += 4) {  // 4 of this wave's chunks per round (all reads, then store + DMA each)
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = lds4[min((wave + (j0 + u) * nW) * 64 + lane, N)];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunks are in registers before the DMA may overwrite them
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = wave + (j0 + u) * nW;
+                    const int idx = c * 64 + lane;
+                    if (c < nChunks && idx < N) {
+                        if (store_mode == 2)
+                            __builtin_nontemporal_store(v[u], out + idx);
+                        else
+                            out[idx] = v[u];
+                    }
+                    if (next && c < nChunks) dma_chunk(nsrc, c);
                 }
             }
         }
@@ -191,17 +280,29 @@ int chain_num_cus() {
 
 bool gf_chain_available(const gf_plan* plan, int op) { return plan->mat[op].cn_waves > 0; }
 
+#ifdef GF_CHAIN_TRACE
+extern "C" int gf_chain_trace_set(unsigned long long* buf) {
+    GF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace), &buf, sizeof(buf)));
+    return GF_OK;
+}
+#endif
+
 // nHops successive hops of every panel: tap h + 1 = op(S) tap h, tap 0 = Xin, tap h + 1 at Xout + h * tapStride.
 int gf_spmm_chain_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, int nHops, int64_t tapStride,
                          hipStream_t st) {
     const gf_csr_dev& m = plan->mat[op];
     const int N = plan->n;
     GF_REQUIRE_ARG(m.cn_waves > 0, "gf_khop_panel: the plan has no chain image (N = %d > %d?)", N, kPanelMaxNodes);
+    GF_REQUIRE_ARG(tapStride % 4 == 0, "gf_khop_panel: tap stride %lld is not a multiple of 4 floats", (long long)tapStride);
     const bool uniform = m.pn_uniform && g_tune.panel_uniform;
     const size_t lds = (size_t)(N + 1) * 16;
-    const int thr = m.cn_waves * 64;
+    // gatherers + storers: one wave moves ~20 GB/s of stores whatever the rest of the chip does (tools/hbm_ceiling.hip), two cover the
+    // 160 KB per hop of a full-LDS panel within the gather time
+    const int storers = m.cn_waves >= 14 ? 2 : 1;
+    const int waves = m.cn_waves + storers;
+    const int thr = waves * 64;
     int wgPerCU = (int)((160 * 1024) / (lds < 1024 ? 1024 : lds));
-    const int waveCap = 32 / m.cn_waves;
+    const int waveCap = 32 / waves;
     if (wgPerCU > waveCap) wgPerCU = waveCap;
     if (wgPerCU > 8) wgPerCU = 8;
     if (wgPerCU < 1) wgPerCU = 1;
@@ -210,8 +311,8 @@ int gf_spmm_chain_launch(const gf_plan* plan, int op, const float* Xin, float* X
     auto kern = uniform ? spmm_chain_kernel<1> : spmm_chain_kernel<0>;
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.cn_gtab, m.cn_rowoff,
-                       uniform ? (const void*)m.cn_col4 : (const void*)m.cn_col2, m.cn_val4, m.pn_uval, Xin, Xout, N, nPanels, m.cn_sets,
-                       nHops, tapStride, g_tune.spmm_store);
+                       (const void*)m.cn_col8, m.cn_val4, m.pn_uval, Xin, Xout, N, nPanels, m.cn_sets,
+                       nHops, tapStride, g_tune.spmm_store, storers);
     GF_LAUNCH_CHECK("spmm_chain_kernel");
     return GF_OK;
 }

@@ -87,22 +87,25 @@ struct gf_csr_dev {
     double pn_conflict = 0.0;       // expected LDS cycles per ds_read_b128 step after the bank-aware ordering (diagnostic)
     // Chain image (gf_chain.hip): the K-1 hops of one panel run inside LDS, outputs are held in registers until every wave has
     // finished gathering and are then written over the panel.  Because outputs pass through registers, rows need not be
-    // computed in natural order: rows are sorted by degree, chunk c (64 consecutive sorted rows) goes to wave c % cn_waves as its
-    // set c / cn_waves (<= kChainSets sets per wave), so the 64 rows a wave walks together have (almost) equal length -- the ELL
-    // fill that lane = row lockstep wastes in the natural-order octets above (0.61 on the SBM of config 2) goes to ~0.9.
-    // A wave's blocks are stored back to back: group-row g of the stream lives at cn_col*[g * 64 + lane] (same entry words as the
-    // panel image); cn_gtab[w * 16 + 0] = first group-row of wave w, [w * 16 + 1 + r] = end of its block r.
-    int32_t cn_waves = 0;           // waves per workgroup (1, 2, 4, 8, 16); 0 = no chain image
+    // computed in natural order: rows are sorted by degree, the chunks (64 consecutive sorted rows) are dealt to the cn_waves
+    // gather waves in boustrophedon order (set r of wave w = chunk r * W + w for even r, r * W + W-1-w for odd r: every wave gets
+    // the same mix of long and short rows), <= kChainSets sets per wave, so the 64 rows a wave walks together have (almost) equal
+    // length -- the ELL fill that lane = row lockstep wastes in the natural-order octets above (0.61 on the SBM of config 2)
+    // goes to ~0.9.
+    // A wave's blocks are stored back to back as 16-byte words of 8 x 16-bit columns = two group-rows (blocks padded to an even number
+    // of group-rows): word u of the stream lives at cn_col8[u * 64 + lane], the values of its group-rows at cn_val4[(2u + {0,1}) * 64
+    // + lane];  cn_gtab[w * 32 + 0] = first word of wave w, [w * 32 + 1 + r] = end of its block r, [w * 32 + 16 + r] = 1 when block r
+    // has an odd number of group-rows (the second half of its last word is padding and is not gathered).
+    int32_t cn_waves = 0;           // gather waves per workgroup (1, 2, 4, 8, 14; one or two more waves store); 0 = no chain image
     int32_t cn_sets = 0;            // row sets per wave
     uint32_t* cn_rowoff = nullptr;  // [cn_sets][cn_waves * 64]  LDS byte offset (row * 16) of the row of (set, thread); 0xffffffff = none
-    int32_t* cn_gtab = nullptr;     // [cn_waves * 16]
-    uint4* cn_col4 = nullptr;       // value-free stream (uniform plans)
-    uint2* cn_col2 = nullptr;       // weighted stream
-    float4* cn_val4 = nullptr;
+    int32_t* cn_gtab = nullptr;     // [cn_waves * 32]
+    uint4* cn_col8 = nullptr;       // 8 x 16-bit columns per lane and word
+    float4* cn_val4 = nullptr;      // 4 values (read when the stored values are not all equal)
     double cn_fill = 1.0;
     double cn_conflict = 0.0;
 };
-constexpr int kChainSets = 10;      // 16 waves x 10 sets x 64 rows = 10240 >= kPanelMaxNodes
+constexpr int kChainSets = 12;      // 14 gather waves x 12 sets x 64 rows = 10752 >= kPanelMaxNodes (waves 15 and 16 store)
 constexpr int32_t kPanelMaxNodes = 10239;   // 16 bytes per node + one zero slot in 160 KiB of LDS
 constexpr int32_t kPanelMaxDeg = 65535;
 

@@ -383,8 +383,10 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
 // ---- chain image (gf_chain.hip; layout described at gf_csr_dev::cn_*) --------------------------------------------------
 int upload_chain(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     const int32_t nChunks = (n + 63) / 64;
-    int W = 1;
-    while (W < 16 && (nChunks + W - 1) / W > kChainSets) W <<= 1;
+    static const int kGatherWaves[5] = {1, 2, 4, 8, 14};  // + the storer wave(s): workgroups of 128 ... 1024 threads
+    int W = 14;
+    for (int i = 4; i >= 0; --i)
+        if ((nChunks + kGatherWaves[i] - 1) / kGatherWaves[i] <= kChainSets) W = kGatherWaves[i];
     const int R = (nChunks + W - 1) / W;
     if (R > kChainSets) return GF_OK;  // cannot happen for n <= kPanelMaxNodes
     std::vector<int32_t> order(n);
@@ -394,14 +396,13 @@ int upload_chain(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     });
     const int T = W * 64;
     std::vector<uint32_t> rowoff((size_t)R * T, 0xffffffffu);
-    std::vector<int32_t> gtab((size_t)W * 16, 0);
+    std::vector<int32_t> gtab((size_t)W * 32, 0);
     EllStreams ell;
     const bool reorder = g_tune.panel_order != 0;
     for (int w = 0; w < W; ++w) {
-        gtab[(size_t)w * 16] = ell.group_rows();
+        gtab[(size_t)w * 32] = ell.group_rows() / 2;
         for (int r = 0; r < R; ++r) {
-            const int32_t c = r * W + w;  // chunk: sorted rows 64c .. 64c+63; the waves take the chunks round-robin, so each wave
-                                          // gets the same mix of long and short rows
+            const int32_t c = r * W + ((r & 1) ? W - 1 - w : w);  // chunk: sorted rows 64c .. 64c+63, dealt boustrophedon
             int32_t rows[64];
             for (int l = 0; l < 64; ++l) {
                 const int64_t pos = (int64_t)c * 64 + l;
@@ -409,19 +410,26 @@ int upload_chain(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
                 if (rows[l] < n) rowoff[(size_t)r * T + w * 64 + l] = (uint32_t)rows[l] * 16u;
             }
             // every block has at least one group-row: the kernel commits a set when its stream position reaches the block's end
-            emit_ell_block(n, a, rows, reorder, false, 1, ell);
-            gtab[(size_t)w * 16 + 1 + r] = ell.group_rows();
+            const int32_t gr = emit_ell_block(n, a, rows, reorder, false, 1, ell);
+            if (gr & 1) ell.sentinel_rows(n, 1);  // storage padding to a whole word; flagged in the table, never gathered
+            gtab[(size_t)w * 32 + 1 + r] = ell.group_rows() / 2;
+            gtab[(size_t)w * 32 + 16 + r] = gr & 1;
         }
     }
-    ell.sentinel_rows(n, 2);  // the two-deep prefetch of the last wave runs past its stream
+    ell.sentinel_rows(n, 4);  // the two-word prefetch of the last wave runs past its stream
+    std::vector<uint4> col8(ell.col2.size() / 2);  // [word][lane] = {group-row 2u, group-row 2u + 1}
+    for (size_t u = 0; u < col8.size() / 64; ++u)
+        for (int l = 0; l < 64; ++l) {
+            const uint2 lo = ell.col2[(2 * u) * 64 + l], hi = ell.col2[(2 * u + 1) * 64 + l];
+            col8[u * 64 + l] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
     d.cn_fill = ell.slots ? (double)a.col.size() / (double)ell.slots : 1.0;
     d.cn_conflict = ell.steps ? ell.cycles / (double)ell.steps : 0.0;
     int rc;
     if ((rc = upload(rowoff, &d.cn_rowoff, bytes))) return rc;
     if ((rc = upload(gtab, &d.cn_gtab, bytes))) return rc;
-    if (d.pn_uniform && (rc = upload(ell.col4, &d.cn_col4, bytes))) return rc;
-    if ((rc = upload(ell.col2, &d.cn_col2, bytes))) return rc;
-    if ((rc = upload(ell.val4, &d.cn_val4, bytes))) return rc;
+    if ((rc = upload(col8, &d.cn_col8, bytes))) return rc;
+    if ((rc = upload(ell.val4, &d.cn_val4, bytes))) return rc;   // kept for uniform plans too (knob panel_uniform = 0)
     d.cn_waves = W;
     d.cn_sets = R;
     return GF_OK;
@@ -442,8 +450,7 @@ void free_csr(gf_csr_dev& d) {
     if (d.pn_val4) (void)hipFree(d.pn_val4);
     if (d.cn_rowoff) (void)hipFree(d.cn_rowoff);
     if (d.cn_gtab) (void)hipFree(d.cn_gtab);
-    if (d.cn_col4) (void)hipFree(d.cn_col4);
-    if (d.cn_col2) (void)hipFree(d.cn_col2);
+    if (d.cn_col8) (void)hipFree(d.cn_col8);
     if (d.cn_val4) (void)hipFree(d.cn_val4);
     d = gf_csr_dev{};
 }
