@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- edges*taps/sec of one GraphFilter forward+backward (BASELINE.json metric) on N MI355X GPUs.
+"""bench.py -- edges*taps/sec of the graph-filter hot path (BASELINE.json metric) on N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                       # N = 1, the north-star workload (cfg4), steps / warmup chosen so the timed region is >= 0.5 s
+    python bench.py --workload cfg2 --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (config.workload = "cfg2"): BASELINE.json configs[1] -- synthetic SBM N=10k, nnz~100k, batch 256 per GPU,
-K=5, F 32->32, fp32.  A step = one pass of the hot path over one batch: GraphFilter forward + backward (dx, dh, db)
-through the C ABI; for N>1 plus the ONE bucketed RCCL all-reduce of the tap/bias gradients (batch-DP, weak scaling:
-per-GPU batch fixed).  Inputs are resident in HBM before the timed region.  value = B_global * nnz * K / t_step.
+Workloads = BASELINE.json configs (config.workload names the one that ran):
+  cfg4 (default)  ER N=100k nnz~1M, 128 samples per GPU (configs[3]: batch 1024 over 8 GPUs), GraphFilter K=5, F 32->32.  This is the
+                  size BASELINE.json's roofline target is stated on, and it fits one GPU.
+  cfg2            SBM N=10k nnz~100k, batch 256, GraphFilter K=5, 32->32 (configs[1])
+  cfg1            sourceLocGNN SelectionGNN: SBM N=100, F=[1,32,32], K=[5,5], MaxPoolLocal, MLP [5] (configs[0], examples/sourceLocGNN.py)
+  cfg3            movieGNN SelectionGNN on a MovieLens-100k-sized graph: N=1682, kNN-10 weights, F=[1,64,32], K=[5,5], NoPool, MLP [1]
+  cfg5            EdgeVariantGF (per-edge taps) SBM N=50k nnz~500k, K=3, 32->32, batch 16 (configs[4])
+A step = one pass of the hot path over one batch resident in HBM: forward + backward (dx, dh, db) through the C ABI; for N > 1 plus the
+ONE bucketed RCCL all-reduce of the parameter gradients (batch-axis data parallelism, weak scaling: per-GPU batch fixed).
+value = B_global * sum_layers(nnz * K) / t_step, t_step from the barrier + synchronize bracket the harness prescribes; the median of
+per-step HIP-event times is reported next to it (ms_per_step_median).
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (one hop of the K-hop SpMM, in the pipeline the layer runs): achieved = algorithmic
-                  bytes per launch (2*B*N*G*4 + nnz*8 + (N+1)*4) / average launch time measured here with
-                  HIP events on the launch stream (gf_time_spmm_hop[_panel]); peak = 8 TB/s HBM3E; traffic = PMC HBM bytes
-                  per launch from profiles/*_pmc.json for this workload and kernel (rocprofv3 --pmc in its own pass), else null.
-  cpu_baseline -- the reference's CPU path (oracle restatement of graphML.py:152-175: dense S, torch.matmul loop, cat,
-                  permute) timed on this box's host cores on a bounded batch sample; rank 0, N=1 only.
+  roofline     -- the dominant kernel: achieved = algorithmic bytes per launch / its average launch time, timed here with
+                  HIP events on the launch stream; peak = 8 TB/s HBM3E; traffic = PMC HBM bytes per launch from profiles/*_pmc.json
+                  (rocprofv3 --pmc in passes of their own, tools/pmc_collect.sh) for this workload and kernel, else null.
+  cpu_baseline -- the reference's CPU path (oracle/: restatement of graphML.py:152-175 / :457-488 in torch / numpy) timed on this box's
+                  host cores on a bounded sample of the same workload; rank 0, N = 1 only.
 """
 import argparse
 import ctypes
@@ -34,32 +41,98 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-WORKLOADS = {
-    # name: graph model, N, avg degree, per-GPU batch, G, F, K
-    "cfg2": dict(model="sbm", N=10_000, deg=10.0, B=256, G=32, F=32, K=5,
-                 desc="SBM N=10k nnz~100k, batch 256/GPU, K=5, F 32->32 (BASELINE configs[1])"),
-    "cfg4": dict(model="er", N=100_000, deg=10.0, B=128, G=32, F=32, K=5,
-                 desc="ER N=100k nnz~1M, batch 128/GPU (1024 over 8 GPUs), K=5, F=32 (BASELINE configs[3])"),
-    "tiny": dict(model="sbm", N=1000, deg=10.0, B=32, G=32, F=32, K=5, desc="plumbing check"),
-}
 HBM_PEAK_GBS = 8000.0
+WORKLOADS = {
+    "cfg4": dict(kind="filter", graph="er", N=100_000, deg=10.0, B=128, G=32, F=32, K=5, steps=25, warmup=5, cpu_sample=8,
+                 desc="ER N=100k nnz~1M, batch 128/GPU (1024 over 8 GPUs), K=5, F 32->32 (BASELINE configs[3], the north-star size)"),
+    "cfg2": dict(kind="filter", graph="sbm", N=10_000, deg=10.0, B=256, G=32, F=32, K=5, steps=250, warmup=20, cpu_sample=64,
+                 desc="SBM N=10k nnz~100k, batch 256/GPU, K=5, F 32->32 (BASELINE configs[1])"),
+    "cfg1": dict(kind="selgnn", graph="sbm", N=100, deg=30.0, B=100, dimF=[1, 32, 32], K=[5, 5], sel=[10, 10], pool="MaxPoolLocal",
+                 alpha=[6, 8], mlp=[5], steps=1500, warmup=50, cpu_sample=100,
+                 desc="sourceLocGNN SelectionGNN: SBM N=100, F=[1,32,32], K=[5,5], MaxPoolLocal [10,10] alpha [6,8], MLP [5], batch 100/GPU (BASELINE configs[0])"),
+    "cfg3": dict(kind="selgnn", graph="knn", N=1682, deg=10.0, B=256, dimF=[1, 64, 32], K=[5, 5], sel=[1682, 1682], pool="NoPool",
+                 alpha=[1, 1], mlp=[1], steps=400, warmup=20, cpu_sample=64,
+                 desc="movieGNN SelectionGNN on a MovieLens-100k-sized graph: N=1682 kNN-10 weights, F=[1,64,32], K=[5,5], NoPool, MLP [1], batch 256/GPU (BASELINE configs[2])"),
+    "cfg5": dict(kind="evgf", graph="sbm", N=50_000, deg=10.0, B=16, G=32, F=32, K=3, steps=15, warmup=3, cpu_sample=2,
+                 desc="EdgeVariantGF per-edge taps: SBM N=50k nnz~500k, K=3, F 32->32, batch 16/GPU (BASELINE configs[4])"),
+    "tiny": dict(kind="filter", graph="sbm", N=1000, deg=10.0, B=32, G=32, F=32, K=5, steps=50, warmup=5, cpu_sample=8, desc="plumbing check"),
+}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def make_graph(wl):
+    from alegnn_amd import graphgen
+    if wl["graph"] == "knn":
+        return graphgen.knn_weighted(wl["N"], k=int(wl["deg"]), seed=0)
+    return (graphgen.sbm if wl["graph"] == "sbm" else graphgen.er)(wl["N"], avg_degree=wl["deg"], seed=0)
+
+
+class Workload:
+    """module + inputs + the step; units = edges*taps of one sample (sum over the filter layers of nnz * K)."""
+
+    def __init__(self, name, wl, dev, rank):
+        from alegnn_amd.modules.architectures import SelectionGNN
+        from alegnn_amd.utils import graphML as gml
+        self.name, self.wl, self.dev = name, wl, dev
+        self.A = make_graph(wl)
+        self.nnz = int(self.A.nnz)
+        N, B = wl["N"], wl["B"]
+        torch.manual_seed(0)
+        gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+        if wl["kind"] == "filter":
+            self.module = gml.GraphFilter(wl["G"], wl["F"], wl["K"], 1, True)
+            self.module.addGSO(self.A)
+            self.module.to(dev)
+            self.x = torch.randn(B, wl["G"], N, device=dev, generator=gen).requires_grad_(True)
+            self.dy = torch.randn(B, wl["F"], N, device=dev, generator=gen)
+            self.units = self.nnz * wl["K"]
+        elif wl["kind"] == "evgf":
+            self.module = gml.EdgeVariantGF(wl["G"], wl["F"], wl["K"], N, N, 1, True, sparse=True)
+            self.module.addGSO(self.A)
+            self.module.to(dev)
+            self.x = torch.randn(B, wl["G"], N, device=dev, generator=gen).requires_grad_(True)
+            self.dy = torch.randn(B, wl["F"], N, device=dev, generator=gen)
+            self.units = self.nnz * wl["K"]
+        else:
+            self.module = SelectionGNN(wl["dimF"], wl["K"], True, torch.nn.ReLU, wl["sel"], getattr(gml, wl["pool"]), wl["alpha"],
+                                       wl["mlp"], self.A).to(dev)
+            self.x = torch.randn(B, wl["dimF"][0], N, device=dev, generator=gen).requires_grad_(True)
+            self.dy = None
+            self.units = self.nnz * sum(wl["K"])
+
+    def step_fwd_bwd(self):
+        self.x.grad = None
+        if self.dy is not None:
+            self.module(self.x).backward(self.dy)
+        else:
+            self.module(self.x).square().sum().backward()          # the examples' losses need labels; any scalar loss drives the same path
+
+
+def timed_hip_events(fn, n):
+    """n calls, each between two HIP events on the launch stream (= torch's current stream: every C-ABI call is handed
+    torch.cuda.current_stream()); returns the per-call milliseconds."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    return [e0.elapsed_time(e1) for e0, e1 in ev]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per workload, >= 0.5 s of timed region)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="batch entries of the workload timed on the CPU")
-    ap.add_argument("--detail", action="store_true", help="per-kernel timings to stderr")
-    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2], help="0 auto | 1 node-major (L2 gathers) | 2 column panels (LDS gathers)")
-    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="gf_tune knob for experiments (repeatable)")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="batch entries of the workload timed on the CPU")
+    ap.add_argument("--detail", action="store_true", help="per-building-block timings to stderr (filter workloads)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="gf_tune knob (needs GFHIP_EXPERIMENTS=1; repeatable)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,33 +149,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from alegnn_amd import _lib, graphgen, parallel
-    from alegnn_amd.utils import graphML as gml
-
-    if args.pipeline:
-        _lib.check(_lib.lib().gf_tune(b"pipeline", args.pipeline), "gf_tune pipeline")
+    from alegnn_amd import _lib, parallel
     for kv in args.tune:
         key, val = kv.split("=")
         _lib.check(_lib.lib().gf_tune(key.encode(), int(val)), "gf_tune " + key)
     wl = WORKLOADS[args.workload]
-    N, B, G, F, K = wl["N"], wl["B"], wl["G"], wl["F"], wl["K"]
-    A = (graphgen.sbm if wl["model"] == "sbm" else graphgen.er)(N, avg_degree=wl["deg"], seed=0)
-    nnz = int(A.nnz)
-    torch.manual_seed(0)
-    layer = gml.GraphFilter(G, F, K, 1, True)
-    layer.addGSO(A)
-    layer.to(dev)
-    parallel.broadcast_parameters(layer)
-    bucket = parallel.GradBucket(layer.parameters())
-    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.randn(B, G, N, device=dev, generator=gen).requires_grad_(True)     # synthetic signals, resident in HBM
-    dy = torch.randn(B, F, N, device=dev, generator=gen)
+    steps = args.steps if args.steps is not None else wl["steps"]
+    warmup = args.warmup if args.warmup is not None else wl["warmup"]
+    w = Workload(args.workload, wl, dev, rank)
+    parallel.broadcast_parameters(w.module)
+    bucket = parallel.GradBucket(w.module.parameters())
 
     def step():
         bucket.zero_()
-        x.grad = None
-        y = layer(x)
-        y.backward(dy)
+        w.step_fwd_bwd()
         bucket.allreduce_mean()
 
     def sync_all():
@@ -110,11 +170,11 @@ def main():
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -122,59 +182,31 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # the slowest rank defines the step time
         elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = (B * world) * nnz * K / (elapsed / args.steps)
+    ms_per_step = 1e3 * elapsed / steps
+    B = wl["B"]
+    value = (B * world) * w.units / (elapsed / steps)
+    per_step = timed_hip_events(step, max(20, min(steps, 50)))    # median of >= 20, HIP events
+    ms_median = float(np.median(per_step))
 
-    # ---- roofline of the dominant kernel: one SpMM hop of the pipeline the layer actually runs, HIP events on the
-    #      launch stream (gf_time_spmm_hop*: hipEventRecord on that stream around `iters` back-to-back launches) -----------
     L = _lib.lib()
-    plans = layer._gso.plans(dev)
-    pipe = L.gf_lsigf_pipeline(plans, 1, G, F, K)
-    ms = np.zeros(1, dtype=np.float32)
-    stream = torch.cuda.current_stream().cuda_stream
-    msp = ms.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-    if pipe == 2:                                            # column panels, gathers from LDS
-        X0 = torch.randn(B * G // 4, N, 4, device=dev)
-        X1 = torch.empty_like(X0)
-        _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B * G // 4, 20, stream, msp))
-        kname = "spmm_panel_kernel (one hop, op=S^T, column panels through LDS)"
-    else:                                                    # node-major, gathers through L2
-        X0 = torch.randn(B, N, G, device=dev)
-        X1 = torch.empty_like(X0)
-        _lib.check(L.gf_time_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, G, 20, stream, msp))
-        kname = "spmm_sell_kernel (one hop, op=S^T, node-major through L2)"
-    hop_ms = float(ms[0])
-    hop_bytes = 2 * B * N * G * 4 + nnz * 8 + (N + 1) * 4    # read X once, write X once, read the CSR once
-    achieved = hop_bytes / (hop_ms * 1e-3) / 1e9
-    traffic = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
-        try:
-            pm = json.load(open(f))
-            if pm.get("workload") == args.workload and pm.get("kernel", "").split("<")[0] == kname.split(" ")[0]:
-                traffic = pm.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    algorithmic_bytes=hop_bytes, launch_ms=round(hop_ms, 5), pipeline=int(pipe))
-
+    roofline = ROOFLINES[wl["kind"]](L, w, wl)                      # every rank runs it: keeps the ranks in step
     detail = None
-    if args.detail and rank == 0:
-        detail = kernel_breakdown(L, layer, plans, x.detach(), dy, B, N, G, F, K, dev)
+    if args.detail and rank == 0 and wl["kind"] == "filter":
+        detail = kernel_breakdown(L, w, wl)
         log("breakdown_ms", json.dumps(detail))
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(A, layer, x.detach(), nnz, K, min(args.cpu_sample, B))
+        cpu = CPU_BASELINES[wl["kind"]](w, wl, args.cpu_sample or wl["cpu_sample"])
 
     if rank == 0:
-        out = dict(metric="edges*taps/sec (GraphFilter fwd+bwd)", value=value, unit="edges*taps/s", n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=args.workload, description=wl["desc"], graph=wl["model"], N=N, nnz=nnz,
-                               batch_per_gpu=B, global_batch=B * world, G=G, F=F, K=K, E=1,
-                               parallelism=f"batch-dp{world}", grad_bucket_bytes=bucket.nbytes()),
-                   roofline=roofline, cpu_baseline=cpu)
+        cfg = dict(workload=args.workload, description=wl["desc"], graph=wl["graph"], N=wl["N"], nnz=w.nnz, batch_per_gpu=B,
+                   global_batch=B * world, K=wl["K"], E=1, parallelism=f"batch-dp{world}", grad_bucket_bytes=bucket.nbytes(),
+                   rccl_ranks=(dist.get_world_size() if distributed else 0),
+                   devices=[torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())][:world])
+        cfg.update({k: wl[k] for k in ("G", "F", "dimF", "sel", "pool", "alpha", "mlp") if k in wl})
+        out = dict(metric="edges*taps/sec (GraphFilter fwd+bwd)", value=value, unit="edges*taps/s", n_gpus=world, steps=steps,
+                   warmup=warmup, ms_per_step=ms_per_step, ms_per_step_median=ms_median, higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic", config=cfg, roofline=roofline, cpu_baseline=cpu)
         if detail:
             out["breakdown_ms"] = detail
         print(json.dumps(out), flush=True)
@@ -182,12 +214,184 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_breakdown(L, layer, plans, x, dy, B, N, G, F, K, dev):
-    """Per-building-block time (torch events on the launch stream = torch's current stream), median of 10."""
+# ------------------------------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernel of each workload kind
+# ------------------------------------------------------------------------------------------------------------------------------
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch from the committed PMC summaries (profiles/*_pmc.json, newest round last)."""
+    traffic = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            pm = json.load(open(f))
+        except Exception:
+            continue
+        if pm.get("workload") == workload and pm.get("kernel") == kernel:
+            traffic = pm.get("hbm_bytes_per_launch")
+    return traffic
+
+
+def hop_bytes(B, N, W, nnz):
+    return 2 * B * N * W * 4 + nnz * 8 + (N + 1) * 4            # SURVEY.md 8d: read X once, write X once, read the CSR once
+
+
+def filter_hop_roofline(L, plans, name, B, N, W, K, nnz, dev):
+    """One K-hop chain of a GraphFilter layer in the pipeline that layer runs, HIP events inside the library (gf_time_*:
+    hipEventRecord on the launch stream around `iters` back-to-back launches)."""
+    ms = ctypes.c_float()
+    st = torch.cuda.current_stream().cuda_stream
+    pipe = L.gf_lsigf_pipeline(plans, 1, W, W, K)
     from alegnn_amd import _lib
-    T = K
-    Z = torch.empty((T, B, N, G), device=dev)
-    P = torch.empty((T, B, N, F), device=dev)
+    if pipe == 2:                                                 # column panels: the K-1 hops of a panel are ONE launch (gf_chain.hip)
+        Z = torch.randn(K, B * W // 4, N, 4, device=dev)
+        _lib.check(L.gf_time_khop_panel(plans, 1, 0, Z.data_ptr(), B, W, K, 20, st, ctypes.byref(ms)))
+        kern, hops = "spmm_chain_kernel", K - 1
+        note = ("K-1 hops of every panel in one launch, panel resident in LDS: HBM sees 1 read + (K-1) writes of the signal per launch, "
+                "the algorithmic count (a read and a write per hop) is what `achieved` divides by")
+    else:                                                         # node-major, gathers through L2
+        X0 = torch.randn(B, N, W, device=dev)
+        X1 = torch.empty_like(X0)
+        _lib.check(L.gf_time_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, W, 20, st, ctypes.byref(ms)))
+        kern, hops = "spmm_sell_kernel", 1
+        note = "one hop per launch, node-major rows gathered through L2 / Infinity Cache"
+    nbytes = hops * hop_bytes(B, N, W, nnz)
+    achieved = nbytes / (ms.value * 1e-3) / 1e9
+    return dict(bound="hbm", kernel=kern, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name, kern), algorithmic_bytes=nbytes,
+                launch_ms=round(ms.value, 5), hops_per_launch=hops, pipeline=int(pipe), note=note)
+
+
+def roofline_filter(L, w, wl):
+    plans = w.module._gso.plans(w.dev)
+    return filter_hop_roofline(L, plans, w.name, wl["B"], wl["N"], wl["G"], wl["K"], w.nnz, w.dev)
+
+
+def roofline_selgnn(L, w, wl):
+    """The hidden GraphFilter layer (F1 -> F2 on the full graph) carries the K-hop traffic: its chain at the width it runs."""
+    layer = w.module.GFL[3]
+    plans = layer._gso.plans(w.dev)
+    W = wl["dimF"][1]
+    r = filter_hop_roofline(L, plans, w.name, wl["B"], layer.N, W, wl["K"][1], int(layer._gso.mats[0].nnz), w.dev)
+    r["layer"] = f"GFL[3]: GraphFilter {W}->{wl['dimF'][2]}, K={wl['K'][1]}, N={layer.N}"
+    return r
+
+
+def roofline_evgf(L, w, wl):
+    """EVGF forward: V0 = diag taps, K-1 edge taps (ev_hop_lds4_kernel, the dominant kernel), the sum over (g, k).  Algorithmic
+    bytes: per tap the edge weights F*G*nnzp*4 and the chain state read and written 2*B*F*G*N*4."""
+    B, G, F, K, N = wl["B"], wl["G"], wl["F"], wl["K"], wl["N"]
+    nnzp = int(w.module._patterns[0].nnzp)
+    with torch.no_grad():
+        xs = w.x.detach()
+        ts = timed_hip_events(lambda: w.module(xs), 12)[2:]
+    ms = float(np.median(ts))
+    state = B * F * G * N * 4
+    tap = F * G * nnzp * 4 + 2 * state
+    fwd = (F * G * N * 4 + B * G * N * 4 + state) + (K - 1) * tap + (K * state + B * F * N * 4)   # diag tap + edge taps + sum
+    achieved = fwd / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="gf_evgf_forward (ev_diag + (K-1) x ev_hop_lds4_kernel + ev_sum)", achieved=round(achieved, 1),
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(w.name, "ev_hop_lds4_kernel"),
+                algorithmic_bytes=fwd, algorithmic_bytes_per_tap=tap, launch_ms=round(ms, 4), nnzp=nnzp,
+                note="whole forward timed with HIP events on the launch stream; per-kernel split: profiles/*cfg5*_kernel_stats.csv")
+
+
+ROOFLINES = {"filter": roofline_filter, "selgnn": roofline_selgnn, "evgf": roofline_evgf}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# CPU baselines: the oracle (port of the reference's CPU path), bounded samples
+# ------------------------------------------------------------------------------------------------------------------------------
+def _csr_t(A):
+    At = A.T.tocsr()
+    return torch.sparse_csr_tensor(torch.from_numpy(At.indptr.astype(np.int64)), torch.from_numpy(At.indices.astype(np.int64)),
+                                   torch.from_numpy(At.data.astype(np.float32)), size=A.shape)
+
+
+def cpu_filter(w, wl, sample):
+    """The reference's own CPU path (dense S + matmul / cat / permute, oracle.graph_filter_step_dense) on `sample` batch entries
+    where dense S fits (N <= 20k), else the sparse-CSR restatement; all host cores."""
+    from oracle import lsigf_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    wt, b = w.module.weight.detach().cpu(), w.module.bias.detach().cpu()
+    sample = min(sample, wl["B"])
+    xs = w.x.detach()[:sample].cpu()
+    N, K = wl["N"], wl["K"]
+    out = dict(cores=cores, kind="port", unit="edges*taps/s")
+    St = _csr_t(w.A)
+    orc.graph_filter_step_sparse_torch(wt, b, St, xs[:2])
+    t0 = time.perf_counter()
+    orc.graph_filter_step_sparse_torch(wt, b, St, xs)
+    dt_sparse = time.perf_counter() - t0
+    out["sparse_port_value"] = sample * w.nnz * K / dt_sparse
+    if N <= 20_000:                                           # dense S is N^2*4 bytes: 400 MB at N=10k, 40 GB at 100k
+        S = torch.from_numpy(w.A.toarray().astype(np.float32))[None]
+        orc.graph_filter_step_dense(wt, b, S, xs[:2])          # warm-up
+        t0 = time.perf_counter()
+        orc.graph_filter_step_dense(wt, b, S, xs)
+        dt = time.perf_counter() - t0
+        out.update(value=sample * w.nnz * K / dt, seconds=round(dt, 3),
+                   sample=f"literal dense restatement of graphML.py:152-175 (fwd+bwd, fp32), {sample} of the batch's {wl['B']} entries")
+    else:
+        out.update(value=out["sparse_port_value"], seconds=round(dt_sparse, 3),
+                   sample=f"sparse-CSR CPU restatement of graphML.py:152-175 (dense S would be {N * N * 4 / 1e9:.0f} GB), fwd+bwd fp32, "
+                          f"{sample} of the batch's {wl['B']} entries")
+    return out
+
+
+def cpu_selgnn(w, wl, sample):
+    """The GraphFilter layers of the architecture in the reference's dense form (the layers that define the metric's units), each at
+    the node count it runs on; pooling / MLP are not part of the units and are left out."""
+    from oracle import lsigf_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    sample = min(sample, wl["B"])
+    S = torch.from_numpy(w.A.toarray().astype(np.float32))[None]
+    nodes = [wl["N"]] + list(wl["sel"])
+    dt = 0.0
+    for l in range(2):
+        layer = w.module.GFL[3 * l]
+        wt, b = layer.weight.detach().cpu(), layer.bias.detach().cpu()
+        x = torch.randn(sample, wl["dimF"][l], nodes[l])
+        orc.graph_filter_step_dense(wt, b, S, x[:2])
+        t0 = time.perf_counter()
+        orc.graph_filter_step_dense(wt, b, S, x)
+        dt += time.perf_counter() - t0
+    return dict(cores=cores, kind="port", unit="edges*taps/s", value=sample * w.units / dt, seconds=round(dt, 3),
+                sample=f"the two GraphFilter layers in the literal dense form of graphML.py:152-175 + :2125-2144 (fwd+bwd, fp32), {sample} samples")
+
+
+def cpu_evgf(w, wl, sample):
+    """scipy restatement of EVGF with per-edge taps (oracle/evgf_oracle.py), forward + analytic backward, one host core."""
+    import scipy.sparse as sp
+    from oracle import evgf_oracle as evo
+    sample = min(sample, wl["B"])
+    m = w.module
+    pat = m._patterns[0]
+    P = sp.csr_matrix((np.ones(pat.nnzp, dtype=np.float32), pat.indices, pat.indptr), shape=(pat.N, pat.N))
+    wd = m.weightEVdiag.detach()[:, 0].cpu().numpy()
+    we = m.weightEVedges[0].detach().cpu().numpy()
+    xs = w.x.detach()[:sample].cpu().numpy()
+    dys = w.dy[:sample].cpu().numpy()
+    t0 = time.perf_counter()
+    evo.evgf_sparse(P, wd, we, xs, None, dtype=np.float32)
+    evo.evgf_sparse_grads(P, wd, we, xs, dys, dtype=np.float32)
+    dt = time.perf_counter() - t0
+    return dict(cores=1, kind="port", unit="edges*taps/s", value=sample * w.units / dt, seconds=round(dt, 3),
+                sample=f"scipy restatement of graphML.py:457-488 with per-edge taps (forward + analytic backward, fp32), {sample} of the batch's {wl['B']} entries")
+
+
+CPU_BASELINES = {"filter": cpu_filter, "selgnn": cpu_selgnn, "evgf": cpu_evgf}
+
+
+def kernel_breakdown(L, w, wl):
+    """Per-building-block time of a GraphFilter layer (torch events on the launch stream = torch's current stream), median of 10."""
+    from alegnn_amd import _lib
+    layer, dev = w.module, w.dev
+    B, N, G, F, K = wl["B"], wl["N"], wl["G"], wl["F"], wl["K"]
+    plans = layer._gso.plans(dev)
+    x, dy = w.x.detach(), w.dy
+    Z = torch.empty((K, B, N, G), device=dev)
+    P = torch.empty((K, B, N, F), device=dev)
     y = torch.empty((B, F, N), device=dev)
     dx = torch.empty((B, G, N), device=dev)
     dh = torch.empty_like(layer.weight)
@@ -195,84 +399,35 @@ def kernel_breakdown(L, layer, plans, x, dy, B, N, G, F, K, dev):
     nb = L.gf_grad_taps_workspace_bytes(B, N, G, F, 1, K)
     ws = torch.empty(nb // 4 + 1, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    w, b = layer.weight.detach(), layer.bias.detach()
+    wt, b = layer.weight.detach(), layer.bias.detach()
     if L.gf_lsigf_pipeline(plans, 1, G, F, K) == 2:
-        def khop(buf, op, width):                            # as separate launches (the layer fuses the K-1 hops of a chain)
-            tap = B * N * width
-            for k in range(1, K):
-                rc = L.gf_spmm_hop_panel(plans[0], op, buf.data_ptr() + 4 * tap * (k - 1), buf.data_ptr() + 4 * tap * k,
-                                         B * width // 4, st)
-                if rc:
-                    return rc
-            return 0
         calls = {
             "pack_x": lambda: L.gf_pack_panels(x.data_ptr(), Z.data_ptr(), B, G, N, N, st),
-            "khop_fwd(K-1 panel hops)": lambda: khop(Z, 0, G),
-            "contract_fwd": lambda: L.gf_contract_panel(Z.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, N, N, G, F, 1, K, 0, st),
+            "khop_fwd(chain: K-1 hops)": lambda: L.gf_khop_panel(plans, 1, 0, Z.data_ptr(), B, G, K, st),
+            "contract_fwd": lambda: L.gf_contract_panel(Z.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), B, N, N, G, F, 1, K, 0, st),
             "pack_dy": lambda: L.gf_pack_panels(dy.data_ptr(), P.data_ptr(), B, F, N, N, st),
-            "grad_taps": lambda: L.gf_grad_taps_panel(Z.data_ptr(), P.data_ptr(), dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, N, G, F, 1, K, st),
-            "khop_bwd(K-1 panel hops)": lambda: khop(P, 1, F),
-            "contract_bwd": lambda: L.gf_contract_panel(P.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, N, N, G, F, 1, K, 1, st),
-            # what the layer actually runs: for G, F <= 32 the backward produces dx and dh in ONE pass over the adjoint stack
-            # (bwd_fused_panel_kernel) instead of grad_taps + contract_bwd above
-            "lsigf_forward(whole)": lambda: L.gf_lsigf_forward(plans, 1, x.data_ptr(), w.data_ptr(), b.data_ptr(), Z.data_ptr(), y.data_ptr(),
-                                                              B, G, F, K, N, st),
-            "lsigf_backward(whole)": lambda: L.gf_lsigf_backward(plans, 1, dy.data_ptr(), Z.data_ptr(), w.data_ptr(), P.data_ptr(), dx.data_ptr(),
-                                                                dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, G, F, K, N, st),
+            "khop_bwd(chain: K-1 hops)": lambda: L.gf_khop_panel(plans, 1, 1, P.data_ptr(), B, F, K, st),
+            "grad_taps (separate)": lambda: L.gf_grad_taps_panel(Z.data_ptr(), P.data_ptr(), dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, N, G, F, 1, K, st),
+            "contract_bwd (separate)": lambda: L.gf_contract_panel(P.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), B, N, N, G, F, 1, K, 1, st),
         }
     else:
-      calls = {
-        "layout_in": lambda: L.gf_layout_bgn_to_bng(x.data_ptr(), Z.data_ptr(), B, G, N, N, st),
-        "khop_fwd(K-1 hops)": lambda: L.gf_khop(plans, 1, 0, Z.data_ptr(), B, G, K, st),
-        "contract_fwd": lambda: L.gf_contract(Z.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, N, N, G, F, 1, K, 0, st),
-        "layout_dy": lambda: L.gf_layout_bgn_to_bng(dy.data_ptr(), P.data_ptr(), B, F, N, N, st),
-        "grad_taps": lambda: L.gf_grad_taps(Z.data_ptr(), P.data_ptr(), dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, N, G, F, 1, K, st),
-        "khop_bwd(K-1 hops)": lambda: L.gf_khop(plans, 1, 1, P.data_ptr(), B, F, K, st),
-        "contract_bwd": lambda: L.gf_contract(P.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, N, N, G, F, 1, K, 1, st),
-      }
+        calls = {
+            "layout_in": lambda: L.gf_layout_bgn_to_bng(x.data_ptr(), Z.data_ptr(), B, G, N, N, st),
+            "khop_fwd(K-1 hops)": lambda: L.gf_khop(plans, 1, 0, Z.data_ptr(), B, G, K, st),
+            "contract_fwd": lambda: L.gf_contract(Z.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), B, N, N, G, F, 1, K, 0, st),
+            "layout_dy": lambda: L.gf_layout_bgn_to_bng(dy.data_ptr(), P.data_ptr(), B, F, N, N, st),
+            "grad_taps": lambda: L.gf_grad_taps(Z.data_ptr(), P.data_ptr(), dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, N, G, F, 1, K, st),
+            "khop_bwd(K-1 hops)": lambda: L.gf_khop(plans, 1, 1, P.data_ptr(), B, F, K, st),
+            "contract_bwd": lambda: L.gf_contract(P.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), B, N, N, G, F, 1, K, 1, st),
+        }
+    calls["lsigf_forward(whole)"] = lambda: L.gf_lsigf_forward(plans, 1, x.data_ptr(), wt.data_ptr(), b.data_ptr(), Z.data_ptr(), y.data_ptr(),
+                                                               B, G, F, K, N, st)
+    calls["lsigf_backward(whole)"] = lambda: L.gf_lsigf_backward(plans, 1, dy.data_ptr(), Z.data_ptr(), wt.data_ptr(), P.data_ptr(), dx.data_ptr(),
+                                                                 dh.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, B, G, F, K, N, st)
     out = {}
     for name, fn in calls.items():
-        ts = []
-        for i in range(12):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(fn(), name)
-            e1.record()
-            e1.synchronize()
-            if i >= 2:
-                ts.append(e0.elapsed_time(e1))
+        ts = timed_hip_events(lambda: _lib.check(fn(), name), 12)[2:]
         out[name] = round(float(np.median(ts)), 4)
-    return out
-
-
-def cpu_baseline(A, layer, x, nnz, K, sample):
-    """The reference's own CPU path (dense S + matmul/cat/permute, oracle.graph_filter_step_dense) on `sample`
-    batch entries of the workload, all host cores; plus the sparse-CSR CPU restatement on the same sample."""
-    from oracle import lsigf_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
-    w, b = layer.weight.detach().cpu(), layer.bias.detach().cpu()
-    xs = x[:sample].cpu()
-    N = A.shape[0]
-    out = dict(cores=cores, kind="port", unit="edges*taps/s")
-    St = torch.sparse_csr_tensor(torch.from_numpy(A.T.tocsr().indptr.astype(np.int64)),
-                                 torch.from_numpy(A.T.tocsr().indices.astype(np.int64)),
-                                 torch.from_numpy(A.T.tocsr().data.astype(np.float32)), size=(N, N))
-    orc.graph_filter_step_sparse_torch(w, b, St, xs[:4])
-    t0 = time.perf_counter()
-    orc.graph_filter_step_sparse_torch(w, b, St, xs)
-    out["sparse_port_value"] = sample * nnz * K / (time.perf_counter() - t0)
-    if N <= 20_000:                                           # dense S is N^2*4 bytes: 400 MB at N=10k, 40 GB at 100k
-        S = torch.from_numpy(A.toarray().astype(np.float32))[None]
-        orc.graph_filter_step_dense(w, b, S, xs[:2])          # warm-up
-        t0 = time.perf_counter()
-        orc.graph_filter_step_dense(w, b, S, xs)
-        dt = time.perf_counter() - t0
-        out.update(value=sample * nnz * K / dt, seconds=round(dt, 3),
-                   sample=f"literal dense restatement of graphML.py:152-175 (fwd+bwd, fp32), {sample} of the batch's entries")
-    else:
-        out.update(value=out["sparse_port_value"],
-                   sample=f"sparse-CSR CPU restatement (dense S would be {N * N * 4 / 1e9:.0f} GB), {sample} batch entries")
     return out
 
 

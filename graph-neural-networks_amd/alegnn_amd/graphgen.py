@@ -108,3 +108,19 @@ def er(N, avg_degree=10.0, seed=0, directed=False, normalize=True) -> sp.csr_mat
     A = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(N, N))
     A.data[:] = 1.0
     return _normalise(A, normalize)
+
+
+def knn_weighted(N, k=10, seed=0, normalize=True) -> sp.csr_matrix:
+    """MovieLens-shaped GSO (BASELINE configs[2]): every node keeps k neighbours with similarity weights in (0, 1], the graph is
+    symmetrised (an edge survives if either end kept it, as the reference's kNN sparsification does, graphTools.py:650-678 on the
+    Pearson matrix of dataTools.py:1814-1871) and divided by its largest eigenvalue.  Synthetic stand-in: the data set itself needs
+    the network."""
+    rng = np.random.RandomState(seed)
+    rows = np.repeat(np.arange(N), k)
+    cols = rng.randint(0, N - 1, size=N * k)
+    cols = cols + (cols >= rows)                       # no self loops
+    w = rng.uniform(0.05, 1.0, size=N * k)
+    A = sp.csr_matrix((w, (rows, cols)), shape=(N, N))
+    A.sum_duplicates()
+    A = A.maximum(A.T)
+    return _normalise(A, normalize)

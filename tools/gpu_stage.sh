@@ -31,5 +31,16 @@ chain3)  # chain parity + probe
   timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "chain or pipelines_agree or edge_cases" > $O/pytest.log 2>&1; tail -5 $O/pytest.log
   timeout 600 python tools/chain_probe.py > $O/probe.log 2>&1; cat $O/probe.log
   ;;
+suite)   # the whole GPU suite (what the driver runs at round end) + smoke
+  timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -8 $O/pytest.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+  ;;
+bench)   # the driver's bench line + the other BASELINE workloads (CPU baselines included)
+  for w in cfg4 cfg2 cfg1 cfg3 cfg5; do timeout 900 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; tail -2 $O/bench_$w.err | cut -c1-300; cut -c1-1500 $O/bench_$w.json; done
+  ;;
+pmc)     # PMC traffic of the dominant kernels (own passes)
+  bash tools/pmc_collect.sh cfg4 spmm_sell_kernel r02 > $O/pmc_cfg4.log 2>&1; tail -1 $O/pmc_cfg4.log | cut -c1-800
+  bash tools/pmc_collect.sh cfg2 spmm_chain_kernel r02 > $O/pmc_cfg2.log 2>&1; tail -1 $O/pmc_cfg2.log | cut -c1-800
+  ;;
 *) echo "unknown stage $S"; exit 2;;
 esac

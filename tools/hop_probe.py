@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Launch the dominant kernel of a bench.py workload a few times, nothing else on the stream after set-up: the target of
+`rocprofv3 --pmc ...` / `--kernel-trace --stats` (tools/pmc_collect.sh).  Usage: hop_probe.py <workload> [iters] [key=val ...]"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-neural-networks_amd")]
+import torch
+import bench
+from alegnn_amd import _lib
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+L = _lib.lib()
+for kv in sys.argv[3:]:
+    k, v = kv.split("=")
+    assert L.gf_tune(k.encode(), int(v)) == 0, k
+dev = torch.device("cuda:0")
+wl = bench.WORKLOADS[name]
+w = bench.Workload(name, wl, dev, 0)
+st = torch.cuda.current_stream().cuda_stream
+if wl["kind"] == "evgf":
+    with torch.no_grad():
+        for _ in range(iters):
+            w.module(w.x.detach())
+else:
+    layer = w.module if wl["kind"] == "filter" else w.module.GFL[3]
+    B, N = wl["B"], layer.N
+    W = wl["G"] if wl["kind"] == "filter" else wl["dimF"][1]
+    K = wl["K"] if wl["kind"] == "filter" else wl["K"][1]
+    plans = layer._gso.plans(dev)
+    if L.gf_lsigf_pipeline(plans, 1, W, W, K) == 2:
+        Z = torch.randn(K, B * W // 4, N, 4, device=dev)
+        for _ in range(iters):
+            _lib.check(L.gf_khop_panel(plans, 1, 0, Z.data_ptr(), B, W, K, st))
+    else:
+        X0 = torch.randn(B, N, W, device=dev); X1 = torch.empty_like(X0)
+        for _ in range(iters):
+            _lib.check(L.gf_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, W, st))
+torch.cuda.synchronize()
