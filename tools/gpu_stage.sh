@@ -42,5 +42,10 @@ pmc)     # PMC traffic of the dominant kernels (own passes)
   bash tools/pmc_collect.sh cfg4 spmm_sell_kernel r02 > $O/pmc_cfg4.log 2>&1; tail -1 $O/pmc_cfg4.log | cut -c1-800
   bash tools/pmc_collect.sh cfg2 spmm_chain_kernel r02 > $O/pmc_cfg2.log 2>&1; tail -1 $O/pmc_cfg2.log | cut -c1-800
   ;;
+fullsize) # full-size parity tests + the two SelectionGNN bench lines + PMC traffic
+  timeout 1500 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu --durations=5 > $O/pytest_fullsize.log 2>&1; tail -12 $O/pytest_fullsize.log
+  for w in cfg1 cfg3; do timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; tail -2 $O/bench_$w.err | cut -c1-300; cut -c1-1800 $O/bench_$w.json; done
+  bash tools/gpu_stage.sh pmc $2
+  ;;
 *) echo "unknown stage $S"; exit 2;;
 esac
