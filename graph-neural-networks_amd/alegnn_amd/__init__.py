@@ -31,4 +31,7 @@ def install(reference_graphML_module):
     reference_graphML_module.NodeVariantGF = amd_gml.NodeVariantGF      # architectures.py:1630
     reference_graphML_module.GatedGRNN = amd_gml.GatedGRNN              # graphML.py:3642, 3810, 3985, 4163 (the HiddenState family)
     reference_graphML_module.HiddenState = amd_gml.HiddenState          # architectures.py:4497
+    reference_graphML_module.TimeGatedHiddenState = amd_gml.TimeGatedHiddenState      # architectures.py:4812
+    reference_graphML_module.NodeGatedHiddenState = amd_gml.NodeGatedHiddenState      # architectures.py:4816
+    reference_graphML_module.jARMA = amd_gml.jARMA                      # graphML.py:2826 (GraphFilterARMA.forward)
     return reference_graphML_module

@@ -43,18 +43,68 @@ class SparseGSO:
         self._plans = {}          # device index -> (ctypes array of plan pointers, [raw pointers])
         self._finalizer = weakref.finalize(self, SparseGSO._destroy_all, self._plans)
 
+    # ---- copying / pickling: the host CSR travels, device plans are rebuilt on first use (reference modules can be deep-copied and
+    #      pickled -- copy.deepcopy(model), torch.save(model) -- so ours must be; ctypes handles and the finalizer cannot travel) ------
+    def __getstate__(self):
+        return {"mats": self.mats}
+
+    def __setstate__(self, state):
+        self.__init__(state["mats"])
+
+    def __deepcopy__(self, memo):
+        return SparseGSO(self.mats)
+
+    # ---- derived operators (callers whose recursion uses a part of S: jARMA's Jacobi splitting, graphML.py:565-575) -----------------
+    def transposed(self) -> "SparseGSO":
+        return SparseGSO([m.T.tocsr() for m in self.mats])
+
+    def diagonal(self) -> np.ndarray:
+        """[E, N] diagonals."""
+        return np.stack([np.asarray(m.diagonal()) for m in self.mats])
+
+    def offdiagonal(self) -> "SparseGSO":
+        out = []
+        for m in self.mats:
+            o = m.tolil(copy=True)
+            o.setdiag(0)
+            o = o.tocsr()
+            o.eliminate_zeros()
+            out.append(o)
+        return SparseGSO(out)
+
     # ---- construction --------------------------------------------------------------------------------
+    _dense_cache = {}            # (data_ptr, version, shape, dtype, device) -> SparseGSO: functional calls LSIGF(h, S_dense, x) in a loop
+    _DENSE_CACHE_MAX = 8         # (GatedGRNN per time step, jARMA) must not rebuild host CSR + device plans on every call
+
     @classmethod
     def from_any(cls, S) -> "SparseGSO":
         if isinstance(S, SparseGSO):
             return S
+        if isinstance(S, torch.Tensor) and S.layout == torch.strided:
+            key = (S.data_ptr(), S._version, tuple(S.shape), S.dtype, str(S.device))
+            hit = cls._dense_cache.get(key)
+            if hit is not None and hit[0]() is S:                # same tensor object, unmodified since
+                return hit[1]
+            gso = cls._from_dense_tensor(S)
+            if len(cls._dense_cache) >= cls._DENSE_CACHE_MAX:
+                cls._dense_cache.pop(next(iter(cls._dense_cache)))
+            cls._dense_cache[key] = (weakref.ref(S), gso)
+            return gso
+        return cls._from_other(S)
+
+    @classmethod
+    def _from_dense_tensor(cls, S) -> "SparseGSO":
+        return cls._from_other(S.detach().cpu().numpy())
+
+    @classmethod
+    def _from_other(cls, S) -> "SparseGSO":
         if isinstance(S, torch.Tensor):
             if S.layout != torch.strided:                       # torch sparse COO / CSR, 2-D
                 Sc = S.detach().cpu().to_sparse_coo().coalesce()
                 assert Sc.dim() == 2, "sparse torch GSO must be 2-D (one edge feature)"
                 idx = Sc.indices().numpy()
                 return cls([sp.csr_matrix((Sc.values().numpy(), (idx[0], idx[1])), shape=tuple(Sc.shape))])
-            S = S.detach().cpu().numpy()
+            S = S.detach().cpu().numpy()                        # (strided tensors arrive here as numpy already)
         if sp.issparse(S):
             return cls([S])
         if isinstance(S, (list, tuple)):
@@ -126,6 +176,17 @@ class EdgePattern:
     ``(|S_e| + I > zeroTolerance)`` restricted to entries whose row < M or column < M (hybrid mask)."""
 
     ZERO_TOLERANCE = 1e-9                                       # graphML.py:27
+
+    def __getstate__(self):
+        return {"indptr": self.indptr, "indices": self.indices, "N": self.N}
+
+    def __setstate__(self, state):
+        n = state["N"]
+        self.__init__(sp.csr_matrix((np.ones(len(state["indices"]), dtype=np.float32), state["indices"], state["indptr"]), shape=(n, n)))
+
+    def __deepcopy__(self, memo):
+        n = self.N
+        return EdgePattern(sp.csr_matrix((np.ones(self.nnzp, dtype=np.float32), self.indices, self.indptr), shape=(n, n)))
 
     def __init__(self, pattern: sp.csr_matrix):
         pattern = sp.csr_matrix(pattern)

@@ -116,7 +116,10 @@ class Trainer:
     def _graph_step(self, xTrain, yTrain, samplesType, indices, weight):
         """zero-grad + forward + loss + backward for this batch shape, captured on first use and replayed afterwards.
         Returns (loss tensor, output tensor): the graph's static outputs, valid until the next replay."""
-        key = (tuple(xTrain.shape), tuple(yTrain.shape), xTrain.dtype, yTrain.dtype)
+        # A captured step embeds raw device pointers of the GSO plans and the per-rank loss weight: both are part of the key, and the
+        # entry keeps the GSO objects alive (their finalizer frees the plans) -- changeGSO() simply leads to a new capture.
+        gsos = tuple(m._gso for m in self.model.archit.modules() if getattr(m, "_gso", None) is not None)
+        key = (tuple(xTrain.shape), tuple(yTrain.shape), xTrain.dtype, yTrain.dtype, float(weight), tuple(id(g_) for g_ in gsos))
         g = self._graphs.get(key)
         if g is None:
             dev = self.model.device
@@ -146,9 +149,8 @@ class Trainer:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = body()
-            g = self._graphs[key] = dict(graph=graph, x=sx, y=sy, out=out, weight=weight,
+            g = self._graphs[key] = dict(graph=graph, x=sx, y=sy, out=out, weight=weight, gsos=gsos,
                                          grads=[p.grad for p in params], params=params)
-        assert g["weight"] == weight, "hipGraph: the per-rank share of this batch size changed"
         g["x"].copy_(xTrain, non_blocking=True)
         g["y"].copy_(yTrain, non_blocking=True)
         g["graph"].replay()

@@ -6,6 +6,8 @@ Drop-in for the symbols SelectionGNN binds from alegnn/utils/graphML.py:
     EdgeVariantGF  (graphML.py:2511-2712)  -> same ctor / parameters (dense weightEV), or per-edge storage (sparse=True)
     GatedGRNN      (graphML.py:1292-1527)  hidden-state recursion, one LSIGF over all B*T inputs + one per time step
     HiddenState    (graphML.py:3540-3681)  the module around it (GraphRecurrentNN's recurrent layer)
+    TimeGatedHiddenState / NodeGatedHiddenState (graphML.py:3683-4031)  the gated recurrent layers (GatedGCRNNforRegression & co.)
+    jARMA          (graphML.py:490-638)    ARMA filter by Jacobi iterations: sparse hops instead of dense [F,E,P,G,N,N] products
     NVGF           (graphML.py:293-387)    -> alegnn_amd.functional.NVGF  (HIP: LSIGF's tap stack, per-node bank)
     NodeVariantGF  (graphML.py:2317-2509)  the module around it (NodeVariantGNN's layer)
     NoPool         (graphML.py:1850-1888)  identity pooling
@@ -26,7 +28,8 @@ from ..functional import EVGF_edges, LSIGF, NVGF, expand_node_taps, max_pool_loc
 from ..gso import EdgePattern, SparseGSO
 from . import graphTools
 
-__all__ = ["LSIGF", "GraphFilter", "EdgeVariantGF", "NoPool", "MaxPoolLocal", "FusedReLU", "GatedGRNN", "HiddenState", "NVGF", "NodeVariantGF"]
+__all__ = ["LSIGF", "GraphFilter", "EdgeVariantGF", "NoPool", "MaxPoolLocal", "FusedReLU", "GatedGRNN", "HiddenState", "TimeGatedHiddenState",
+           "NodeGatedHiddenState", "jARMA", "NVGF", "NodeVariantGF"]
 
 
 class FusedReLU(nn.Identity):
@@ -456,3 +459,176 @@ class HiddenState(nn.Module):
                      "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias) + "nonlinearity=%s" % (self.sigma)
         reprString += "GSO stored" if self.S is not None else "no GSO stored"
         return reprString
+
+
+class _GatedHiddenStateBase(nn.Module):
+    """Common part of TimeGatedHiddenState / NodeGatedHiddenState (graphML.py:3683-4031): the state taps (``aWeights``, ``bWeights``,
+    ``xBias``, ``zBias``) and two ungated HiddenState layers whose outputs feed the input / forget gates.  Same parameter names and
+    shapes as the reference: its checkpoints load."""
+
+    def __init__(self, F, H, K, nonlinearity=torch.tanh, E=1, bias=True):
+        super().__init__()
+        self.F = F
+        self.H = H
+        self.K = K
+        self.E = E
+        self.S = None
+        self._gso = None
+        self.bias = bias
+        self.sigma = nonlinearity
+        self.aWeights = nn.parameter.Parameter(torch.Tensor(H, E, K, F))
+        self.bWeights = nn.parameter.Parameter(torch.Tensor(H, E, K, H))
+        self.inputGateGRNN = HiddenState(F, H, K, bias=bias)         # :3748 / :3920
+        self.forgetGateGRNN = HiddenState(F, H, K, bias=bias)        # :3750 / :3922
+        if self.bias:
+            self.xBias = nn.parameter.Parameter(torch.Tensor(H, 1))
+            self.zBias = nn.parameter.Parameter(torch.Tensor(H, 1))
+        else:
+            self.register_parameter('xBias', None)
+            self.register_parameter('zBias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.F * self.K)                      # :3765-3771
+        self.aWeights.data.uniform_(-stdv, stdv)
+        self.bWeights.data.uniform_(-stdv, stdv)
+        if self.bias:
+            self.xBias.data.uniform_(-stdv, stdv)
+            self.zBias.data.uniform_(-stdv, stdv)
+
+    def _set_gso(self, S):
+        if sp.issparse(S) or isinstance(S, (list, tuple)):
+            S = SparseGSO.from_any(S)
+        assert len(S.shape) == 3 and S.shape[0] == self.E           # :3822-3824
+        self.N = S.shape[1]
+        assert S.shape[2] == self.N
+        self.S = S
+        self._gso = SparseGSO.from_any(S)
+        self.inputGateGRNN.addGSO(self._gso)
+        self.forgetGateGRNN.addGSO(self._gso)
+
+    def _check(self, x, z0):
+        assert self._gso is not None
+        assert len(x.shape) == 4 and x.shape[2] == self.F
+        B, T, N = x.shape[0], x.shape[1], x.shape[3]
+        assert len(z0.shape) == 3 and z0.shape[0] == B and z0.shape[1] == self.H and z0.shape[2] == N
+        return B, T, N
+
+    def _state(self, x, z0, qHat, qCheck, T):
+        z = GatedGRNN(self.aWeights, self.bWeights, self._gso, x, z0, self.sigma, qHat, qCheck, xBias=self.xBias, zBias=self.zBias)
+        return z, z[:, T - 1:T].unsqueeze(1)                        # index_select(T-1) then unsqueeze(1), as HiddenState
+
+    def extra_repr(self):
+        reprString = "in_features=%d, hidden_features=%d, " % (self.F, self.H) + "filter_taps=%d, " % (self.K) + \
+                     "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias) + "nonlinearity=%s" % (self.sigma)
+        reprString += "GSO stored" if self.S is not None else "no GSO stored"
+        return reprString
+
+
+class TimeGatedHiddenState(_GatedHiddenStateBase):
+    """TimeGatedHiddenState(signal_features, hidden_features, filter_taps, nonlinearity=torch.tanh, edge_features=1, bias=True)
+    -- graphML.py:3683-3855.  One scalar input gate and one forget gate per (sample, time step): a fully connected layer on the
+    states of an ungated recurrent layer, ``inputGateFC`` / ``forgetGateFC`` = Linear(H*N, 1) created by ``addGSO`` (:3829-3830).
+    forward(x [B,T,F,N], z0 [B,H,N]) -> (z [B,T,H,N], z_T [B,1,1,H,N]); every LSIGF inside runs on the HIP path."""
+
+    def addGSO(self, S):
+        self._set_gso(S)
+        dt, dev = self.aWeights.dtype, self.aWeights.device
+        self.inputGateFC = nn.Linear(self.H * self.N, 1, self.bias).to(device=dev, dtype=dt)
+        self.forgetGateFC = nn.Linear(self.H * self.N, 1, self.bias).to(device=dev, dtype=dt)
+
+    def forward(self, x, z0):
+        B, T, N = self._check(x, z0)
+        zHat, _ = self.inputGateGRNN(x, z0)                          # :3795-3798
+        qHat = torch.sigmoid(self.inputGateFC(zHat.reshape((B, T, self.H * N)))).unsqueeze(2)       # B x T x 1 x 1
+        zCheck, _ = self.forgetGateGRNN(x, z0)                       # :3801-3804
+        qCheck = torch.sigmoid(self.forgetGateFC(zCheck.reshape((B, T, self.H * N)))).unsqueeze(2)
+        return self._state(x, z0, qHat, qCheck, T)
+
+
+class NodeGatedHiddenState(_GatedHiddenStateBase):
+    """NodeGatedHiddenState(...) -- graphML.py:3857-4031.  One input gate and one forget gate per (sample, time step, node): a
+    GraphFilter(H, 1, K) on the states of an ungated recurrent layer, ``inputGateGraphFilter`` / ``forgetGateGraphFilter`` created by
+    ``addGSO`` (:4012-4013).  forward as TimeGatedHiddenState."""
+
+    def addGSO(self, S):
+        self._set_gso(S)
+        dt, dev = self.aWeights.dtype, self.aWeights.device
+        self.inputGateGraphFilter = GraphFilter(self.H, 1, self.K, bias=self.bias).to(device=dev, dtype=dt)
+        self.forgetGateGraphFilter = GraphFilter(self.H, 1, self.K, bias=self.bias).to(device=dev, dtype=dt)
+        self.inputGateGraphFilter.addGSO(self._gso)
+        self.forgetGateGraphFilter.addGSO(self._gso)
+
+    def forward(self, x, z0):
+        B, T, N = self._check(x, z0)
+        zHat, _ = self.inputGateGRNN(x, z0)                          # :3970-3973
+        qHat = torch.sigmoid(self.inputGateGraphFilter(zHat.reshape((B * T, self.H, N)))).reshape((B, T, 1, N))
+        zCheck, _ = self.forgetGateGRNN(x, z0)                       # :3976-3979
+        qCheck = torch.sigmoid(self.forgetGateGraphFilter(zCheck.reshape((B * T, self.H, N)))).reshape((B, T, 1, N))
+        return self._state(x, z0, qHat, qCheck, T)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ARMA filter by Jacobi iterations (SURVEY.md section 8 f-3): the residue is an LSIGF, the iterations are hops with the
+# off-diagonal part of S
+# ---------------------------------------------------------------------------------------------------------------
+def _shift(off_t, v):
+    """Stilde_e @ v for every edge feature e: v [B', E, G, N] -> [B', E, G, N], each product through the HIP filter (an LSIGF with
+    K = 2 whose only non-zero taps are the identity on tap 1, on the plan of Stilde_e^T: LSIGF applies x S, the iteration needs S x).
+    off_t: one single-feature SparseGSO (of Stilde_e^T) per edge feature."""
+    Bp, E, G, N = v.shape
+    sel = torch.zeros((G, 1, 2, G), dtype=v.dtype, device=v.device)
+    sel[:, 0, 1, :] = torch.eye(G, dtype=v.dtype, device=v.device)
+    return torch.stack([LSIGF(sel, off_t[e], v[:, e].contiguous()) for e in range(E)], dim=1)
+
+
+def jARMA(psi, varphi, phi, S, x, b=None, tMax=5):
+    """ARMA graph filter evaluated with tMax Jacobi iterations -- reference signature and semantics, graphML.py:490-638:
+
+        u_f = sum_{e,g} sum_p [ sum_{tau=0..tMax} (-1)^tau varphi_p (Sbar_p^-1 Stilde)^tau Sbar_p^-1 x_g
+                                + (-1)^(tMax+1) (Sbar_p^-1 Stilde)^(tMax+1) x_g ]  +  LSIGF(phi, S, x)  (+ b)
+        Sbar_p^{fge} = Diag(S_e) - psi_p^{fge} I,   Stilde = DiagOff(S_e)
+
+    psi, varphi [F,E,P,G], phi [F,E,K,G], S [E,N,N] (dense tensor or anything SparseGSO.from_any accepts), x [B,G,N].
+    The reference materialises Sbar^-1 Stilde as a dense [F,E,P,G,N,N] tensor (:585-589); here Sbar^-1 is the diagonal it is
+    ([F,E,P,G,N], elementwise) and every product with Stilde is a sparse hop of the [B,F,E,P,G] chain states on the HIP path."""
+    F, E, P, G = psi.shape
+    assert varphi.shape == psi.shape                                 # :549-552
+    assert phi.shape[0] == F and phi.shape[1] == E and phi.shape[3] == G
+    B = x.shape[0]
+    assert x.shape[1] == G
+    N = x.shape[2]
+    gso = SparseGSO.from_any(S)
+    assert gso.E == E and gso.N == N                                 # :560-561
+    key = "_jarma_parts"
+    parts = getattr(gso, key, None)
+    if parts is None:                                                # the Jacobi splitting of S, once per GSO
+        off = gso.offdiagonal().transposed()
+        parts = ([SparseGSO([m]) for m in off.mats], gso.diagonal())
+        setattr(gso, key, parts)
+    off_t, diag = parts
+    d = torch.as_tensor(diag, dtype=x.dtype, device=x.device)        # [E, N]
+    Dinv = 1.0 / (d.reshape(1, E, 1, 1, N) - psi.reshape(F, E, P, G, 1))      # Sbar^-1 (diagonal), [F,E,P,G,N]   (:573-583)
+
+    def shift(v):                                                    # v [B,F,E,P,G,N] -> Sbar^-1 Stilde v
+        w = v.permute(0, 1, 3, 2, 4, 5).reshape(B * F * P, E, G, N)
+        w = _shift(off_t, w).reshape(B, F, P, E, G, N).permute(0, 1, 3, 2, 4, 5)
+        return Dinv.unsqueeze(0) * w
+
+    x1 = Dinv.unsqueeze(0) * x.reshape(B, 1, 1, 1, G, N)             # Sbar^-1 x                       (:584-586)
+    y = x.reshape(B, 1, 1, 1, G, N).expand(B, F, E, P, G, N)
+    sign = 1.0
+    H1 = varphi.reshape(1, F, E, P, G, 1) * x1                       # tau = 0 term of H1
+    for tau in range(1, tMax + 1):                                   # :602-612
+        x1 = shift(x1)
+        y = shift(y)
+        sign = -sign
+        H1 = H1 + sign * varphi.reshape(1, F, E, P, G, 1) * x1
+    y = shift(y)                                                     # (Sbar^-1 Stilde)^(tMax+1) x     (:627)
+    H2 = -y if tMax % 2 == 0 else y                                  # :629
+    u = (H1 + H2).sum(dim=(2, 3, 4))                                 # over e, p, g -> [B,F,N]          (:630-635)
+    u = u + LSIGF(phi, gso, x)                                       # H3: the residue filter          (:598)
+    if b is not None:
+        u = u + b
+    return u
+

@@ -45,17 +45,22 @@ __global__ __launch_bounds__(TILE* TROWS) void transpose_pad_kernel(const float*
     }
 }
 
+constexpr int kMaxGridZ = 65535;
+
 }  // namespace
 
 extern "C" int gf_layout_bgn_to_bng(const float* x, float* X, int32_t B, int32_t G, int32_t Nin, int32_t N, void* stream) {
     GF_REQUIRE_ARG(x && X, "gf_layout_bgn_to_bng: NULL tensor");
     GF_REQUIRE_SHAPE(B > 0 && G > 0 && Nin > 0 && N >= Nin, "gf_layout_bgn_to_bng: bad shape B=%d G=%d Nin=%d N=%d", B, G,
                      Nin, N);
-    GF_REQUIRE_SHAPE(B <= 65535, "gf_layout_bgn_to_bng: batch %d > 65535", B);
-    dim3 grid((N + TILE - 1) / TILE, (G + TILE - 1) / TILE, B), block(TILE, TROWS);
-    hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, gf_stream(stream), x, X, G, Nin, N, (int64_t)G * Nin,
-                       (int64_t)N * G, (const float*)nullptr);
-    GF_LAUNCH_CHECK("transpose_pad_kernel(bgn->bng)");
+    // the batch rides on gridDim.z (<= 65535): recurrent layers fold B*T into the batch, so longer batches go in slices
+    for (int32_t b0 = 0; b0 < B; b0 += kMaxGridZ) {
+        const int32_t nb = B - b0 < kMaxGridZ ? B - b0 : kMaxGridZ;
+        dim3 grid((N + TILE - 1) / TILE, (G + TILE - 1) / TILE, nb), block(TILE, TROWS);
+        hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, gf_stream(stream), x + (int64_t)b0 * G * Nin, X + (int64_t)b0 * N * G, G, Nin,
+                           N, (int64_t)G * Nin, (int64_t)N * G, (const float*)nullptr);
+        GF_LAUNCH_CHECK("transpose_pad_kernel(bgn->bng)");
+    }
     return GF_OK;
 }
 
@@ -63,21 +68,26 @@ extern "C" int gf_layout_bng_to_bgn(const float* X, float* x, int32_t B, int32_t
     GF_REQUIRE_ARG(x && X, "gf_layout_bng_to_bgn: NULL tensor");
     GF_REQUIRE_SHAPE(B > 0 && G > 0 && Nout > 0 && N >= Nout, "gf_layout_bng_to_bgn: bad shape B=%d G=%d N=%d Nout=%d", B,
                      G, N, Nout);
-    GF_REQUIRE_SHAPE(B <= 65535, "gf_layout_bng_to_bgn: batch %d > 65535", B);
     // in = X viewed [B, R = N(only first Nout rows used), C = G]; out[b][g][n] has leading dim Nout, so run the
     // kernel with R = Nout rows of the input (input batch stride still N*G).
-    dim3 grid((G + TILE - 1) / TILE, (Nout + TILE - 1) / TILE, B), block(TILE, TROWS);
-    hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, gf_stream(stream), X, x, Nout, G, G, (int64_t)N * G,
-                       (int64_t)G * Nout, (const float*)nullptr);
-    GF_LAUNCH_CHECK("transpose_pad_kernel(bng->bgn)");
+    for (int32_t b0 = 0; b0 < B; b0 += kMaxGridZ) {
+        const int32_t nb = B - b0 < kMaxGridZ ? B - b0 : kMaxGridZ;
+        dim3 grid((G + TILE - 1) / TILE, (Nout + TILE - 1) / TILE, nb), block(TILE, TROWS);
+        hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, gf_stream(stream), X + (int64_t)b0 * N * G, x + (int64_t)b0 * G * Nout, Nout, G,
+                           G, (int64_t)N * G, (int64_t)G * Nout, (const float*)nullptr);
+        GF_LAUNCH_CHECK("transpose_pad_kernel(bng->bgn)");
+    }
     return GF_OK;
 }
 
 // dy [B,F,Nin] (reference layout) -> P0 [B,N,F] node-major with the ReLU mask of the saved output y applied on the way
 int gf_layout_masked_launch(const float* dy, const float* y, float* X, int B, int G, int Nin, int N, hipStream_t st) {
-    GF_REQUIRE_SHAPE(B <= 65535, "gf_layout: batch %d > 65535", B);
-    dim3 grid((N + TILE - 1) / TILE, (G + TILE - 1) / TILE, B), block(TILE, TROWS);
-    hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, st, dy, X, G, Nin, N, (int64_t)G * Nin, (int64_t)N * G, y);
-    GF_LAUNCH_CHECK("transpose_pad_kernel(masked)");
+    for (int b0 = 0; b0 < B; b0 += kMaxGridZ) {
+        const int nb = B - b0 < kMaxGridZ ? B - b0 : kMaxGridZ;
+        dim3 grid((N + TILE - 1) / TILE, (G + TILE - 1) / TILE, nb), block(TILE, TROWS);
+        hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, st, dy + (int64_t)b0 * G * Nin, X + (int64_t)b0 * N * G, G, Nin, N,
+                           (int64_t)G * Nin, (int64_t)N * G, y ? y + (int64_t)b0 * G * Nin : nullptr);
+        GF_LAUNCH_CHECK("transpose_pad_kernel(masked)");
+    }
     return GF_OK;
 }

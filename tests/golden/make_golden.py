@@ -204,6 +204,64 @@ def grnn_case(name, S, B, T, F, H, K, gating, seed=0):
     print(f"grnn_{name}: z{tuple(z.shape)} gating={gating}")
 
 
+def gated_hidden_state_case(name, kind, S, B, T, F, H, K, seed=0):
+    """gml.TimeGatedHiddenState / gml.NodeGatedHiddenState (graphML.py:3683-4031): module forward + autograd, with the gate layers
+    the module creates in addGSO (Linear(H*N, 1) / GraphFilter(H, 1, K))."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    E, N = S.shape[0], S.shape[1]
+    layer = (gml.TimeGatedHiddenState if kind == "time" else gml.NodeGatedHiddenState)(F, H, K, nonlinearity=torch.tanh, E=E, bias=True)
+    layer.addGSO(torch.tensor(S))
+    x = rng.randn(B, T, F, N)
+    z0 = rng.randn(B, H, N)
+    dz = rng.randn(B, T, H, N)
+    xt, z0t = torch.tensor(x, requires_grad=True), torch.tensor(z0, requires_grad=True)
+    z, zT = layer(xt, z0t)
+    (z * torch.tensor(dz)).sum().backward()
+    out = dict(x=x, z0=z0, dz=dz, kind=np.array(kind), z=z.detach().numpy(), zT_shape=np.array(zT.shape), dx=xt.grad.numpy(),
+               dz0=z0t.grad.numpy(), dims=np.array([F, H, K, E]), **coo(S))
+    for k, v in layer.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in layer.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"gatedhs_{name}.npz"), **out)
+    print(f"gatedhs_{name}: z{tuple(z.shape)} keys={list(layer.state_dict())}")
+
+
+def jarma_case(name, S, B, G, F, P, K, tMax, bias=True, seed=0):
+    """gml.jARMA (graphML.py:490-638): forward + autograd wrt the three tap sets, the input and the bias."""
+    rng = np.random.RandomState(seed)
+    E, N = S.shape[0], S.shape[1]
+    psi = rng.uniform(1.5, 2.5, (F, E, P, G)) * rng.choice([-1.0, 1.0], (F, E, P, G))     # away from the diagonal of S: Sbar invertible
+    varphi = rng.uniform(-1, 1, (F, E, P, G)) / np.sqrt(G * P)
+    phi = rng.uniform(-1, 1, (F, E, K, G)) / np.sqrt(G * K)
+    x = rng.randn(B, G, N)
+    b = rng.uniform(-1, 1, (F, 1)) if bias else None
+    dy = rng.randn(B, F, N)
+    t = {k: torch.tensor(v, requires_grad=True) for k, v in dict(psi=psi, varphi=varphi, phi=phi, x=x).items()}
+    bt = torch.tensor(b, requires_grad=True) if bias else None
+    y = gml.jARMA(t["psi"], t["varphi"], t["phi"], torch.tensor(S), t["x"], bt, tMax=tMax)
+    (y * torch.tensor(dy)).sum().backward()
+    out = dict(psi=psi, varphi=varphi, phi=phi, x=x, dy=dy, tMax=np.array(tMax), y=y.detach().numpy(), **coo(S))
+    for k, v in t.items():
+        out["d" + k] = v.grad.numpy()
+    if bias:
+        out["b"], out["db"] = b, bt.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"jarma_{name}.npz"), **out)
+    print(f"jarma_{name}: y{tuple(y.shape)} tMax={tMax}")
+
+
+def f3_cases(sbm, asym, asym37):
+    gated_hidden_state_case("sbm100_time", "time", sbm[None], B=3, T=4, F=2, H=8, K=3, seed=5)
+    gated_hidden_state_case("sbm100_node", "node", sbm[None], B=2, T=3, F=4, H=8, K=3, seed=6)
+    gated_hidden_state_case("asym37_node", "node", asym37, B=2, T=3, F=3, H=4, K=2, seed=7)
+    diag = asym37.copy()
+    diag[0, np.arange(37), np.arange(37)] = np.linspace(-0.4, 0.4, 37)                       # a GSO with a non-zero diagonal
+    jarma_case("asym37diag_P2", diag, B=3, G=4, F=5, P=2, K=3, tMax=5, seed=8)
+    jarma_case("asym_E2_P1_t4", asym, B=2, G=3, F=4, P=1, K=2, tMax=4, bias=False, seed=9)   # E = 2, even tMax (sign of H2)
+    jarma_case("sbm100_P3", sbm[None], B=2, G=8, F=8, P=3, K=4, tMax=3, seed=10)
+
+
 def graph_recurrent_nn_case(name, S2d, B, T, seed=0):
     """archit.GraphRecurrentNN (architectures.py:4357-4672).  The initial state is drawn inside splitForward (:4556); the same
     draw is repeated here after re-seeding and stored, so that the rebuilt model can be fed the identical z0."""
@@ -408,6 +466,9 @@ def main():
         return
     if "--grnn-only" in sys.argv:
         grnn_cases(sbm, asym, fb)
+        return
+    if "--f3-only" in sys.argv:
+        f3_cases(sbm, asym, asym37)
         return
     if "--trainer-only" in sys.argv:
         trainer_cases(G, sbm)

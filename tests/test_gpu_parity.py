@@ -437,6 +437,44 @@ def test_gated_grnn_matches_reference(path):
         assert torch.equal(zz, z.detach()) and list(zT.shape) == d["zT_shape"].tolist()
 
 
+@pytest.mark.parametrize("path", golden_files("gatedhs"), ids=case_id)
+def test_gated_hidden_state_modules_match_reference(path):
+    """TimeGatedHiddenState / NodeGatedHiddenState (graphML.py:3683-4031): two ungated recurrent layers feed the gates (a Linear(H*N, 1)
+    per time step, or a GraphFilter(H, 1, K) per node), the gated recursion produces the states; the reference's own state_dict loads."""
+    d = load(path)
+    F, H, K, E = (int(v) for v in d["dims"])
+    cls = gml.TimeGatedHiddenState if str(d["kind"]) == "time" else gml.NodeGatedHiddenState
+    layer = cls(F, H, K, nonlinearity=torch.tanh, E=E, bias=True)
+    layer.addGSO(torch.tensor(d["S"]))
+    layer.load_state_dict({k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")})
+    layer = layer.float().to(DEV)
+    x, z0 = cu(d["x"], True), cu(d["z0"], True)
+    z, zT = layer(x, z0)
+    assert list(zT.shape) == d["zT_shape"].tolist()
+    (z * cu(d["dz"])).sum().backward()
+    assert relerr(z.detach().cpu().numpy(), d["z"]) < 3 * FWD_RTOL          # three chained recurrent layers + sigmoid gates
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    assert relerr(z0.grad.cpu().numpy(), d["dz0"]) < GRAD_RTOL
+    for k, p in layer.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
+
+
+@pytest.mark.parametrize("path", golden_files("jarma"), ids=case_id)
+def test_jarma_matches_reference(path):
+    """jARMA (graphML.py:490-638): Jacobi iterations as sparse hops of the [B,F,E,P,G] chain states (the reference multiplies dense
+    [F,E,P,G,N,N] tensors) + the LSIGF residue; output and the gradients of all three tap sets, the input and the bias."""
+    d = load(path)
+    t = {k: cu(d[k], True) for k in ("psi", "varphi", "phi", "x")}
+    b = cu(d["b"], True) if "b" in d else None
+    y = gml.jARMA(t["psi"], t["varphi"], t["phi"], torch.tensor(d["S"]), t["x"], b, tMax=int(d["tMax"]))
+    y.backward(cu(d["dy"]))
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < 2 * FWD_RTOL
+    for k, v in t.items():
+        assert relerr(v.grad.cpu().numpy(), d["d" + k]) < GRAD_RTOL, k
+    if b is not None:
+        assert relerr(b.grad.cpu().numpy(), d["db"]) < GRAD_RTOL
+
+
 def test_graph_recurrent_nn_matches_reference():
     from alegnn_amd.modules.architectures import GraphRecurrentNN
     d = load(os.path.join(GOLDEN, "grnnarch_sbm100.npz"))
@@ -577,6 +615,27 @@ def test_gradients_are_deterministic(cfg2):
     for a, b in zip(*grads):
         assert torch.equal(a, b)
     layer.zero_grad()
+
+
+def test_batch_beyond_the_grid_z_limit(pipeline_knob):
+    """Recurrent layers fold B*T into the batch: more than 65535 batch entries through the node-major layout kernels (they put the
+    batch on gridDim.z and go in slices), forward and gradients against the oracle."""
+    N, B, G, F, K = 12, 70_000, 4, 4, 3
+    rng = np.random.RandomState(0)
+    A = sp.random(N, N, density=0.3, format="csr", random_state=rng, data_rvs=rng.randn) * 0.3
+    pipeline_knob(pipeline=1)
+    h = (rng.uniform(-1, 1, (F, 1, K, G)) / np.sqrt(G * K)).astype(np.float32)
+    x = rng.randn(B, G, N).astype(np.float32)
+    dy = rng.randn(B, F, N).astype(np.float32)
+    ht, xt = cu(h, True), cu(x, True)
+    y = LSIGF(ht, SparseGSO([A]), xt, None)
+    y.backward(cu(dy))
+    sl = [0, 65534, 65535, 65536, B - 1]
+    assert relerr(y.detach()[sl].cpu().numpy(), orc.lsigf_sparse(h, [A], x[sl], None)) < FWD_RTOL
+    dx, _, _ = orc.lsigf_sparse_grads(h, [A], x[sl], None, dy[sl])
+    assert relerr(xt.grad[sl].cpu().numpy(), dx) < GRAD_RTOL
+    _, dh, _ = orc.lsigf_sparse_grads(h, [A], x, None, dy)
+    assert relerr(ht.grad.cpu().numpy(), dh) < GRAD_RTOL
 
 
 def test_error_conventions_on_device():

@@ -590,3 +590,74 @@ def test_trainer_hip_graph_option_is_inert_off_gpu(tmp_path):
                  hipGraph=True, **ast.literal_eval(str(d["trainKw"])))
     assert m.trainer.useGraph and len(m.trainer._graphs) == 0
     assert np.allclose(tv["lossTrain"], d["lossTrain"], rtol=1e-9, atol=1e-12)
+
+
+# ---- callers of LSIGF whose own logic is host-side composition ------------------------------------------
+def _cpu_lsigf(h, S, x, b=None, activation=None):
+    """The oracle's dense LSIGF behind alegnn_amd's call signature: lets the HOST logic of jARMA / the gated hidden-state modules be
+    checked against the reference's goldens on a box without a GPU (the HIP kernels under the same calls are checked by -m gpu)."""
+    from oracle import lsigf_oracle as orc
+    gso = SparseGSO.from_any(S)
+    N, nin = gso.N, x.shape[2]
+    xp = torch.nn.functional.pad(x, (0, N - nin))
+    y = orc.lsigf_dense(h, gso.to_dense(x.dtype), xp, b)[:, :, :nin]
+    return torch.relu(y) if activation == "relu" else y
+
+
+@pytest.mark.parametrize("path", sorted(__import__("glob").glob(os.path.join(GOLDEN, "jarma_*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+def test_jarma_host_logic_reproduces_reference(path, monkeypatch):
+    monkeypatch.setattr(gml, "LSIGF", _cpu_lsigf)
+    d = load(path)
+    t = {k: torch.tensor(d[k], requires_grad=True) for k in ("psi", "varphi", "phi", "x")}
+    b = torch.tensor(d["b"], requires_grad=True) if "b" in d else None
+    y = gml.jARMA(t["psi"], t["varphi"], t["phi"], torch.tensor(d["S"]), t["x"], b, tMax=int(d["tMax"]))
+    (y * torch.tensor(d["dy"])).sum().backward()
+    assert np.abs(y.detach().numpy() - d["y"]).max() < 1e-10 * np.abs(d["y"]).max()
+    for k, v in t.items():
+        assert np.abs(v.grad.numpy() - d["d" + k]).max() < 1e-9 * np.abs(d["d" + k]).max(), k
+    if b is not None:
+        assert np.abs(b.grad.numpy() - d["db"]).max() < 1e-9 * np.abs(d["db"]).max()
+
+
+@pytest.mark.parametrize("path", sorted(__import__("glob").glob(os.path.join(GOLDEN, "gatedhs_*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+def test_gated_hidden_state_host_logic_reproduces_reference(path, monkeypatch):
+    monkeypatch.setattr(gml, "LSIGF", _cpu_lsigf)
+    d = load(path)
+    F, H, K, E = (int(v) for v in d["dims"])
+    cls = gml.TimeGatedHiddenState if str(d["kind"]) == "time" else gml.NodeGatedHiddenState
+    layer = cls(F, H, K, nonlinearity=torch.tanh, E=E, bias=True).double()
+    layer.addGSO(torch.tensor(d["S"]))
+    sd = {k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")}
+    assert set(sd) == set(layer.state_dict())                       # the reference's checkpoint keys, exactly
+    layer.load_state_dict(sd)
+    x, z0 = torch.tensor(d["x"], requires_grad=True), torch.tensor(d["z0"], requires_grad=True)
+    z, zT = layer(x, z0)
+    assert list(zT.shape) == d["zT_shape"].tolist()
+    (z * torch.tensor(d["dz"])).sum().backward()
+    assert np.abs(z.detach().numpy() - d["z"]).max() < 1e-10
+    assert np.abs(x.grad.numpy() - d["dx"]).max() < 1e-9 * max(1.0, np.abs(d["dx"]).max())
+    for k, p in layer.named_parameters():
+        assert np.abs(p.grad.numpy() - d["grad:" + k]).max() < 1e-9 * max(1.0, np.abs(d["grad:" + k]).max()), k
+
+
+def test_gso_objects_copy_and_pickle():
+    """Reference modules can be deep-copied and pickled (copy.deepcopy(model), torch.save(model)); the GSO holders carry ctypes plan
+    handles and a finalizer, so they travel as host CSR and rebuild their device plans on first use."""
+    import copy
+    import pickle
+    A = sp.random(50, 50, density=0.1, format="csr", random_state=np.random.RandomState(0))
+    layer = gml.GraphFilter(4, 8, 3)
+    layer.addGSO(A)
+    layer._gso._plans[0] = ("fake-handle-array", [])                # as if device plans existed (no GPU here)
+    try:
+        for clone in (copy.deepcopy(layer), pickle.loads(pickle.dumps(layer))):
+            assert clone._gso is not layer._gso and clone._gso._plans == {}
+            assert (clone._gso.mats[0] != layer._gso.mats[0]).nnz == 0
+            assert torch.equal(clone.weight, layer.weight)
+    finally:
+        layer._gso._plans.clear()
+    ev = gml.EdgeVariantGF(2, 3, 2, 50, 50, 1, True, sparse=True)
+    ev.addGSO(A)
+    clone = pickle.loads(pickle.dumps(ev))
+    assert clone._patterns[0].nnzp == ev._patterns[0].nnzp and clone._patterns[0]._plans == {}
+

@@ -47,5 +47,13 @@ fullsize) # full-size parity tests + the two SelectionGNN bench lines + PMC traf
   for w in cfg1 cfg3; do timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; tail -2 $O/bench_$w.err | cut -c1-300; cut -c1-1800 $O/bench_$w.json; done
   bash tools/gpu_stage.sh pmc $2
   ;;
+stats)   # rocprofv3 --kernel-trace --stats of the bench command, per workload (own runs: no counters here)
+  for w in cfg4 cfg2 cfg5 cfg3; do
+    rm -rf $O/kt_$w; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o bench -- python bench.py --workload $w --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/bench_prof_$w.err
+    f=$(find $O/kt_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_${w}_kernel_stats.csv && head -8 $f | cut -c1-200
+    rm -rf $O/kt_$w
+  done
+  bash tools/pmc_collect.sh cfg5 ev_hop_lds4_kernel r02 > $O/pmc_cfg5.log 2>&1; tail -1 $O/pmc_cfg5.log | cut -c1-600
+  ;;
 *) echo "unknown stage $S"; exit 2;;
 esac

@@ -24,7 +24,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 constexpr unsigned kPad = 0xffffffffu;
-constexpr int kWaves = 8;   // waves per workgroup
+#ifndef KW
+#define KW 8
+#endif
+constexpr int kWaves = KW;   // waves per workgroup
 
 // stream[(wg * kWaves + wave) * L4 + s][lg] : u32x4 = 4 consecutive entries of lane group lg; entry = dest_local << 17 | src
 template <int ACCUM>
@@ -109,19 +112,20 @@ int main(int argc, char** argv) {
     std::vector<float> hx((size_t)N * 32);
     CK(hipMemcpy(hx.data(), X, hx.size() * 4, hipMemcpyDeviceToHost));
 
-    for (int D : {1040, 520}) {
+    for (int D : {520, 260, 130}) {
         const int blocksPerEntry = (N + D - 1) / D;
-        const int wgPerCU = (160 * 1024) / (D * 128);
+        int wgPerCU = (160 * 1024) / (D * 128);
+        if (wgPerCU * kWaves > 32) wgPerCU = 32 / kWaves;
         const int passBlocks = 32 * wgPerCU;            // destination blocks an XCD works on concurrently
-        for (int sorted = 1; sorted >= 0; --sorted) {
-            // build the streams: lane group (wave, lg) of block blk owns rows blk*D + (wave*8 + lg) + 64*t
+        for (int sorted = 1; sorted >= 1; --sorted) {
+            // build the streams: lane group (wave, lg) of block blk owns rows blk*D + (wave*8 + lg) + kWaves*8*t
             int L = 0;
             std::vector<std::vector<unsigned>> lists((size_t)blocksPerEntry * kWaves * 8);
             for (int blk = 0; blk < blocksPerEntry; ++blk)
                 for (int q = 0; q < kWaves * 8; ++q) {
                     auto& li = lists[(size_t)blk * kWaves * 8 + q];
-                    for (int t = 0; q + 64 * t < D; ++t) {
-                        const int dl = q + 64 * t, row = blk * D + dl;
+                    for (int t = 0; q + kWaves * 8 * t < D; ++t) {
+                        const int dl = q + kWaves * 8 * t, row = blk * D + dl;
                         if (row >= N) break;
                         for (int src : nbr[row]) li.push_back(((unsigned)dl << 17) | (unsigned)src);
                     }
