@@ -345,6 +345,69 @@ class NodeVariantGNN(SelectionGNN):
         return self.MLP(y.reshape(batchSize, self.F[-1] * self.N[-1])), y
 
 
+class EdgeVariantGNN(SelectionGNN):
+    """Edge-variant filter stack -- architectures.py:1721-1955 (BASELINE configs[4] as an architecture): ``EVGFL`` = [EdgeVariantGF,
+    sigma, rho] x L and ``MLP``; same constructor and state_dict keys as the reference (dense ``weightEV [F,E,K,G,N,N]`` per layer).
+    Superset: ``sparse=True`` keeps the taps per edge (the only form that exists at N = 5e4).  GSO ingest / ordering are
+    SelectionGNN's."""
+
+    def __init__(self,
+                 # Graph filtering
+                 dimNodeSignals, nShiftTaps, nFilterNodes, bias,
+                 # Nonlinearity
+                 nonlinearity,
+                 # Pooling
+                 nSelectedNodes, poolingFunction, poolingSize,
+                 # MLP in the end
+                 dimLayersMLP,
+                 # Structure
+                 GSO, order=None, sparse=False):
+        nn.Module.__init__(self)
+        assert len(dimNodeSignals) == len(nShiftTaps) + 1           # :1812-1818
+        assert len(nFilterNodes) == len(nShiftTaps)
+        assert len(nSelectedNodes) == len(nShiftTaps)
+        assert len(poolingSize) == len(nShiftTaps)
+        self.L = len(nShiftTaps)
+        self.F = dimNodeSignals
+        self.K = nShiftTaps
+        self.M = nFilterNodes
+        self.bias = bias
+        self.sigma = nonlinearity
+        self.rho = poolingFunction
+        self.alpha = poolingSize
+        self.dimLayersMLP = dimLayersMLP
+        self.coarsening = False
+        self._order_name = order
+        self._install_gso(GSO)
+        self.N = [self._gso.N] + nSelectedNodes
+        evgfl = []
+        for l in range(self.L):                                     # :1873-1886: every layer filters on the full graph (N[0])
+            evgfl.append(gml.EdgeVariantGF(self.F[l], self.F[l + 1], self.K[l], self.M[l], self.N[0], self.E, self.bias, sparse=sparse))
+            evgfl[3 * l].addGSO(self._gso)
+            evgfl.append(self.sigma())
+            evgfl.append(self.rho(self.N[l], self.N[l + 1], self.alpha[l]))
+            evgfl[3 * l + 2].addGSO(self._gso)
+        self.EVGFL = nn.Sequential(*evgfl)
+        fc = []
+        if len(self.dimLayersMLP) > 0:                              # :1890-1907
+            fc.append(nn.Linear(self.N[-1] * self.F[-1], dimLayersMLP[0], bias=self.bias))
+            for l in range(len(dimLayersMLP) - 1):
+                fc.append(self.sigma())
+                fc.append(nn.Linear(dimLayersMLP[l], dimLayersMLP[l + 1], bias=self.bias))
+        self.MLP = nn.Sequential(*fc)
+
+    def changeGSO(self, GSO, nSelectedNodes=[], poolingSize=[]):
+        raise NotImplementedError("the reference's EdgeVariantGNN has no changeGSO (the edge taps are tied to the graph)")
+
+    def splitForward(self, x):
+        assert len(x.shape) == 3                                    # :1918-1922
+        batchSize = x.shape[0]
+        assert x.shape[1] == self.F[0]
+        assert x.shape[2] == self.N[0]
+        y = self.EVGFL(self._reorder(x))                            # :1924-1926
+        return self.MLP(y.reshape(batchSize, self.F[-1] * self.N[-1])), y
+
+
 class GraphRecurrentNN(nn.Module):
     """Graph recurrent network -- architectures.py:4357-4672: HiddenState (z_t = sigma(A(S)x_t + B(S)z_{t-1})), an output
     GraphFilter on every z_t followed by rho, and a per-node readout.  Same constructor, sub-module names

@@ -251,7 +251,28 @@ def jarma_case(name, S, B, G, F, P, K, tMax, bias=True, seed=0):
     print(f"jarma_{name}: y{tuple(y.shape)} tMax={tMax}")
 
 
+def edge_variant_gnn_case(name, S2d, B, seed=0):
+    """archit.EdgeVariantGNN (architectures.py:1721-1955): hybrid edge-variant layers (M < N) + MaxPoolLocal + MLP."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    N = S2d.shape[0]
+    net = archit.EdgeVariantGNN([2, 4, 4], [3, 2], [20, 10], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [3], S2d)
+    x = rng.randn(B, 2, N)
+    xt = torch.tensor(x, requires_grad=True)
+    y, ygnn = net.splitForward(xt)
+    w = rng.randn(*y.shape)
+    (y * torch.tensor(w)).sum().backward()
+    out = dict(x=x, w=w, y=y.detach().numpy(), ygnn=ygnn.detach().numpy(), dx=xt.grad.numpy(), **coo(S2d[None]))
+    for k, v in net.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"evgnn_{name}.npz"), **out)
+    print(f"evgnn_{name}: y{tuple(y.shape)} ygnn{tuple(ygnn.shape)} keys={list(net.state_dict())}")
+
+
 def f3_cases(sbm, asym, asym37):
+    edge_variant_gnn_case("asym37", asym37[0], B=4, seed=11)
     gated_hidden_state_case("sbm100_time", "time", sbm[None], B=3, T=4, F=2, H=8, K=3, seed=5)
     gated_hidden_state_case("sbm100_node", "node", sbm[None], B=2, T=3, F=4, H=8, K=3, seed=6)
     gated_hidden_state_case("asym37_node", "node", asym37, B=2, T=3, F=3, H=4, K=2, seed=7)

@@ -475,6 +475,27 @@ def test_jarma_matches_reference(path):
         assert relerr(b.grad.cpu().numpy(), d["db"]) < GRAD_RTOL
 
 
+def test_edge_variant_gnn_matches_reference():
+    """archit.EdgeVariantGNN (architectures.py:1721-1955, BASELINE configs[4] as an architecture): two hybrid EdgeVariantGF layers
+    (dense reference parameters, gathered on the pattern), ReLU, MaxPoolLocal, MLP -- the reference's state_dict loads, outputs and every
+    gradient agree (off-pattern entries of weightEV get exactly zero gradient on both sides)."""
+    from alegnn_amd.modules.architectures import EdgeVariantGNN
+    d = load(os.path.join(GOLDEN, "evgnn_asym37.npz"))
+    net = EdgeVariantGNN([2, 4, 4], [3, 2], [20, 10], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [3], d["S"][0])
+    sd = {k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")}
+    assert set(sd) == set(net.state_dict())
+    net.load_state_dict(sd)
+    net = net.float().to(DEV)
+    x = cu(d["x"], True)
+    y, ygnn = net.splitForward(x)
+    (y * cu(d["w"])).sum().backward()
+    assert relerr(ygnn.detach().cpu().numpy(), d["ygnn"]) < 2 * FWD_RTOL
+    assert relerr(y.detach().cpu().numpy(), d["y"]) < 5 * FWD_RTOL
+    assert relerr(x.grad.cpu().numpy(), d["dx"]) < GRAD_RTOL
+    for k, p in net.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), d["grad:" + k]) < GRAD_RTOL, k
+
+
 def test_graph_recurrent_nn_matches_reference():
     from alegnn_amd.modules.architectures import GraphRecurrentNN
     d = load(os.path.join(GOLDEN, "grnnarch_sbm100.npz"))

@@ -661,3 +661,16 @@ def test_gso_objects_copy_and_pickle():
     clone = pickle.loads(pickle.dumps(ev))
     assert clone._patterns[0].nnzp == ev._patterns[0].nnzp and clone._patterns[0]._plans == {}
 
+
+def test_edge_variant_gnn_has_the_reference_surface():
+    """Constructor, sub-module names and checkpoint keys of archit.EdgeVariantGNN (architectures.py:1721-1955)."""
+    from alegnn_amd.modules.architectures import EdgeVariantGNN
+    d = load(os.path.join(GOLDEN, "evgnn_asym37.npz"))
+    net = EdgeVariantGNN([2, 4, 4], [3, 2], [20, 10], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [3], d["S"][0])
+    sd = {k[3:]: torch.tensor(v) for k, v in d.items() if k.startswith("sd:")}
+    assert set(sd) == set(net.state_dict())
+    net.double().load_state_dict(sd)
+    assert net.N == [37, 20, 10] and net.EVGFL[0].M == 20 and net.EVGFL[3].M == 10 and net.EVGFL[3].N == 37
+    with pytest.raises(AssertionError):
+        EdgeVariantGNN([2, 4, 4], [3], [20, 10], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [3], d["S"][0])
+
