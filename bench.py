@@ -158,12 +158,21 @@ def main():
     warmup = args.warmup if args.warmup is not None else wl["warmup"]
     w = Workload(args.workload, wl, dev, rank)
     parallel.broadcast_parameters(w.module)
-    bucket = parallel.GradBucket(w.module.parameters())
+    # One flat gradient bucket + ONE all-reduce per step under data parallelism; a single process has nothing to reduce and, like the
+    # trainer (modules/training.py), lets backward write the gradients (no bucket: at config 5 the bucket is the 4.7 GB of per-edge
+    # taps, and zeroing + accumulating into it costs 3.4 ms per step that no single-GPU training step pays).
+    params = [p for p in w.module.parameters() if p.requires_grad]
+    bucket = parallel.GradBucket(params) if distributed else None
 
     def step():
-        bucket.zero_()
+        if bucket is not None:
+            bucket.zero_()
+        else:
+            for p in params:
+                p.grad = None
         w.step_fwd_bwd()
-        bucket.allreduce_mean()
+        if bucket is not None:
+            bucket.allreduce_mean()
 
     def sync_all():
         if distributed:
@@ -200,7 +209,7 @@ def main():
 
     if rank == 0:
         cfg = dict(workload=args.workload, description=wl["desc"], graph=wl["graph"], N=wl["N"], nnz=w.nnz, batch_per_gpu=B,
-                   global_batch=B * world, K=wl["K"], E=1, parallelism=f"batch-dp{world}", grad_bucket_bytes=bucket.nbytes(),
+                   global_batch=B * world, K=wl["K"], E=1, parallelism=f"batch-dp{world}", grad_bucket_bytes=(bucket.nbytes() if bucket is not None else sum(p.numel() * 4 for p in params)),
                    rccl_ranks=(dist.get_world_size() if distributed else 0),
                    devices=[torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())][:world])
         cfg.update({k: wl[k] for k in ("G", "F", "dimF", "sel", "pool", "alpha", "mlp") if k in wl})
@@ -244,9 +253,14 @@ def filter_hop_roofline(L, plans, name, B, N, W, K, nnz, dev):
     if pipe == 2:                                                 # column panels: the K-1 hops of a panel are ONE launch (gf_chain.hip)
         Z = torch.randn(K, B * W // 4, N, 4, device=dev)
         _lib.check(L.gf_time_khop_panel(plans, 1, 0, Z.data_ptr(), B, W, K, 20, st, ctypes.byref(ms)))
-        kern, hops = "spmm_chain_kernel", K - 1
-        note = ("K-1 hops of every panel in one launch, panel resident in LDS: HBM sees 1 read + (K-1) writes of the signal per launch, "
-                "the algorithmic count (a read and a write per hop) is what `achieved` divides by")
+        if L.gf_khop_panel_uses_chain(plans[0], 0, B * W // 4) == 1:
+            kern, hops = "spmm_chain_kernel", K - 1
+            note = ("K-1 hops of every panel in one launch, panel resident in LDS: HBM sees 1 read + (K-1) writes of the signal per launch, "
+                    "the algorithmic count (a read and a write per hop) is what `achieved` divides by")
+        else:                                                     # few panels / small weighted GSO: one launch per hop
+            kern, hops = "spmm_panel_kernel", 1
+            ms.value /= (K - 1)
+            note = "one hop per launch (the K-1 launches of a chain timed together, launch_ms = their mean), gathers from an LDS-resident panel"
     else:                                                         # node-major, gathers through L2
         X0 = torch.randn(B, N, W, device=dev)
         X1 = torch.empty_like(X0)

@@ -37,6 +37,7 @@ _SIGNATURES = {
                                      _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_lsigf_pipeline": (_c.c_int, [_c.POINTER(_vp), _i32, _i32, _i32, _i32]),
     "gf_khop_panel": (_c.c_int, [_c.POINTER(_vp), _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "gf_khop_panel_uses_chain": (_c.c_int, [_vp, _i32, _i32]),
     "gf_time_khop_panel": (_c.c_int, [_c.POINTER(_vp), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _c.POINTER(_c.c_float)]),
     "gf_pack_panels": (_c.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gf_unpack_panels": (_c.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -28,15 +28,25 @@ int pick_pipeline(const gf_plan* const* plans, int E, int G, int F, int K) {  //
     return ok ? 2 : 1;
 }
 
+bool use_chain(const gf_plan* plan, int op, int nPanels) {
+    const gf_csr_dev& mm = plan->mat[op];
+    const bool weighted_small = !(mm.pn_uniform && g_tune.panel_uniform) && mm.cn_np == 2;
+    return gf_chain_available(plan, op) && (g_tune.panel_chain == 2 || (g_tune.panel_chain == 1 && nPanels * 4 > 256 && !weighted_small));
+}
+
 int khop_panel(const gf_plan* const* plans, int E, int op, float* Zp, int B, int W, int K, hipStream_t st) {
     const int64_t tap = (int64_t)B * plans[0]->n * W;
     const int nPanels = B * (W / 4);
     if (K < 2) return GF_OK;
     for (int e = 0; e < E; ++e) {
         float* first = Zp + (int64_t)(1 + e * (K - 1)) * tap;  // taps 1 + e(K-1) ... of this edge feature are consecutive
-        // the K-1 hops of a panel inside LDS (one launch per edge feature) -- unless there are so few panels that most CUs would
-        // idle: the per-hop kernel can put several workgroups on one panel, the chain cannot (its panel lives in one CU's LDS)
-        if (gf_chain_available(plans[e], op) && (g_tune.panel_chain == 2 || (g_tune.panel_chain == 1 && nPanels * 4 > 256))) {
+        // The K-1 hops of a panel inside LDS (one launch per edge feature) -- unless
+        //   * there are so few panels that most CUs would idle: the per-hop kernel can put several workgroups on one panel, the
+        //     chain cannot (its panel lives in one CU's LDS);
+        //   * the GSO is weighted and small (two panels fit the LDS): the value stream is 4x the column stream and the per-hop
+        //     kernel, which shares it between two panels with less bookkeeping, is faster there (N = 1682, config 3: 126 vs 170 us
+        //     per chain of 2048 panels; from N ~ 5000 on the two are equal and the chain needs no start-stagger tuning).
+        if (use_chain(plans[e], op, nPanels)) {
             const int rc = gf_spmm_chain_launch(plans[e], op, Zp, first, nPanels, K - 1, tap, st);
             if (rc != GF_OK) return rc;
             continue;
@@ -69,6 +79,11 @@ extern "C" int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t
     GF_REQUIRE_ARG(plans && E > 0 && plans[0], "gf_lsigf_pipeline: NULL plans");
     GF_REQUIRE_SHAPE(K > 0, "gf_lsigf_pipeline: K = %d", K);
     return pick_pipeline(plans, E, G, F, K);
+}
+
+extern "C" int gf_khop_panel_uses_chain(const gf_plan* plan, int32_t op, int32_t n_panels) {
+    GF_REQUIRE_ARG(plan != nullptr && (op == GF_OP_FWD || op == GF_OP_BWD) && n_panels > 0, "gf_khop_panel_uses_chain: bad argument");
+    return use_chain(plan, op, n_panels) ? 1 : 0;
 }
 
 extern "C" int gf_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, void* stream) {

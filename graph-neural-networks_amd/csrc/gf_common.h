@@ -97,7 +97,8 @@ struct gf_csr_dev {
     // + lane];  cn_gtab[w * 32 + 0] = first word of wave w, [w * 32 + 1 + r] = end of its block r, [w * 32 + 16 + r] = 1 when block r
     // has an odd number of group-rows (the second half of its last word is padding and is not gathered).
     int32_t cn_waves = 0;           // gather waves per workgroup (1, 2, 4, 8, 14; one or two more waves store); 0 = no chain image
-    int32_t cn_sets = 0;            // row sets per wave
+    int32_t cn_sets = 0;            // row sets per wave (<= kChainSets / cn_np)
+    int32_t cn_np = 1;              // panels per workgroup pass: 2 while two panels fit the LDS (N <= 5119), else 1
     uint32_t* cn_rowoff = nullptr;  // [cn_sets][cn_waves * 64]  LDS byte offset (row * 16) of the row of (set, thread); 0xffffffff = none
     int32_t* cn_gtab = nullptr;     // [cn_waves * 32]
     uint4* cn_col8 = nullptr;       // 8 x 16-bit columns per lane and word

@@ -313,17 +313,22 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __
 }
 
 // ---- y: Yt[f][n][b] = bias[f] + sum_{k} sum_{g} V[k][f*G+g][n][b]      (graphML.py:481-487) ----------------------------
+// VEC = 4: 16 bytes per lane and term (N*B % 4 == 0); the sum runs over k then g in the same order either way.
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void ev_sum_kernel(const float* __restrict__ V, const float* __restrict__ bias,
                                                           float* __restrict__ Yt, int G, int K, int64_t NB, int64_t CNB,
                                                           int64_t total) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int64_t NBv = NB / VEC;
     for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
-        const int64_t f = idx / NB, nb = idx - f * NB;
-        float acc = bias ? bias[f] : 0.f;
+        const int64_t f = idx / NBv, nb = (idx - f * NBv) * VEC;
+        vec_t acc = bias ? bias[f] : 0.f;
         for (int k = 0; k < K; ++k) {
             const float* v = V + (int64_t)k * CNB + f * G * NB + nb;
-            for (int g = 0; g < G; ++g) acc += v[(int64_t)g * NB];
+#pragma unroll 8
+            for (int g = 0; g < G; ++g) acc += *reinterpret_cast<const vec_t*>(v + (int64_t)g * NB);
         }
-        Yt[idx] = acc;
+        *reinterpret_cast<vec_t*>(Yt + f * NB + nb) = acc;
     }
 }
 
@@ -715,7 +720,10 @@ extern "C" int gf_evgf_forward(const gf_ev_plan* plan, const float* x, const flo
         if (rc != GF_OK) return rc;
     }
     const int64_t FNB = (int64_t)F * NB;
-    hipLaunchKernelGGL(ev_sum_kernel, dim3(grid_for(FNB)), dim3(kThreads), 0, st, V, bias, Yt, G, K, NB, CNB, FNB);
+    if (NB % 4 == 0)
+        hipLaunchKernelGGL(ev_sum_kernel<4>, dim3(grid_for(FNB / 4)), dim3(kThreads), 0, st, V, bias, Yt, G, K, NB, CNB, FNB / 4);
+    else
+        hipLaunchKernelGGL(ev_sum_kernel<1>, dim3(grid_for(FNB)), dim3(kThreads), 0, st, V, bias, Yt, G, K, NB, CNB, FNB);
     GF_LAUNCH_CHECK("ev_sum_kernel");
     return from_nodebatch(Yt, y, B, F, N, Nin, st);
 }

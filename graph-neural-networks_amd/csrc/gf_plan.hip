@@ -383,12 +383,16 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
 // ---- chain image (gf_chain.hip; layout described at gf_csr_dev::cn_*) --------------------------------------------------
 int upload_chain(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     const int32_t nChunks = (n + 63) / 64;
+    // two panels per pass while both fit the LDS: the accumulators of a hop are sets x panels x 4 registers per lane, so a pair
+    // halves the sets a wave may take (more, shorter-lived waves for the same rows)
+    const int np = (2 * (size_t)(n + 1) * 16 <= 160 * 1024) ? 2 : 1;
+    const int maxSets = kChainSets / np;
     static const int kGatherWaves[5] = {1, 2, 4, 8, 14};  // + the storer wave(s): workgroups of 128 ... 1024 threads
     int W = 14;
     for (int i = 4; i >= 0; --i)
-        if ((nChunks + kGatherWaves[i] - 1) / kGatherWaves[i] <= kChainSets) W = kGatherWaves[i];
+        if ((nChunks + kGatherWaves[i] - 1) / kGatherWaves[i] <= maxSets) W = kGatherWaves[i];
     const int R = (nChunks + W - 1) / W;
-    if (R > kChainSets) return GF_OK;  // cannot happen for n <= kPanelMaxNodes
+    if (R > maxSets) return GF_OK;  // cannot happen for n <= kPanelMaxNodes
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
@@ -432,6 +436,7 @@ int upload_chain(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     if ((rc = upload(ell.val4, &d.cn_val4, bytes))) return rc;   // kept for uniform plans too (knob panel_uniform = 0)
     d.cn_waves = W;
     d.cn_sets = R;
+    d.cn_np = np;
     return GF_OK;
 }
 

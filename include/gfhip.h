@@ -125,6 +125,9 @@ int gf_time_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, fl
  * its K-1 hops inside LDS (gf_chain.hip); W % 4 == 0.  gf_time_khop_panel: the same call `iters` times between two HIP
  * events on `stream`, average milliseconds per call (per K-1 hops of every edge feature). */
 int gf_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, void* stream);
+/* 1 when gf_khop_panel runs the chain kernel (spmm_chain_kernel, one launch per edge feature) for n_panels panels on this plan, 0 when it
+ * runs one spmm_panel_kernel launch per hop (few panels; small weighted GSOs): which kernel a profile of the call shows */
+int gf_khop_panel_uses_chain(const gf_plan* plan, int32_t op, int32_t n_panels);
 int gf_time_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, int32_t iters,
                        void* stream, float* avg_ms);
 /* as gf_contract / gf_grad_taps with Z (and P0) in panel layout */

@@ -858,6 +858,7 @@ def test_spmm_hop_panel_against_scipy(N, P, kind, pipeline_knob):
     (37, 3, 8, 3, "weighted"), (64, 2, 4, 2, "uniform"), (100, 5, 8, 5, "weighted"), (641, 7, 8, 4, "uniform"),
     (1300, 3, 32, 5, "weighted"), (2600, 9, 16, 3, "uniform"), (5200, 40, 8, 3, "weighted"), (5121, 33, 32, 5, "uniform"),
     (10000, 30, 32, 5, "uniform"), (10239, 70, 8, 4, "weighted"), (9000, 1, 4, 6, "weighted"),
+    (1000, 3, 4, 3, "weighted"), (300, 5, 12, 4, "uniform"), (5119, 7, 4, 3, "weighted"),       # two panels per pass, odd panel counts
 ], ids=lambda v: str(v))
 def test_khop_panel_chain_against_scipy(N, B, W, K, kind, pipeline_knob):
     """The K-1 hops of a panel inside LDS (gf_chain.hip) against scipy, tap by tap and for both operators: 1 .. 16 waves per

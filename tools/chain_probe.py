@@ -24,6 +24,8 @@ st = torch.cuda.current_stream().cuda_stream
 print(f"N={N} panels={P}")
 for deg in [float(d) for d in os.environ.get('PROBE_DEGS', '0,2.5,5,10,20').split(',')]:
     A = graphgen.sbm(N, avg_degree=deg, seed=0) if deg > 0 else sp.csr_matrix((N, N), dtype=np.float32)
+    if os.environ.get('PROBE_WEIGHTED') == '1' and A.nnz:
+        A = A.copy(); A.data = A.data * np.random.RandomState(1).uniform(0.5, 1.5, A.nnz)
     gso = SparseGSO([A])
     plans = gso.plans(dev)
     row = [f"deg {deg:4.1f} nnz {A.nnz:7d}"]
