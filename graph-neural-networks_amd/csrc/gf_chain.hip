@@ -17,7 +17,7 @@
 //     (160 KB per hop for a full-LDS panel) run under the gathers instead of between them.  One wave moves ~20 GB/s of stores
 //     whatever the rest of the chip does (tools/hbm_ceiling.hip), so a full-LDS workgroup has two.  History (profiles/r02_a_chain):
 //     every wave storing its share after the rewrite 250 us per hop at config 2 (the per-hop kernel: 150 us); one storer 131 us
-//     (it needs 10.3 us per hop, the gatherers 6.7 us); two storers 127 us.
+//     (it needs 10.3 us per hop, the gatherers 6.7 us); two storers 122-127 us (raising their priority with s_setprio: no change).
 //   * NP = 2 panels side by side in LDS when two fit (N <= 5119): one entry word drives two gathers, the (column, value) stream --
 //     which, for graphs this small, is several times the panel itself -- is read once per pair.
 //   * per hop two workgroup barriers (gathers done | panel rewritten), LDS-only: global stores stay in flight across them.
