@@ -140,8 +140,6 @@ struct gf_tuning {
     int panel_order = 1;        // 1 = bank-aware neighbour order at plan creation (set BEFORE gf_plan_create)
     int panel_chain = 1;        // the K-1 hops of a panel inside LDS (gf_chain.hip): 1 = when there are enough panels to fill the CUs,
                                 // 2 = always, 0 = never (one launch per hop, gf_panel.hip)
-    int panel_stagger = 20;     // start delay between workgroup phases: low 4 bits = ~0.5 us quanta per phase step, bits 4+ = log2(phases) - 2
-                                // (20 = 8 phases x 2 us, the measured optimum at N = 1e4); 0 = start together
     int panel_rotate = 1;       // 1 = each workgroup walks the slice list from its own starting offset
     int panel_grid = 0;         // experiments: cap on the panel kernel's grid (0 = one workgroup per LDS-full)
     int bwd_fuse = 1;           // panel pipeline backward: 1 = dx and dh from the adjoint stack in one kernel (G, F <= 32), 0 = separate

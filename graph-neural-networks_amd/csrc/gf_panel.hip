@@ -13,8 +13,10 @@
 //
 // Kernel (persistent; 16 / 8 / 4 waves per workgroup by N, as many workgroups per CU as LDS allows):
 //   * per panel: every wave loads its share of the panel into LDS (HBM-bound phase), barrier, every wave computes its slices
-//     (LDS / issue-bound phase), barrier.  Workgroups start staggered so that the phases of different CUs interleave and
-//     HBM stays busy (measured at N = 1e4: 224 us in lock step = 53 load + 138 compute + 33 lost, 189 us staggered).
+//     (LDS / issue-bound phase), barrier.  (Round 1 started the workgroups of a full-LDS launch staggered by a timing-tuned
+//     s_sleep ladder so that the phases of different CUs interleave: 224 -> 189 us at N = 1e4.  Full-LDS panels now run in the
+//     chain kernel, gf_chain.hip, which needs no such constant; this kernel serves launches with several workgroups per CU,
+//     whose phases interleave by themselves, and launches with few panels.)
 //     (A variant with dedicated loader waves prefetching the next panel into registers overlapped perfectly but left only
 //     2 compute waves per SIMD: 255 us.  A wave's vector-memory results return in issue order, so a computing wave cannot
 //     keep HBM loads in flight without stalling its own L2-latency entry loads behind them.)
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
                                                           const void* __restrict__ cols, const float4* __restrict__ vals,
                                                           float uval, const float* __restrict__ Xin, float* __restrict__ Xout,
                                                           int N, int nSlices, int nPanels, int sentinel, int store_mode,
-                                                          int stagger, int ush, int rotate, int split) {
+                                                          int ush, int rotate, int split) {
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [N + 1]: the panel + one zero slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,21 +73,6 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     const unsigned regionB = (unsigned)(N + 1) * 16u;
     if (tid < NP) lds4[tid * (N + 1) + N] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the zero slots empty ELL slots gather from
     const int rot = rotate ? (int)(((blockIdx.x / (unsigned)split) * 41u) % (unsigned)nSlices) : 0;  // the same for the workgroups sharing a pass
-    {
-        // De-synchronise the workgroups once (see the header comment).
-        // stagger = 16 * (log2 of the number of phases - 2) + sleep quanta of 16 * 64 cycles (~0.5 us) per phase step
-        if (stagger >= 64) {  // pseudo-random start delay in [0, (stagger - 64) * 0.5 us)
-            unsigned hsh = (blockIdx.x >> 3) * 2654435761u;
-            hsh ^= hsh >> 15;
-            const int q = (int)((hsh & 1023u) * (unsigned)(stagger - 64) >> 10);
-            for (int i = 0; i < q; ++i) __builtin_amdgcn_s_sleep(16);
-        } else {
-            const int nph = 4 << (stagger >> 4);
-            const int phase = (int)((blockIdx.x >> 3) & (nph - 1));  // workgroups b, b+8, ... share an XCD: spread within each XCD
-            for (int i = 0; i < phase * (stagger & 15); ++i) __builtin_amdgcn_s_sleep(16);
-        }
-    }
-
     // request group-rows [g0, g0 + kGC) of an ELL block (g0 = absolute group-row index)
     auto load_chunk = [&](colw (&cc)[kGC], f32x4 (&vv)[kGC], int g0) {
 #pragma unroll
@@ -342,15 +329,13 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
         grid = (int64_t)nGroups * split;
     }
     if (g_tune.panel_grid > 0 && grid > g_tune.panel_grid) grid = g_tune.panel_grid / split * split;  // experiments: fewer workgroups than CUs
-    const bool multipass = nGroups * split > grid;  // staggered starts only pay when a workgroup walks several passes
     typedef void (*kern_t)(const int2*, const int32_t*, const void*, const float4*, float, const float*, float*, int, int, int, int, int,
-                           int, int, int, int);
+                           int, int, int);
     kern_t kern = np == 2 ? (uniform ? (kern_t)spmm_panel_kernel<1, 2> : (kern_t)spmm_panel_kernel<0, 2>)
                           : (uniform ? (kern_t)spmm_panel_kernel<1, 1> : (kern_t)spmm_panel_kernel<0, 1>);
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
-                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, (wgPerCU > 1 || !multipass) ? 0 : g_tune.panel_stagger,
-                       m.pn_ushift, g_tune.panel_rotate, split);
+                       Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, m.pn_ushift, g_tune.panel_rotate, split);
     GF_LAUNCH_CHECK("spmm_panel_kernel");
     return GF_OK;
 }

@@ -78,7 +78,6 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "bwd_fuse")) g_tune.bwd_fuse = value;
     else if (!strcmp(key, "panel_grid")) g_tune.panel_grid = value;
     else if (!strcmp(key, "panel_rotate")) g_tune.panel_rotate = value;
-    else if (!strcmp(key, "panel_stagger")) g_tune.panel_stagger = value;
     else if (!strcmp(key, "panel_chain")) g_tune.panel_chain = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);

@@ -209,7 +209,7 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * "spmm_pf" (workgroups per tile prefetching the next gather panel, -1 = heuristic, 0 = off), "spmm_ucap" (0 | 8 | 16 gathers in flight per lane), "spmm_load" (0 = plain | 1 = non-temporal gather loads),
  * "spmm_store" (0 = plain | 1 = write-through sc1 | 2 = non-temporal output stores), "contract_generic" (0/1),
  * "pipeline" (0 = auto | 1 = node-major | 2 = column panels), "panel_uniform" (0/1 use the value-free stream),
- * "panel_order" (0/1 bank-aware neighbour order; read by gf_plan_create), "panel_sort" (0/1 octets sorted by longest row; read by gf_plan_create), "panel_stagger" (start delay step between workgroup phases, ~2 us units),
+ * "panel_order" (0/1 bank-aware neighbour order; read by gf_plan_create), "panel_sort" (0/1 octets sorted by longest row; read by gf_plan_create),
  * "panel_rotate" (0/1 per-workgroup rotated slice walk), "panel_np" (0 = heuristic | 1 | 2 panels per pass), "panel_split" (workgroups per pass
  * for small batches: 0 = as many as fit, 1 = off), "panel_chain" (0/1 the K-1 hops of a panel inside LDS, gf_chain.hip), "gradw_lds" (0/1),
  * "bwd_fuse" (0/1 dx and dh of the panel pipeline in one pass over the adjoint stack when G, F <= 32).
