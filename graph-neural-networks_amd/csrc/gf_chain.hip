@@ -25,7 +25,9 @@
 //     (a wave overwrites only what it has just read back).
 // What bounds it at config 2: HBM writes.  A chain moves 1 read + 4 writes of 328 MB; the chip sustains ~4.9 TB/s of writes
 // (tools/hbm_ceiling.hip), i.e. ~290 us for the 1.64 GB against 480-510 us measured: the CUs store ~60 % of the time (nothing to
-// store during hop 0 and the panel load; the LDS is full, so the next panel cannot be fetched early).
+// store during hop 0 and the panel load; the LDS is full, so the next panel cannot be fetched early).  Inside a hop the slowest of the
+// 14 gather waves finishes ~40 % after the fastest: two SIMDs carry 4 gather waves, two carry 3 + a storer, and a SIMD's issue
+// slots go to its oldest wave first (per-wave trace; static s_setprio by wave age only inverts the order, the spread stays).
 // Determinism: each row's sum runs in the plan's fixed neighbour order in one lane; no atomics.
 #include "gf_common.h"
 
