@@ -48,7 +48,7 @@ WORKLOADS = {
     "cfg2": dict(kind="filter", graph="sbm", N=10_000, deg=10.0, B=256, G=32, F=32, K=5, steps=250, warmup=20, cpu_sample=64,
                  desc="SBM N=10k nnz~100k, batch 256/GPU, K=5, F 32->32 (BASELINE configs[1])"),
     "cfg1": dict(kind="selgnn", graph="sbm", N=100, deg=30.0, B=100, dimF=[1, 32, 32], K=[5, 5], sel=[10, 10], pool="MaxPoolLocal",
-                 alpha=[6, 8], mlp=[5], steps=1500, warmup=50, cpu_sample=100,
+                 alpha=[6, 8], mlp=[5], steps=1500, warmup=50, cpu_sample=100, hip_graph=True,
                  desc="sourceLocGNN SelectionGNN: SBM N=100, F=[1,32,32], K=[5,5], MaxPoolLocal [10,10] alpha [6,8], MLP [5], batch 100/GPU (BASELINE configs[0])"),
     "cfg3": dict(kind="selgnn", graph="knn", N=1682, deg=10.0, B=256, dimF=[1, 64, 32], K=[5, 5], sel=[1682, 1682], pool="NoPool",
                  alpha=[1, 1], mlp=[1], steps=400, warmup=20, cpu_sample=64,
@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None, help="batch entries of the workload timed on the CPU")
     ap.add_argument("--detail", action="store_true", help="per-building-block timings to stderr (filter workloads)")
+    ap.add_argument("--no-graph", action="store_true", help="launch-bound workloads (cfg1): eager launches instead of one HIP-graph replay per step")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="gf_tune knob (needs GFHIP_EXPERIMENTS=1; repeatable)")
     args = ap.parse_args()
 
@@ -182,6 +183,25 @@ def main():
     for _ in range(warmup):
         step()
     sync_all()
+    # A step of ~60 launches of a few microseconds each is bound by the host's launch rate: such workloads (config 1) replay the
+    # step as ONE HIP graph -- the library only launches on the stream it is handed, allocates nothing and never synchronises, so
+    # torch.cuda.graph captures it as is.  Single process only (the captured step has no collective).
+    use_graph = bool(wl.get("hip_graph")) and not distributed and not args.no_graph
+    eager_step = step
+    if use_graph:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eager_step()
+        step = graph.replay
+        for _ in range(warmup):
+            step()
+        sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -210,7 +230,7 @@ def main():
     if rank == 0:
         cfg = dict(workload=args.workload, description=wl["desc"], graph=wl["graph"], N=wl["N"], nnz=w.nnz, batch_per_gpu=B,
                    global_batch=B * world, K=wl["K"], E=1, parallelism=f"batch-dp{world}", grad_bucket_bytes=(bucket.nbytes() if bucket is not None else sum(p.numel() * 4 for p in params)),
-                   rccl_ranks=(dist.get_world_size() if distributed else 0),
+                   rccl_ranks=(dist.get_world_size() if distributed else 0), hip_graph=use_graph,
                    devices=[torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())][:world])
         cfg.update({k: wl[k] for k in ("G", "F", "dimF", "sel", "pool", "alpha", "mlp") if k in wl})
         out = dict(metric="edges*taps/sec (GraphFilter fwd+bwd)", value=value, unit="edges*taps/s", n_gpus=world, steps=steps,

@@ -52,8 +52,11 @@ __device__ unsigned long long* g_chain_trace = nullptr;
 #endif
 constexpr int kWaitVm0 = 0x0F70;  // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields at their maxima) in the gfx9 encoding
 
+#ifndef GF_CHAIN_MAXT
+#define GF_CHAIN_MAXT 1024
+#endif
 template <int UNIFORM, int NP>
-__global__ __launch_bounds__(1024) void spmm_chain_kernel(const int32_t* __restrict__ gtab, const uint32_t* __restrict__ rowoff,
+__global__ __launch_bounds__(GF_CHAIN_MAXT) void spmm_chain_kernel(const int32_t* __restrict__ gtab, const uint32_t* __restrict__ rowoff,
                                                           const void* __restrict__ cols, const float4* __restrict__ vals, float uval,
                                                           const float* __restrict__ Xin, float* __restrict__ Xout, int N, int nPanels,
                                                           int R, int nHops, int64_t tapStride, int store_mode, int nStorers) {
