@@ -185,7 +185,8 @@ __global__ __launch_bounds__(GF_CHAIN_MAXT) void spmm_chain_kernel(const int32_t
                     vA[0] = val4[(int64_t)(2 * u) * 64], vA[1] = val4[(int64_t)(2 * u + 1) * 64];
                     vB[0] = val4[(int64_t)(2 * u + 2) * 64], vB[1] = val4[(int64_t)(2 * u + 3) * 64];
                 }
-                f32x4 a0[NP], a1[NP];
+                f32x4 a0[NP];   // one running sum per panel (a second, interleaved one costs 4 registers per panel the kernel does not have:
+                                // 131 VGPRs against the 128 of a 1024-thread workgroup; the phase is LDS-bound, not add-latency-bound)
                 auto gather4 = [&](unsigned lo, unsigned hi, const f32x4& w) {
                     const unsigned o0 = (lo & 0xffffu) << 4, o1 = (lo >> 16) << 4, o2 = (hi & 0xffffu) << 4, o3 = (hi >> 16) << 4;
 #pragma unroll
@@ -197,14 +198,14 @@ __global__ __launch_bounds__(GF_CHAIN_MAXT) void spmm_chain_kernel(const int32_t
                         const f32x4 x3 = *reinterpret_cast<lds_f32x4*>(o3 + rb);
                         if (UNIFORM) {
                             a0[k] += x0;
-                            a1[k] += x1;
+                            a0[k] += x1;
                             a0[k] += x2;
-                            a1[k] += x3;
+                            a0[k] += x3;
                         } else {
                             a0[k] += w.x * x0;
-                            a1[k] += w.y * x1;
+                            a0[k] += w.y * x1;
                             a0[k] += w.z * x2;
-                            a1[k] += w.w * x3;
+                            a0[k] += w.w * x3;
                         }
                     }
                 };
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(GF_CHAIN_MAXT) void spmm_chain_kernel(const int32_t
                 };
                 auto block = [&](int ue, int odd, f32x4 (&out)[NP]) {  // words [u, ue) of the stream, ue > u; odd: the last word is half empty
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) a0[k] = a1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int k = 0; k < NP; ++k) a0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (par == 0) {
                         for (;;) {
                             step(cA, vA, !(odd && u + 1 == ue));
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(GF_CHAIN_MAXT) void spmm_chain_kernel(const int32_t
                         }
                     }
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) out[k] = a0[k] + a1[k];
+                    for (int k = 0; k < NP; ++k) out[k] = a0[k];
                 };
 #pragma unroll
                 for (int r = 0; r < kSets; ++r) {
