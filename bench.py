@@ -43,7 +43,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
 WORKLOADS = {
-    "cfg4": dict(kind="filter", graph="er", N=100_000, deg=10.0, B=128, G=32, F=32, K=5, steps=25, warmup=5, cpu_sample=8,
+    "cfg4": dict(kind="filter", graph="er", N=100_000, deg=10.0, B=128, G=32, F=32, K=5, steps=100, warmup=5, cpu_sample=6,
                  desc="ER N=100k nnz~1M, batch 128/GPU (1024 over 8 GPUs), K=5, F 32->32 (BASELINE configs[3], the north-star size)"),
     "cfg2": dict(kind="filter", graph="sbm", N=10_000, deg=10.0, B=256, G=32, F=32, K=5, steps=250, warmup=20, cpu_sample=64,
                  desc="SBM N=10k nnz~100k, batch 256/GPU, K=5, F 32->32 (BASELINE configs[1])"),
