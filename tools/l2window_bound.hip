@@ -80,6 +80,79 @@ __global__ __launch_bounds__(kWaves * 64) void window_kernel(const u32x4* __rest
     }
 }
 
+// Persistent variant with an XCD-local barrier at the start of every pass (and at nSync - 1 evenly spaced points inside it): the
+// workgroups of an XCD (blockIdx % 8) walk the passes of that XCD together, so that their sweeps over the source rows stay aligned
+// and the rows in flight really are one sliding window.  grid = 8 * passBlocks workgroups, all resident.
+template <int ACCUM>
+__global__ __launch_bounds__(kWaves * 64) void window_sync_kernel(const u32x4* __restrict__ stream, const float* __restrict__ X,
+                                                                  float* __restrict__ Y, int N, int D, int L4, int blocksPerEntry,
+                                                                  int passBlocks, float uval, int entriesPerXcd, int nSync,
+                                                                  unsigned* __restrict__ counters, unsigned epoch0) {
+    extern __shared__ __attribute__((aligned(16))) float4 accs[];
+    f32x4* acc4 = reinterpret_cast<f32x4*>(accs);
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane & 7, lg = lane >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;      // cu: 0 .. passBlocks-1
+    const int passesPerEntry = (blocksPerEntry + passBlocks - 1) / passBlocks;
+    unsigned* ctr = counters + xcd * 32;                       // one counter per XCD, 128 bytes apart
+    unsigned arrived = epoch0;
+    auto xcd_barrier = [&]() {
+        __syncthreads();
+        arrived += (unsigned)passBlocks;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int guard = 0;
+            while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrived) < 0 && ++guard < (1 << 22))
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    };
+    for (int pass = 0; pass < entriesPerXcd * passesPerEntry; ++pass) {
+        const int b = (pass / passesPerEntry) * 8 + xcd;
+        const int blk = (pass % passesPerEntry) * passBlocks + cu;
+        const bool live = blk < blocksPerEntry;
+        const float* Xb = X + (int64_t)b * N * 32 + sub * 4;
+        for (int i = tid; i < D * 8; i += kWaves * 64) acc4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const u32x4* st = stream + ((int64_t)((live ? blk : 0) * kWaves + wave) * L4) * 8 + lg;
+        for (int seg = 0; seg < nSync; ++seg) {
+            xcd_barrier();
+            if (!live) continue;
+            const int s0 = (int)((int64_t)L4 * seg / nSync), s1 = (int)((int64_t)L4 * (seg + 1) / nSync);
+            u32x4 e = st[(int64_t)s0 * 8];
+            for (int s = s0; s < s1; ++s) {
+                const u32x4 en = st[(int64_t)(s + 1 < L4 ? s + 1 : s) * 8];
+                f32x4 x[4];
+                const unsigned ee[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ee[u] != kPad) x[u] = *reinterpret_cast<const f32x4*>(Xb + (int64_t)(ee[u] & 0x1ffffu) * 32);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ee[u] != kPad) {
+                        if (ACCUM) {
+                            const int d = (int)(ee[u] >> 17) * 8 + sub;
+                            acc4[d] += x[u];
+                        } else if (x[u].x == 1.2345e30f) {
+                            acc4[sub] = x[u];
+                        }
+                    }
+                e = en;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            float* Yb = Y + (int64_t)b * N * 32 + (int64_t)blk * D * 32;
+            const int rows = min(D, N - blk * D);
+            for (int i = tid; i < rows * 8; i += kWaves * 64) {
+                f32x4 v = acc4[i];
+                v *= uval;
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Yb) + i);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 int main(int argc, char** argv) {
     const int N = 100000, B = argc > 1 ? atoi(argv[1]) : 128;
     const int64_t nnzTarget = 1000000;
@@ -112,12 +185,12 @@ int main(int argc, char** argv) {
     std::vector<float> hx((size_t)N * 32);
     CK(hipMemcpy(hx.data(), X, hx.size() * 4, hipMemcpyDeviceToHost));
 
-    for (int D : {520, 260, 130}) {
+    for (int D : {520, 1040}) {
         const int blocksPerEntry = (N + D - 1) / D;
         int wgPerCU = (160 * 1024) / (D * 128);
         if (wgPerCU * kWaves > 32) wgPerCU = 32 / kWaves;
         const int passBlocks = 32 * wgPerCU;            // destination blocks an XCD works on concurrently
-        for (int sorted = 1; sorted >= 1; --sorted) {
+        for (int sorted = 1; sorted >= (getenv("L2W_SHUFFLED") ? 0 : 1); --sorted) {
             // build the streams: lane group (wave, lg) of block blk owns rows blk*D + (wave*8 + lg) + kWaves*8*t
             int L = 0;
             std::vector<std::vector<unsigned>> lists((size_t)blocksPerEntry * kWaves * 8);
@@ -187,6 +260,49 @@ int main(int argc, char** argv) {
                 printf("D=%4d (%d WG/CU, %d passes/entry) %-8s %-11s L=%3d fill=%.2f  %8.3f ms/hop  %6.0f GB/s algorithmic = %4.1f %% of 8 TB/s  gathered %5.1f TB/s  maxerr=%.2e\n",
                        D, wgPerCU, passesPerEntry, sorted ? "sorted" : "shuffled", accum ? "gather+acc" : "gather-only", L, (double)nnz / slots, ms,
                        bytes / ms / 1e6, bytes / ms / 1e6 / 80.0, (double)nnz * B * 128.0 / ms / 1e9, err);
+            }
+            if (sorted && B % 8 == 0) {
+                unsigned* ctrs;
+                CK(hipMalloc(&ctrs, 8 * 32 * 4));
+                CK(hipMemset(ctrs, 0, 8 * 32 * 4));
+                unsigned epoch = 0;
+                const int nSegTotalPerLaunch = entriesPerXcd * passesPerEntry;
+                for (int nSync : {1, 2, 4}) {
+                    auto kern = window_sync_kernel<1>;
+                    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    hipEvent_t e0, e1;
+                    CK(hipEventCreate(&e0));
+                    CK(hipEventCreate(&e1));
+                    CK(hipMemset(Y, 0xff, (size_t)B * N * 32 * 4));
+                    auto launch = [&]() {
+                        hipLaunchKernelGGL(kern, dim3(8 * passBlocks), dim3(kWaves * 64), lds, 0, (const u32x4*)dst, X, Y, N, D, L4, blocksPerEntry,
+                                           passBlocks, uval, entriesPerXcd, nSync, ctrs, epoch);
+                        epoch += (unsigned)passBlocks * (unsigned)nSegTotalPerLaunch * (unsigned)nSync;
+                    };
+                    launch();
+                    CK(hipDeviceSynchronize());
+                    const int iters = 5;
+                    CK(hipEventRecord(e0));
+                    for (int it = 0; it < iters; ++it) launch();
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    ms /= iters;
+                    std::vector<float> hy((size_t)N * 32);
+                    CK(hipMemcpy(hy.data(), Y + (size_t)(B - 1) * N * 32, hy.size() * 4, hipMemcpyDeviceToHost));
+                    double err = 0.0;
+                    for (int row = 0; row < N; row += 97)
+                        for (int c = 0; c < 32; ++c) {
+                            double sacc = 0.0;
+                            for (int src : nbr[row]) sacc += hx[(size_t)src * 32 + c];
+                            err = std::max(err, std::fabs(sacc * uval - hy[(size_t)row * 32 + c]));
+                        }
+                    const double bytes = 2.0 * B * N * 32 * 4 + nnz * 8.0 + (N + 1) * 4.0;
+                    printf("D=%4d persistent, XCD barrier x%d per pass (%d passes per XCD)  %8.3f ms/hop  %6.0f GB/s algorithmic = %4.1f %% of 8 TB/s  maxerr=%.2e\n",
+                           D, nSync, nSegTotalPerLaunch, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 80.0, err);
+                }
+                CK(hipFree(ctrs));
             }
             CK(hipFree(dst));
         }
