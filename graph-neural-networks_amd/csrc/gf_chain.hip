@@ -27,7 +27,8 @@
 // (tools/hbm_ceiling.hip), i.e. ~290 us for the 1.64 GB against 480-510 us measured: the CUs store ~60 % of the time (nothing to
 // store during hop 0 and the panel load; the LDS is full, so the next panel cannot be fetched early).  Inside a hop the slowest of the
 // 14 gather waves finishes ~40 % after the fastest: two SIMDs carry 4 gather waves, two carry 3 + a storer, and a SIMD's issue
-// slots go to its oldest wave first (per-wave trace; static s_setprio by wave age only inverts the order, the spread stays).
+// slots go to its oldest wave first (per-wave trace; static s_setprio by wave age only inverts the order, the spread stays; the
+// balanced split -- 12 gather waves + 4 storers, one per SIMD, 14 sets per lane -- is slower: 490 vs 475 us per launch).
 // Determinism: each row's sum runs in the plan's fixed neighbour order in one lane; no atomics.
 #include "gf_common.h"
 
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(GF_CHAIN_MAXT) void spmm_chain_kernel(const int32_t
                                                           const void* __restrict__ cols, const float4* __restrict__ vals, float uval,
                                                           const float* __restrict__ Xin, float* __restrict__ Xout, int N, int nPanels,
                                                           int R, int nHops, int64_t tapStride, int store_mode, int nStorers) {
-    constexpr int kSets = kChainSets / NP;          // row sets per lane: the accumulators of a hop are kSets x NP x 4 registers
+    constexpr int kSets = (kChainSets / NP) & ~1;   // row sets per lane: the accumulators of a hop are kSets x NP x 4 registers
     extern __shared__ __attribute__((aligned(16))) float4 panel[];  // NP regions of [N + 1]: a panel + one zero slot each
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -333,7 +334,7 @@ int gf_spmm_chain_launch(const gf_plan* plan, int op, const float* Xin, float* X
     const size_t lds = (size_t)np * (N + 1) * 16;
     // gatherers + storers: one wave moves ~20 GB/s of stores whatever the rest of the chip does (tools/hbm_ceiling.hip), two cover the
     // 160 KB per hop of a full-LDS workgroup within the gather time
-    const int storers = m.cn_waves >= 14 ? 2 : 1;
+    const int storers = m.cn_waves >= kChainBigW ? kChainStorers : 1;
     const int waves = m.cn_waves + storers;
     const int thr = waves * 64;
     int wgPerCU = (int)((160 * 1024) / (lds < 1024 ? 1024 : lds));

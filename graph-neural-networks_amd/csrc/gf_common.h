@@ -106,7 +106,13 @@ struct gf_csr_dev {
     double cn_fill = 1.0;
     double cn_conflict = 0.0;
 };
-constexpr int kChainSets = 12;      // 14 gather waves x 12 sets x 64 rows = 10752 >= kPanelMaxNodes (waves 15 and 16 store)
+#ifndef GF_CHAIN_SETS   // experiments (make variant): sets per lane / gather waves and storer waves of a full-LDS workgroup
+#define GF_CHAIN_SETS 12
+#define GF_CHAIN_BIGW 14
+#define GF_CHAIN_STORERS 2
+#endif
+constexpr int kChainSets = GF_CHAIN_SETS;      // 14 gather waves x 12 sets x 64 rows = 10752 >= kPanelMaxNodes (waves 15 and 16 store)
+constexpr int kChainBigW = GF_CHAIN_BIGW, kChainStorers = GF_CHAIN_STORERS;
 constexpr int32_t kPanelMaxNodes = 10239;   // 16 bytes per node + one zero slot in 160 KiB of LDS
 constexpr int32_t kPanelMaxDeg = 65535;
 

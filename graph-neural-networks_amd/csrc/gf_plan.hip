@@ -385,9 +385,9 @@ int upload_chain(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes) {
     // two panels per pass while both fit the LDS: the accumulators of a hop are sets x panels x 4 registers per lane, so a pair
     // halves the sets a wave may take (more, shorter-lived waves for the same rows)
     const int np = (2 * (size_t)(n + 1) * 16 <= 160 * 1024) ? 2 : 1;
-    const int maxSets = kChainSets / np;
-    static const int kGatherWaves[5] = {1, 2, 4, 8, 14};  // + the storer wave(s): workgroups of 128 ... 1024 threads
-    int W = 14;
+    const int maxSets = (kChainSets / np) & ~1;
+    static const int kGatherWaves[5] = {1, 2, 4, 8, kChainBigW};  // + the storer wave(s): workgroups of 128 ... 1024 threads
+    int W = kChainBigW;
     for (int i = 4; i >= 0; --i)
         if ((nChunks + kGatherWaves[i] - 1) / kGatherWaves[i] <= maxSets) W = kGatherWaves[i];
     const int R = (nChunks + W - 1) / W;
