@@ -183,6 +183,15 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
     int rc = y_relu ? gf_layout_masked_launch(dy, y_relu, P, B, F, Nin, N, gf_stream(stream))
                     : gf_layout_bgn_to_bng(dy, P, B, F, Nin, N, stream);  // P[0] = dy, node-major, rows >= Nin zero
     if (rc != GF_OK) return rc;
+    if (dx && dh && g_tune.bwd_fuse && gf_bwd_fused_supported(G, F, E, K)) {
+        // one pass over the adjoint stack for dx and dh (dh_t = X0^T P_t), as in the panel pipeline: the separate tap-gradient kernel
+        // re-reads the whole forward stack (8.2 GB at config 4)
+        GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
+        rc = gf_khop(plans, E, GF_OP_BWD, P, B, F, K, stream);
+        if (rc != GF_OK) return rc;
+        return gf_bwd_fused_panel_launch(P, Z, h, dx, dh, dbias, workspace, workspace_bytes, B, N, Nin, G, F, E, K, gf_stream(stream),
+                                         /*node_major=*/1);
+    }
     if (dh || dbias) {
         GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
         rc = gf_grad_taps(Z, P, dh, dbias, workspace, workspace_bytes, B, N, G, F, E, K, stream);

@@ -163,7 +163,7 @@ int gf_contract_launch(const float* Z, const float* h, const float* bias, float*
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)
 bool gf_bwd_fused_supported(int G, int F, int E, int K);
 int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
-                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st);
+                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st, int node_major = 0);
 bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F, int K);
 bool gf_contract_panel_fits(int Cin, int Cout, int T);
 bool gf_chain_available(const gf_plan* plan, int op);

@@ -372,7 +372,10 @@ void launch_stage1_panel(const Geo& g, const float* Zp, const float* P0p, float*
 // drops the tile into a wave-private LDS buffer [row][f] and reads it back with lane = f for the reduction MFMAs against the X0
 // tile staged the same way.  HBM: the P stack + X0 once, dx once -- the separate tap-gradient kernel re-read the whole
 // forward stack Z (T*R*G*4 bytes).  G, F <= 32 (one 32x32 accumulator tile per tap), T <= 6 (the dispatcher's limit).
-template <int T, int GIN8, int FIN8>
+// NM = 1: the same pass over NODE-MAJOR stacks P[T][B][N][F], X0[B][N][G] (the pipeline of graphs beyond the LDS panel limit): a lane
+// still holds 4 consecutive f (g) of its row -- its four 16-byte loads per tap then come from one 128-byte row instead of four
+// panels, 32 bytes contiguous per pair of lanes; everything after the loads is identical.
+template <int T, int GIN8, int FIN8, int NM>
 __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* __restrict__ Pp, const float* __restrict__ X0p,
                                                                    const float* __restrict__ h, float* __restrict__ dx,
                                                                    float* __restrict__ partial, float* __restrict__ partial_b, int R,
@@ -402,7 +405,9 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
     const int wg = blockIdx.x * kWaves + wave;
     const int r_begin = wg * rowsPerWave, r_end = min(R, r_begin + rowsPerWave);
     const int64_t N4 = (int64_t)N * 4;
-    const int64_t tapStride = (int64_t)B * QF * N4;
+    const int64_t tapStride = (int64_t)B * QF * N4;     // floats per tap (either layout: B * N * F)
+    const int64_t pstep = NM ? 8 : 2 * N4;              // from one 8-column group of a row to the next: +8 floats | +2 panels
+    const int64_t xstep = NM ? 8 : 2 * N4;
     float* xs = s_t[wave][0];
     float* ps = s_t[wave][1];
 
@@ -418,15 +423,16 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
         const bool rv = r < r_end;
         const int b = rv ? r / N : 0;
         const int n = rv ? r - b * N : 0;
-        const float* pb = Pp + ((int64_t)b * QF + half) * N4 + (int64_t)n * 4;   // + (2u) panels, + t taps
+        const float* pb = NM ? Pp + (int64_t)r * F + 4 * half                     // + 8u floats, + t taps
+                             : Pp + ((int64_t)b * QF + half) * N4 + (int64_t)n * 4;   // + (2u) panels, + t taps
+        const float* xb = NM ? X0p + (int64_t)r * G + 4 * half : X0p + ((int64_t)b * QG + half) * N4 + (int64_t)n * 4;
         float4 x0[GIN8], cur[FIN8], nxt[FIN8];
 #pragma unroll
         for (int u = 0; u < GIN8; ++u)
-            x0[u] = rv ? *reinterpret_cast<const float4*>(X0p + ((int64_t)b * QG + 2 * u + half) * N4 + (int64_t)n * 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            x0[u] = rv ? *reinterpret_cast<const float4*>(xb + (int64_t)u * xstep) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < FIN8; ++u)
-            cur[u] = rv ? *reinterpret_cast<const float4*>(pb + (int64_t)(2 * u) * N4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            cur[u] = rv ? *reinterpret_cast<const float4*>(pb + (int64_t)u * pstep) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < GIN8; ++u) *reinterpret_cast<float4*>(xs + l31 * TS + 8 * u + 4 * half) = x0[u];
 
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
             if (t + 1 < T) {
 #pragma unroll
                 for (int u = 0; u < FIN8; ++u)
-                    nxt[u] = rv ? *reinterpret_cast<const float4*>(pb + (int64_t)(t + 1) * tapStride + (int64_t)(2 * u) * N4)
+                    nxt[u] = rv ? *reinterpret_cast<const float4*>(pb + (int64_t)(t + 1) * tapStride + (int64_t)u * pstep)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             // P tile -> LDS [row][f] for the reduction (the previous tap's reads are complete: same wave, program order)
@@ -514,7 +520,7 @@ bool gf_bwd_fused_supported(int G, int F, int E, int K) {
 }
 
 int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
-                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st) {
+                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st, int node_major) {
     const Geo g = make_geo(B, N, G, F, E, K);
     GF_REQUIRE_SHAPE(g.R < (int64_t)INT32_MAX - 4096, "gf_lsigf_backward: B*N = %lld too large", (long long)g.R);
     GF_REQUIRE_ARG(workspace && workspace_bytes >= g.bytes, "gf_lsigf_backward: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
@@ -524,7 +530,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
     hipError_t attr = hipSuccess;
 #define GF_BF(TT, GG, FF)                                                                                                      \
     do {                                                                                                                        \
-        auto kern = bwd_fused_panel_kernel<TT, GG, FF>;                                                                         \
+        auto kern = node_major ? bwd_fused_panel_kernel<TT, GG, FF, 1> : bwd_fused_panel_kernel<TT, GG, FF, 0>;                 \
         if (lds > 64 * 1024) attr = gf_grant_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, dim3(g.strips), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
                            Nout, B, E, K, g.rowsPerWave);                                                                       \
