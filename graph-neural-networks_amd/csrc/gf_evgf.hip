@@ -519,19 +519,33 @@ __global__ __launch_bounds__(kThreads) void ev_dxt_kernel(const float* __restric
     }
 }
 
-// dbias[f] = sum_{n,b} Dyt[f][n][b]: one workgroup per f, strided partial sums + fixed LDS tree (deterministic)
-__global__ __launch_bounds__(kThreads) void ev_dbias_kernel(const float* __restrict__ Dyt, float* __restrict__ dbias, int64_t NB) {
+// ---- dbias[f] = sum_{n,b} Dyt[f][n][b]   (graphML.py:486-487 under autograd) ---------------------------------------------------
+// Two fixed-order stages: blockIdx.y = one of kBiasSlices contiguous slices of the N*B sum (32 workgroups, one per feature, left
+// 7/8 of the chip idle for 0.77 ms at config 5), then the slices' partial sums in index order.
+constexpr int kBiasSlices = 64;
+__global__ __launch_bounds__(kThreads) void ev_dbias_kernel(const float* __restrict__ Dyt, float* __restrict__ partial, int64_t NB) {
     __shared__ float part[kThreads];
+    const int nS = (int)gridDim.y;
+    const int64_t per = (NB + nS - 1) / nS;
+    const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < NB ? lo + per : NB;
     const float* d = Dyt + (int64_t)blockIdx.x * NB;
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < NB; i += kThreads) acc += d[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) acc += d[i];
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int s = kThreads / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) dbias[blockIdx.x] = part[0];
+    if (threadIdx.x == 0) partial[blockIdx.x * nS + blockIdx.y] = part[0];
+}
+
+__global__ void ev_dbias_finish_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int F, int nS) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float acc = 0.f;
+    for (int s = 0; s < nS; ++s) acc += partial[f * nS + s];
+    dbias[f] = acc;
 }
 
 int lanes_for_batch(int B) {
@@ -744,8 +758,15 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
     if ((rc = to_nodebatch(x, Xt, B, G, Nin, N, st)) != GF_OK) return rc;
     if ((rc = to_nodebatch(dy, Dyt, B, F, Nin, N, st)) != GF_OK) return rc;
     if (dbias) {
-        hipLaunchKernelGGL(ev_dbias_kernel, dim3(F), dim3(kThreads), 0, st, Dyt, dbias, NB);
+        // partial sums live in the (not yet used) dXt region of the scratch (G * N * B floats); tiny problems reduce in one stage
+        int nS = kBiasSlices;
+        if ((int64_t)F * nS > (int64_t)G * NB) nS = 1;
+        hipLaunchKernelGGL(ev_dbias_kernel, dim3(F, nS), dim3(kThreads), 0, st, Dyt, nS > 1 ? dXt : dbias, NB);
         GF_LAUNCH_CHECK("ev_dbias_kernel");
+        if (nS > 1) {
+            hipLaunchKernelGGL(ev_dbias_finish_kernel, dim3((F + 63) / 64), dim3(64), 0, st, dXt, dbias, F, nS);
+            GF_LAUNCH_CHECK("ev_dbias_finish_kernel");
+        }
     }
     // u_{K-1}^{fg} = dy_f : read Dyt through the chain divisor G instead of materialising the broadcast
     const float* Ucur = Dyt;
