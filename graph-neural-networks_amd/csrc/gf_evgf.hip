@@ -98,17 +98,19 @@ __global__ __launch_bounds__(kThreads) void ev_tap0_kernel(const float* __restri
     }
 }
 
-// 4 batch entries per thread (B % 4 == 0): one 64-bit index split per 16 bytes instead of per 4
+// 4 batch entries per thread (B % 4 == 0); the chain rides on blockIdx.y so that the index arithmetic inside a chain is 32-bit (the
+// first version split a 64-bit flat index three times per 16 bytes: 1.13 ms for a 3.3 GB write at config 5)
 __global__ __launch_bounds__(kThreads) void ev_tap0_v4_kernel(const float* __restrict__ wdiag, const float* __restrict__ Xt,
-                                                              float* __restrict__ V0, int G, int64_t NB4, int B4, int64_t total4) {
-    const float4* X4 = reinterpret_cast<const float4*>(Xt);
-    float4* V4 = reinterpret_cast<float4*>(V0);
-    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * kThreads) {
-        const int64_t c = idx / NB4, nb = idx - c * NB4;
-        const int g = (int)(c % G);
-        const float w = wdiag[c * (NB4 / B4) + nb / B4];
-        const float4 x = X4[(int64_t)g * NB4 + nb];
-        V4[idx] = make_float4(w * x.x, w * x.y, w * x.z, w * x.w);
+                                                              float* __restrict__ V0, int G, int N, int B4) {
+    const int c = blockIdx.y, g = c % G;
+    const int NB4 = N * B4;
+    const float4* X4 = reinterpret_cast<const float4*>(Xt) + (int64_t)g * NB4;
+    float4* V4 = reinterpret_cast<float4*>(V0) + (int64_t)c * NB4;
+    const float* wd = wdiag + (int64_t)c * N;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < NB4; i += gridDim.x * kThreads) {
+        const float w = wd[i / B4];
+        const float4 x = X4[i];
+        V4[i] = make_float4(w * x.x, w * x.y, w * x.z, w * x.w);
     }
 }
 
@@ -503,19 +505,22 @@ __global__ __launch_bounds__(kThreads) void ev_dwdiag4_kernel(const float* __res
 }
 
 // dXt[g][n][b] = sum_f wdiag[f*G+g][n] * U0[(f*G+g)/u_div][n][b]
+// VEC batch entries per thread (16-byte loads when N*B % 4 == 0 and B % 4 == 0), g on blockIdx.y: 32-bit indices inside a plane.
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void ev_dxt_kernel(const float* __restrict__ wdiag, const float* __restrict__ U0,
-                                                          float* __restrict__ dXt, int N, int B, int G, int F, int u_div,
-                                                          int64_t total) {
+                                                          float* __restrict__ dXt, int N, int B, int G, int F, int u_div) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int g = blockIdx.y;
     const int64_t NB = (int64_t)N * B;
-    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
-        const int64_t g = idx / NB, nb = idx - g * NB;
-        const int64_t n = nb / B;
-        float acc = 0.f;
+    const int NBv = (int)(NB / VEC), Bv = B / VEC;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < NBv; i += gridDim.x * kThreads) {
+        const int n = i / Bv;
+        vec_t acc = 0.f;
         for (int f = 0; f < F; ++f) {
             const int64_t c = (int64_t)f * G + g;
-            acc = fmaf(wdiag[c * N + n], U0[(c / u_div) * NB + nb], acc);
+            acc += wdiag[c * N + n] * *reinterpret_cast<const vec_t*>(U0 + (c / u_div) * NB + (int64_t)i * VEC);
         }
-        dXt[idx] = acc;
+        *reinterpret_cast<vec_t*>(dXt + (int64_t)g * NB + (int64_t)i * VEC) = acc;
     }
 }
 
@@ -723,8 +728,9 @@ extern "C" int gf_evgf_forward(const gf_ev_plan* plan, const float* x, const flo
     float* Xt = scratch;
     float* Yt = scratch + (int64_t)G * NB;
     if ((rc = to_nodebatch(x, Xt, B, G, Nin, N, st)) != GF_OK) return rc;
-    if (B % 4 == 0)
-        hipLaunchKernelGGL(ev_tap0_v4_kernel, dim3(grid_for(CNB / 4)), dim3(kThreads), 0, st, wdiag, Xt, V, G, NB / 4, B / 4, CNB / 4);
+    if (B % 4 == 0 && C <= 65535 && NB < (int64_t)INT32_MAX)
+        hipLaunchKernelGGL(ev_tap0_v4_kernel, dim3((unsigned)std::min<int64_t>(64, (NB / 4 + kThreads - 1) / kThreads), C), dim3(kThreads), 0, st,
+                           wdiag, Xt, V, G, N, B / 4);
     else
         hipLaunchKernelGGL(ev_tap0_kernel, dim3(grid_for(CNB)), dim3(kThreads), 0, st, wdiag, Xt, V, G, NB, B, CNB);
     GF_LAUNCH_CHECK("ev_tap0_kernel");
@@ -863,8 +869,13 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
         }
     }
     if (dx) {
-        const int64_t GNB = (int64_t)G * NB;
-        hipLaunchKernelGGL(ev_dxt_kernel, dim3(grid_for(GNB)), dim3(kThreads), 0, st, wdiag, Ucur, dXt, N, B, G, F, udiv, GNB);
+        GF_REQUIRE_SHAPE(G <= 65535 && NB < (int64_t)INT32_MAX, "gf_evgf_backward: G = %d / N*B = %lld exceed the launch grid", G, (long long)NB);
+        if (B % 4 == 0)
+            hipLaunchKernelGGL(ev_dxt_kernel<4>, dim3((unsigned)std::min<int64_t>(256, (NB / 4 + kThreads - 1) / kThreads), G), dim3(kThreads), 0,
+                               st, wdiag, Ucur, dXt, N, B, G, F, udiv);
+        else
+            hipLaunchKernelGGL(ev_dxt_kernel<1>, dim3((unsigned)std::min<int64_t>(256, (NB + kThreads - 1) / kThreads), G), dim3(kThreads), 0, st,
+                               wdiag, Ucur, dXt, N, B, G, F, udiv);
         GF_LAUNCH_CHECK("ev_dxt_kernel");
         rc = from_nodebatch(dXt, dx, B, G, N, Nin, st);
     }
