@@ -163,8 +163,19 @@ __global__ __launch_bounds__(kThreads) void ev_hop_kernel(const int32_t* __restr
 // consecutive rows.  The (column, weight) pairs of those rows are loaded once, coalesced (3 of the 4 global loads per entry
 // and thread of the kernel above were index / weight fetches with 16 useful bytes per wave-instruction), then every thread
 // (row, b) walks its row from LDS and only the gathers of v_{k-1} go to memory, 4 in flight per thread.
-constexpr int kRowsPerWG = 128;
+#ifndef GF_EV_RPW
+#define GF_EV_RPW 64
+#endif
+constexpr int kRowsPerWG = GF_EV_RPW;
 constexpr int kEvChunk = 2048;  // staged entries per pass (16 KB of LDS)
+#ifndef GF_EV_U
+#define GF_EV_U 8
+#endif
+constexpr int kEvU = GF_EV_U;  // gathers in flight per row and thread (ev_hop_lds4_kernel)
+#ifndef GF_EV_ROWS
+#define GF_EV_ROWS 1
+#endif
+constexpr int kEvRows = GF_EV_ROWS;  // rows of a thread whose gathers are issued together
 
 template <int LB>
 __global__ __launch_bounds__(kThreads) void ev_hop_lds_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -276,25 +287,41 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __
         }
         __syncthreads();
         if (b < B) {
+            // kEvU gathers in flight per row and the rows of a thread walked together: the tap is bound by the latency of the
+            // gathers (L2 hits, ~2 us under load), so what counts is bytes in flight per CU.  Entries are still added in
+            // ascending order per row: bit-identical to the row-at-a-time loop.
+            constexpr int J = RPW / RPP, JI = J < kEvRows ? J : kEvRows;  // rows of a thread / rows walked together
 #pragma unroll
-            for (int j = 0; j < RPW / RPP; ++j) {
-                const int r = r0 + j * RPP + lr;
-                if (r >= r1) break;
-                int q = max(rowptr[r], base) - base;
-                const int qe = min(rowptr[r + 1], base + cnt) - base;
-                float4 a = acc[j];
-                for (; q + 3 < qe; q += 4) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(vin + (int64_t)s_col[q] * B);
-                    const float4 x1 = *reinterpret_cast<const float4*>(vin + (int64_t)s_col[q + 1] * B);
-                    const float4 x2 = *reinterpret_cast<const float4*>(vin + (int64_t)s_col[q + 2] * B);
-                    const float4 x3 = *reinterpret_cast<const float4*>(vin + (int64_t)s_col[q + 3] * B);
-                    fma4(s_w[q], x0, a);
-                    fma4(s_w[q + 1], x1, a);
-                    fma4(s_w[q + 2], x2, a);
-                    fma4(s_w[q + 3], x3, a);
+            for (int j0 = 0; j0 < J; j0 += JI) {
+                int q[JI], qe[JI];
+                bool more = false;
+#pragma unroll
+                for (int j = 0; j < JI; ++j) {
+                    const int r = r0 + (j0 + j) * RPP + lr;
+                    q[j] = qe[j] = 0;
+                    if (r < r1) {
+                        q[j] = max(rowptr[r], base) - base;
+                        qe[j] = min(rowptr[r + 1], base + cnt) - base;
+                    }
+                    more |= q[j] < qe[j];
                 }
-                for (; q < qe; ++q) fma4(s_w[q], *reinterpret_cast<const float4*>(vin + (int64_t)s_col[q] * B), a);
-                acc[j] = a;
+                while (more) {
+                    float4 x[JI][kEvU];
+#pragma unroll
+                    for (int j = 0; j < JI; ++j)
+#pragma unroll
+                        for (int i = 0; i < kEvU; ++i)
+                            if (q[j] + i < qe[j]) x[j][i] = *reinterpret_cast<const float4*>(vin + (int64_t)s_col[q[j] + i] * B);
+                    more = false;
+#pragma unroll
+                    for (int j = 0; j < JI; ++j) {
+#pragma unroll
+                        for (int i = 0; i < kEvU; ++i)
+                            if (q[j] + i < qe[j]) fma4(s_w[q[j] + i], x[j][i], acc[j0 + j]);
+                        q[j] += kEvU;
+                        more |= q[j] < qe[j];
+                    }
+                }
             }
         }
     }
@@ -567,7 +594,7 @@ int launch_ev_hop(const int32_t* rowptr, const int32_t* col, const int32_t* vidx
     const int rpw = std::max(kRowsPerWG, kThreads / lbw);  // rows per workgroup (RPW of ev_hop_lds_kernel)
     const int nRowBlocks = (N + rpw - 1) / rpw;
     const int64_t nblk = (int64_t)((C + 7) / 8) * 8 * nRowBlocks;
-    static const int env_generic = getenv("GFHIP_EVGF_GENERIC") ? atoi(getenv("GFHIP_EVGF_GENERIC")) : 0;
+    const int env_generic = g_tune.evgf_generic;
     if (B % 4 == 0 && B <= 256 && env_generic == 0) {  // 16-byte gathers: 4 batch entries per thread
         const int lq = lanes_for_batch(B / 4);
         const int rpw4 = std::max(kRowsPerWG, kThreads / lq);
@@ -788,7 +815,7 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
             };
             GF_REQUIRE_SHAPE(chainSlots * ((epc + 3) / 4) < (int64_t)INT32_MAX, "gf_evgf_backward: %lld chains x %lld entries exceed the launch grid",
                              (long long)C, (long long)plan->nnzp);
-            static const int env_scalar = getenv("GFHIP_EVGF_GENERIC") ? atoi(getenv("GFHIP_EVGF_GENERIC")) : 0;
+            const int env_scalar = g_tune.evgf_generic;
             if (B % 4 == 0 && B <= 256 && env_scalar == 0) {
                 const int lq = lanes_for_batch(B / 4);
                 const unsigned grid4 = sddmm_grid(lq);

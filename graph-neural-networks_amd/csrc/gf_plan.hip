@@ -79,6 +79,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_grid")) g_tune.panel_grid = value;
     else if (!strcmp(key, "panel_rotate")) g_tune.panel_rotate = value;
     else if (!strcmp(key, "panel_chain")) g_tune.panel_chain = value;
+    else if (!strcmp(key, "evgf_generic")) g_tune.evgf_generic = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);
         return GF_ERR_ARG;

@@ -714,10 +714,16 @@ def test_edge_variant_gf_matches_reference_golden(path):
     dict(N=400, B=12, G=4, F=6, K=3, M=150, directed=True),         # 16-byte gathers, 3 of 4 lanes per row active, hybrid
     dict(N=300, B=64, G=4, F=4, K=4, M=300, directed=True),         # 16 lanes per row
     dict(N=200, B=132, G=2, F=3, K=2, M=200, directed=False),       # 33 quads per row: 64-lane groups, partly idle
+    dict(N=600, B=16, G=4, F=4, K=3, M=600, directed=False, hub=True),  # a node adjacent to all: its row block exceeds the LDS stage
 ], ids=lambda c: "_".join(f"{k}{v}" for k, v in c.items()))
 def test_evgf_per_edge_storage_vs_oracle(cfg):
     N, B, G, F, K, M = (cfg[k] for k in "NBGFKM")
     A = graphgen.sbm(N, seed=5, directed=cfg["directed"])
+    if cfg.get("hub"):
+        A = A.tolil()
+        A[7, :] = 1.0 / N
+        A[:, 7] = 1.0 / N
+        A = A.tocsr()
     pat = EdgePattern.from_gso(A, M)
     P = evo.ev_pattern(A, M)
     assert np.array_equal(pat.indices, P.indices)
@@ -743,6 +749,29 @@ def test_evgf_per_edge_storage_vs_oracle(cfg):
     y2 = EVGF_edges(pat, wd2, we2, xt2, bt2)
     y2.backward(cu(dy))
     assert torch.equal(y, y2) and torch.equal(we.grad, we2.grad) and torch.equal(xt.grad, xt2.grad)
+
+
+@pytest.mark.parametrize("B,G,K", [(16, 32, 3), (12, 5, 2), (64, 3, 4), (132, 2, 3)])
+def test_evgf_tap_kernels_are_bit_identical(B, G, K, pipeline_knob):
+    """The three tap kernels (16-byte gathers with the entries staged in LDS, 4-byte gathers, one thread per output) add a row's
+    entries in the same order: output and every gradient are bit-identical."""
+    N, F = 900, 4
+    A = graphgen.sbm(N, seed=2, directed=True)
+    pat = EdgePattern.from_gso(A, N)
+    rng = np.random.RandomState(B)
+    wdiag = rng.uniform(-1, 1, (F, G, N)).astype(np.float32)
+    wedge = (rng.uniform(-1, 1, (F, K - 1, G, pat.nnzp)) * 0.3).astype(np.float32)
+    x, dy = rng.randn(B, G, N).astype(np.float32), rng.randn(B, F, N).astype(np.float32)
+    res = []
+    for generic in (0, 2, 1):
+        pipeline_knob(evgf_generic=generic)
+        wd, we, xt = cu(wdiag, True), cu(wedge, True), cu(x, True)
+        y = EVGF_edges(pat, wd, we, xt, None)
+        y.backward(cu(dy))
+        res.append((y.detach(), xt.grad, wd.grad))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
 
 
 def test_edge_variant_gf_sparse_parameters_config5_shape():
@@ -784,7 +813,7 @@ def tune(**kw):
 @pytest.fixture
 def pipeline_knob():
     yield tune
-    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_chain=1, panel_np=0)
+    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_chain=1, panel_np=0, evgf_generic=0)
 
 
 def to_panels(x, N):

@@ -20,6 +20,9 @@ probe)   # chain kernel time split
 variants)  # A/B library builds: probe each alegnn_amd/libgfhip_*.so
   for so in graph-neural-networks_amd/alegnn_amd/libgfhip_*.so; do echo "== $so"; PROBE_DEGS=0,10 GFHIP_LIB=$PWD/$so timeout 300 python tools/chain_probe.py 10000 256 2>&1 | grep -v amdgpu.ids; done > $O/variants.log 2>&1; cat $O/variants.log
   ;;
+evvariants)  # A/B library builds on the EVGF workload
+  for so in graph-neural-networks_amd/alegnn_amd/libgfhip*.so; do echo "== $so"; GFHIP_LIB=$PWD/$so timeout 200 python bench.py --workload cfg5 --no-cpu-baseline --steps 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['launch_ms'])"; done > $O/evvariants.log 2>&1; cat $O/evvariants.log
+  ;;
 trace)   # phase timeline of the chain kernel (trace build)
   for d in 0 10 20; do echo "== degree $d"; GFHIP_LIB=$PWD/graph-neural-networks_amd/alegnn_amd/libgfhip_trace.so timeout 300 python tools/chain_trace.py $d 2>&1 | grep -v amdgpu.ids | head -12; done > $O/trace.log 2>&1; cat $O/trace.log
   ;;

@@ -14,13 +14,21 @@ for kv in sys.argv[3:]:
     k, v = kv.split("=")
     assert L.gf_tune(k.encode(), int(v)) == 0, k
 dev = torch.device("cuda:0")
-wl = bench.WORKLOADS[name]
+wl = dict(bench.WORKLOADS[name])
+if os.environ.get("PROBE_B"):  # same workload at another batch size (row width of the EVGF gathers = 4*B bytes)
+    wl["B"] = int(os.environ["PROBE_B"])
 w = bench.Workload(name, wl, dev, 0)
 st = torch.cuda.current_stream().cuda_stream
 if wl["kind"] == "evgf":
     with torch.no_grad():
+        w.module(w.x.detach())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(iters):
             w.module(w.x.detach())
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"evgf forward B={wl['B']}: {e0.elapsed_time(e1) / iters:.3f} ms")
 else:
     layer = w.module if wl["kind"] == "filter" else w.module.GFL[3]
     B, N = wl["B"], layer.N
