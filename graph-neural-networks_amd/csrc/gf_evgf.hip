@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __
         if (base != seg_lo) __syncthreads();
         for (int i = tid; i < cnt; i += kThreads) {
             s_col[i] = col[base + i];
-            s_w[i] = W[vidx ? vidx[base + i] : base + i];  // (non-temporal loads / stores of the streams: measured slower)
+            s_w[i] = W[vidx ? vidx[base + i] : base + i];  // (non-temporal weight loads: adjoint taps 20 % slower; non-temporal output stores: no change)
         }
         __syncthreads();
         if (b < B) {

@@ -10,19 +10,20 @@ vectors; plain degree sort for comparison).  CPU only (numpy); run: python tools
 Traffic model per hop (config 4: B*G = 4096 columns, 4 bytes per entry of the signal):
   source blocks re-read once per destination range  : ceil(N / rows per workgroup) x the signal
   index stream (2 B per executed slot) per panel     : nnz / fill x 2 B x (4096 / c) panels
-against today's 16.4 GB of gathered 128-byte rows; L2 -> CU delivers 128-byte lines at ~11.5 TB/s (profiles/r02_c_evgf/README.md).
+against today's 16.4 GB of gathered 128-byte rows.  The column 'ms at 10 TB/s' prices the total at the best rate this chip has
+delivered for a stream of this size that does not fit L2 (the production kernel's gathers: 8.6 TB/s, the L2-window prototype: 10.3 TB/s).
 """
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "graph-neural-networks_amd"))
 from alegnn_amd import graphgen
 
-N, COLS, L2_RATE = 100_000, 128 * 32, 11.5e12
+N, COLS, L2_RATE = 100_000, 128 * 32, 10e12
 A = graphgen.er(N, seed=0)
 rows = np.repeat(np.arange(N), np.diff(A.indptr))
 signal = N * COLS * 4
 print(f"ER N={N} nnz={A.nnz}; signal {signal/1e9:.2f} GB per tap; today: {A.nnz*COLS*4/1e9:.1f} GB of 128-byte gathers, 1.90 ms per hop")
-print("cols/panel  nodes/block  blocks  fill(lexsort)  fill(degree)  rows/WG  src re-reads  src GB  index GB  total GB  ms at 11.5 TB/s")
+print("cols/panel  nodes/block  blocks  fill(lexsort)  fill(degree)  rows/WG  src re-reads  src GB  index GB  total GB  ms at 10 TB/s")
 for c in (1, 2, 4):
     blk = 40960 // c
     nb = -(-N // blk)
