@@ -287,9 +287,8 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __
         }
         __syncthreads();
         if (b < B) {
-            // kEvU gathers in flight per row and the rows of a thread walked together: the tap is bound by the latency of the
-            // gathers (L2 hits, ~2 us under load), so what counts is bytes in flight per CU.  Entries are still added in
-            // ascending order per row: bit-identical to the row-at-a-time loop.
+            // kEvU gathers in flight per row, kEvRows rows of a thread walked together (measured: 8 x 1 is as good as it gets, more
+            // in flight is slower -- DESIGN.md section 3.3).  Entries are added in ascending order per row whatever the setting.
             constexpr int J = RPW / RPP, JI = J < kEvRows ? J : kEvRows;  // rows of a thread / rows walked together
 #pragma unroll
             for (int j0 = 0; j0 < J; j0 += JI) {
