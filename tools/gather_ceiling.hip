@@ -34,6 +34,44 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ X
     if (acc.x == 123.456f) sink[0] = acc.y + acc.z + acc.w;
 }
 
+// narrow rows: LPR lanes per row, 16 bytes per lane (LPR = 4: the 64-byte rows of the EVGF tap at B = 16; 2: 32-byte rows at B = 8)
+template <int LPR, int NLOAD>
+__global__ __launch_bounds__(256) void gather_narrow_kernel(const float* __restrict__ X, int rows_mask, long panel_floats, int iters,
+                                                             float* __restrict__ sink) {
+    const int li = threadIdx.x % LPR;
+    const unsigned gid = (blockIdx.x * 256 + threadIdx.x) / LPR;
+    const float* P = X + (long)(blockIdx.x & 7) * panel_floats + li * 4;
+    unsigned h = gid * 2654435761u + 12345u;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        f32x4 v[NLOAD];
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) {
+            h = h * 1664525u + 1013904223u;
+            const unsigned row = (h >> 8) & rows_mask;
+            v[u] = *reinterpret_cast<const f32x4*>(P + (long)row * (LPR * 4));
+        }
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) acc += v[u];
+    }
+    if (acc.x == 123.456f) sink[0] = acc.y + acc.z + acc.w;
+}
+
+template <int LPR, int NLOAD>
+void run_narrow(const float* X, int rows, int blocks, float* sink) {
+    const int iters = 64;
+    const long pf = (long)rows * LPR * 4;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    gather_narrow_kernel<LPR, NLOAD><<<blocks, 256>>>(X, rows - 1, pf, iters, sink);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) gather_narrow_kernel<LPR, NLOAD><<<blocks, 256>>>(X, rows - 1, pf, iters, sink);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    const double reqs = (double)blocks * (256 / LPR) * iters * NLOAD;
+    printf("  rows of %3d B, %2d in flight   panel %7.2f MB per XCD  %8.1f us  %8.1f GB/s gathered  %6.1f G rows/s\n", LPR * 16, NLOAD,
+           rows * LPR * 16.0 / 1e6, ms * 1e3, reqs * LPR * 16 / ms / 1e6, reqs / ms / 1e6);
+}
+
 // short-lived variant: what the hop kernel's waves look like -- ITERS rounds of NLOAD gathers, then ONE 128-byte row store
 template <int NLOAD, int ITERS, int DEP>
 __global__ __launch_bounds__(256) void gather_short_kernel(const float* __restrict__ X, int rows_mask, long panel_floats,
@@ -86,7 +124,18 @@ void run(const char* label, const float* X, int rows, long panel_floats, int blo
     printf("  %-28s panel %7.2f MB  blocks %6d  %8.1f us  %8.1f GB/s gathered\n", label, rows * 128.0 / 1e6, blocks, ms * 1e3, bytes / ms / 1e6);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {   // `gather_ceiling narrow`: row-width sweep for the EVGF tap analysis (profiles/r02_c_evgf)
+        float *X, *sink;
+        CK(hipMalloc(&X, (size_t)8 * 262144 * 128)); CK(hipMalloc(&sink, 64));
+        CK(hipMemset(X, 0, (size_t)8 * 262144 * 128));
+        for (int rows : {16384, 32768, 65536, 262144}) {
+            run_narrow<8, 8>(X, rows, 4096, sink);
+            run_narrow<4, 8>(X, rows, 4096, sink);
+            run_narrow<2, 8>(X, rows, 4096, sink);
+        }
+        return 0;
+    }
     {   // the cfg2 hop has 2.56M (row, batch entry) pairs of ~10 gathers each: same amount of work in different wave shapes
         const int rows = 8192; const long pf = (long)rows * 32; const long groups = 2560000 / 32 * 32;
         float *X, *out; int* idx;
