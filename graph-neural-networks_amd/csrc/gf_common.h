@@ -65,6 +65,9 @@ struct gf_csr_dev {
     int2* sell_ent = nullptr;       // [sell_kptr[n_slices] * 8]
     int32_t* sell_rowid = nullptr;  // [n_slices * 8]  stored position -> original row, -1 past the last row
     int64_t sell_pad_entries = 0;   // padding entries (wasted gathers), for diagnostics
+    int32_t* sell_col = nullptr;    // uniform values only: the columns of sell_ent alone, padding = -1 (half the entry stream)
+    int32_t sell_uniform = 0;       // every stored value equals sell_uval
+    float sell_uval = 0.f;
     // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes.  Work unit = OCTET (8 consecutive rows = one 128-byte
     // line of a column panel); octets are sorted by their longest row and a slice = 8 octets = one wavefront (lane l handles
     // row pn_oct[8s + l/8] * 8 + l%8), so the rows a wave walks together have similar lengths and every octet still stores a

@@ -219,6 +219,19 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, gf_csr_dev& d, int64_t&
     if ((rc = upload(kptr, &d.sell_kptr, bytes))) return rc;
     if ((rc = upload(ent, &d.sell_ent, bytes))) return rc;
     if ((rc = upload(rid, &d.sell_rowid, bytes))) return rc;
+    bool uni = !s.val.empty();
+    for (size_t q = 1; uni && q < s.val.size(); ++q) uni = s.val[q] == s.val[0];
+    d.sell_uniform = uni ? 1 : 0;
+    d.sell_uval = uni ? s.val[0] : 0.f;
+    if (uni) {
+        std::vector<int32_t> colv(ent.size(), -1);
+        for (int32_t sl = 0; sl < ns; ++sl)
+            for (int32_t r = 0; r < 8 && sl * 8 + r < n; ++r) {
+                const int32_t p = sl * 8 + r;
+                for (int32_t q = s.rowptr[p]; q < s.rowptr[p + 1]; ++q) colv[((size_t)kptr[sl] + (q - s.rowptr[p])) * 8 + r] = s.col[q];
+            }
+        if ((rc = upload(colv, &d.sell_col, bytes))) return rc;
+    }
     return upload_panel(n, a, d, bytes);
 }
 
@@ -447,6 +460,7 @@ void free_csr(gf_csr_dev& d) {
     if (d.rowid) (void)hipFree(d.rowid);
     if (d.sell_kptr) (void)hipFree(d.sell_kptr);
     if (d.sell_ent) (void)hipFree(d.sell_ent);
+    if (d.sell_col) (void)hipFree(d.sell_col);
     if (d.sell_rowid) (void)hipFree(d.sell_rowid);
     if (d.pn_slice) (void)hipFree(d.pn_slice);
     if (d.pn_oct) (void)hipFree(d.pn_oct);

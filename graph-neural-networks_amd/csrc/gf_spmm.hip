@@ -28,6 +28,7 @@
 // Kernel B -- CSR, one workgroup per 256/LG rows with its segment staged in LDS (the first version; kept for A/B).
 // Kernel C -- generic: any W (G = 1, odd widths), one thread per output element.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "gf_common.h"
 
@@ -79,16 +80,22 @@ __device__ __forceinline__ float4 load_row(const float* p) {
 //   BL  = 8 / LPR batch entries side by side in one wave, BT = batch entries per lane (register tile)
 //   SPW = consecutive slices one wave walks (the second slice's entries are fetched while the first is gathered)
 // ------------------------------------------------------------------------------------------------------------------
-template <int LPR, int VPL, int BT, int SPW, int NTL, int UCAP>
-__global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __restrict__ kptr, const int2* __restrict__ ent,
+//   UNI = 1: every stored value equals uval (S = A / lambda_max of an unweighted graph): the entry stream is the columns only (4 bytes
+//         instead of 8 per entry: at config 4 it is re-read for each of the 128 batch entries, 1 GB per hop through the same fabric
+//         and the same L2 as the gathers), padding = column -1, rows are summed and scaled once (v * sum(x), as the panel kernels do)
+template <int LPR, int VPL, int BT, int SPW, int NTL, int UCAP, int UNI>
+__global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __restrict__ kptr, const void* __restrict__ ent_v,
                                                              const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
                                                              float* __restrict__ Xout, int N, int B, int nSlices, int nBTiles,
-                                                             int lanes, int parts, int blocksPerTile, int store_mode, int pf_blocks) {
+                                                             int lanes, int parts, int blocksPerTile, int store_mode, int pf_blocks,
+                                                             float uval) {
+    typedef typename std::conditional<UNI != 0, int32_t, int2>::type ent_t;
+    const ent_t* __restrict__ ent = static_cast<const ent_t*>(ent_v);
     constexpr int BL = 8 / LPR;
     constexpr int W = 4 * LPR * VPL;
     constexpr int BTW = BL * BT;  // batch entries per tile
     constexpr int UMAX = (UCAP / (BT * VPL)) > 0 ? (UCAP / (BT * VPL)) : 1;  // neighbours whose gathers are in flight together
-    __shared__ int2 s_ent[kThreads / 64][2][kCK * 8];
+    __shared__ ent_t s_ent[kThreads / 64][2][kCK * 8];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -137,21 +144,29 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
     if (i0 >= nSlP) return;
     const int ns = min(SPW, nSlP - i0);
 
-    int2* ring0 = &s_ent[wave][0][0];
-    int2* ring1 = &s_ent[wave][1][0];
+    ent_t* ring0 = &s_ent[wave][0][0];
+    ent_t* ring1 = &s_ent[wave][1][0];
+    auto pad_entry = []() {
+        if constexpr (UNI != 0) return (int32_t)-1;
+        else return make_int2(0, 0);
+    };
+    auto col_of = [](const ent_t& e) {
+        if constexpr (UNI != 0) return e;
+        else return e.x;
+    };
 
     // entries of k-range [ka, kb) (kb - ka <= kCK) -> 4 registers per lane, coalesced 512-byte reads
-    int2 pre[4];
+    ent_t pre[4];
     auto issue_entries = [&](int ka, int kb) {
         const int cnt = (kb - ka) * 8;
-        const int2* src = ent + (int64_t)ka * 8;
+        const ent_t* src = ent + (int64_t)ka * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int e = j * 64 + lane;
-            pre[j] = (e < cnt) ? src[e] : make_int2(0, 0);
+            pre[j] = (e < cnt) ? src[e] : pad_entry();
         }
     };
-    auto commit_entries = [&](int2* dst) {
+    auto commit_entries = [&](ent_t* dst) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j * 64 + lane] = pre[j];
     };
@@ -197,20 +212,20 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
 
             // -- gather + accumulate the nk neighbours staged in the current slot, UMAX neighbours at a time: all their
             //    gathers are issued before the first FMA (cnt is wave-uniform: scalar branches, exact counts, no padding)
-            const int2* eb = (cur ? ring1 : ring0) + r;
+            const ent_t* eb = (cur ? ring1 : ring0) + r;
             const int nk = kend - kc;
             for (int k = 0; k < nk; k += UMAX) {
                 const int cnt = min(UMAX, nk - k);
                 // all of the chunk's (col, val) pairs first -- unconditional, back-to-back broadcast reads and ONE lgkmcnt wait
                 // (the slot is always fully written, zero-padded), then the gathers, each behind a scalar branch
-                int2 e[UMAX];
+                ent_t e[UMAX];
 #pragma unroll
                 for (int u = 0; u < UMAX; ++u) e[u] = eb[(k + u) * 8];
                 float4 x[UMAX][BT][VPL];
 #pragma unroll
                 for (int u = 0; u < UMAX; ++u)
                     if (u < cnt) {
-                        const unsigned off = __umul24((unsigned)e[u].x, (unsigned)W);
+                        const unsigned off = __umul24((unsigned)max(col_of(e[u]), 0), (unsigned)W);
 #pragma unroll
                         for (int t = 0; t < BT; ++t)
 #pragma unroll
@@ -220,7 +235,9 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
 #pragma unroll
                 for (int u = 0; u < UMAX; ++u)  // ascending k: fixed summation order
                     if (u < cnt) {
-                        const float val = __int_as_float(e[u].y);
+                        float val;
+                        if constexpr (UNI != 0) val = e[u] >= 0 ? 1.f : 0.f;   // (padding: row 0 times zero, as the {0, 0.0f} entries)
+                        else val = __int_as_float(e[u].y);
 #pragma unroll
                         for (int t = 0; t < BT; ++t)
 #pragma unroll
@@ -241,7 +258,10 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
                 if (b < B) {
                     float* o = Xout + (int64_t)b * N * W + (int64_t)orow * W + li * 4;
 #pragma unroll
-                    for (int v = 0; v < VPL; ++v) store_row(o + v * (LPR * 4), acc[t][v], store_mode);
+                    for (int v = 0; v < VPL; ++v) {
+                        if constexpr (UNI != 0) acc[t][v].x *= uval, acc[t][v].y *= uval, acc[t][v].z *= uval, acc[t][v].w *= uval;
+                        store_row(o + v * (LPR * 4), acc[t][v], store_mode);
+                    }
                 }
             }
         }
@@ -413,14 +433,17 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     const int64_t nblk = (int64_t)8 * tilesPerLane * blocksPerTile;
     GF_REQUIRE_SHAPE(nblk < (int64_t)INT32_MAX, "gf_spmm_hop: grid of %lld blocks too large", (long long)nblk);
     dim3 grid((unsigned)nblk), block(kThreads);
-#define GF_SELL_ARGS m.sell_kptr, m.sell_ent, m.sell_rowid, Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store, pf
+    const bool uni = m.sell_uniform && m.sell_col && g_tune.panel_uniform;
+#define GF_SELL_ARGS(ENT) m.sell_kptr, (const void*)(ENT), m.sell_rowid, Xin, Xout, N, B, m.n_slices, nBTiles, lanes, parts, blocksPerTile, g_tune.spmm_store, pf, m.sell_uval
 #define GF_SELL(BTV, SPWV)                                                                                          \
     if (g_tune.spmm_load)                                                                                           \
-        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 1, 16>), grid, block, 0, st, GF_SELL_ARGS);       \
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 1, 16, 0>), grid, block, 0, st, GF_SELL_ARGS(m.sell_ent));    \
     else if (g_tune.spmm_ucap == 8)                                                                                 \
-        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0, 8>), grid, block, 0, st, GF_SELL_ARGS);        \
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0, 8, 0>), grid, block, 0, st, GF_SELL_ARGS(m.sell_ent));     \
+    else if (uni)                                                                                                   \
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0, 16, 1>), grid, block, 0, st, GF_SELL_ARGS(m.sell_col));    \
     else                                                                                                            \
-        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0, 16>), grid, block, 0, st, GF_SELL_ARGS)
+        hipLaunchKernelGGL((spmm_sell_kernel<LPR, VPL, BTV, SPWV, 0, 16, 0>), grid, block, 0, st, GF_SELL_ARGS(m.sell_ent))
 #define GF_SELL_BT(SPWV)             \
     switch (bt) {                    \
         case 1: GF_SELL(1, SPWV); break; \
