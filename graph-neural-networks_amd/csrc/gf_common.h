@@ -157,6 +157,7 @@ struct gf_tuning {
     int panel_np = 0;           // panels per workgroup pass: 0 = heuristic (2 while two workgroups still fit a CU's LDS), 1, 2
     int panel_even = 0;         // 1 = pad every slice to an even number of group-rows (set BEFORE gf_plan_create)
     int panel_sort = 1;         // 1 = octets sorted by their longest row (set BEFORE gf_plan_create)
+    int evgf_idx16 = 1;         // EVGF: 16-bit node indices when N <= 65535 (half the index streams that share L2 with the gather panel)
     int evgf_generic = 0;       // EVGF taps: 0 = best kernel, 1 = one thread per output, 2 = LDS-staged 4-byte gathers (no 16-byte version)
 };
 extern gf_tuning g_tune;

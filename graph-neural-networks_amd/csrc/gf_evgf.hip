@@ -31,6 +31,11 @@ struct gf_ev_plan {
     int32_t* t_rowptr = nullptr;  // [N+1]   transposed pattern: row j lists the entries p with col[p] == j
     int32_t* t_col = nullptr;     // [nnzp]  = row[p]   (ascending within a transposed row)
     int32_t* t_vidx = nullptr;    // [nnzp]  = p        (value index into wedge)
+    // 16-bit copies of the node indices when N <= 65535: the index streams are re-read for every chain and share the 4 MB L2 with the
+    // gather panel (config 5: 2.2 MB -> 1.1 MB per array)
+    uint16_t* col16 = nullptr;
+    uint16_t* row16 = nullptr;
+    uint16_t* t_col16 = nullptr;
 };
 
 namespace {
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds_kernel(const int32_t* __r
 // wave-instruction moves 1 KiB instead of 256 B through the same address path (the gathers are L2 hits: what limits them is
 // the per-lane request rate, not bytes -- the 4-byte version sat at 3.8 TB/s of gathered rows).  Per-element summation
 // order is unchanged: results are bit-identical to ev_hop_lds_kernel.
-template <int LQ>  // lanes per row = B / 4 rounded up to a power of two
-__global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+template <int LQ, class IT>  // lanes per row = B / 4 rounded up to a power of two; IT = int32_t | uint16_t column indices
+__global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __restrict__ rowptr, const IT* __restrict__ col,
                                                                const int32_t* __restrict__ vidx, const float* __restrict__ wedge,
                                                                const float* __restrict__ in, const float* __restrict__ add,
                                                                float* __restrict__ out, int N, int B, int G, int K1, int kidx,
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void ev_hop_lds4_kernel(const int32_t* __
         const int cnt = min(kEvChunk, seg_hi - base);
         if (base != seg_lo) __syncthreads();
         for (int i = tid; i < cnt; i += kThreads) {
-            s_col[i] = col[base + i];
+            s_col[i] = (int32_t)col[base + i];
             s_w[i] = W[vidx ? vidx[base + i] : base + i];  // (non-temporal weight loads: adjoint taps 20 % slower; non-temporal output stores: no change)
         }
         __syncthreads();
@@ -397,8 +402,8 @@ __global__ __launch_bounds__(kThreads) void ev_sddmm_kernel(const int32_t* __res
 #pragma unroll
         for (int e = 0; e < EPG; ++e) {
             const int64_t p = p0 + e < nnzp ? p0 + e : nnzp - 1;  // clamp: the surplus lanes of the last quad recompute its last entry
-            ri[e] = row[p];
-            ci[e] = col[p];
+            ri[e] = (int)row[p];
+            ci[e] = (int)col[p];
         }
         float acc[EPG];
 #pragma unroll
@@ -425,8 +430,8 @@ __global__ __launch_bounds__(kThreads) void ev_sddmm_kernel(const int32_t* __res
 
 // 4 batch entries per lane (B % 4 == 0): 16-byte gathers of u and v, LQ = B/4 lanes per entry group (see ev_hop_lds4_kernel).
 // Fixed summation order (4 in-lane FMAs, then the xor tree), different from the scalar kernel's by rounding only.
-template <int LQ>
-__global__ __launch_bounds__(kThreads) void ev_sddmm4_kernel(const int32_t* __restrict__ row, const int32_t* __restrict__ col,
+template <int LQ, class IT>
+__global__ __launch_bounds__(kThreads) void ev_sddmm4_kernel(const IT* __restrict__ row, const IT* __restrict__ col,
                                                              const float* __restrict__ U, const float* __restrict__ V,
                                                              float* __restrict__ dwedge, int N, int B, int G, int K1, int kidx,
                                                              int64_t nnzp, int u_div, int64_t nChains) {
@@ -453,8 +458,8 @@ __global__ __launch_bounds__(kThreads) void ev_sddmm4_kernel(const int32_t* __re
 #pragma unroll
         for (int e = 0; e < EPG; ++e) {
             const int64_t p = p0 + e < nnzp ? p0 + e : nnzp - 1;
-            ri[e] = row[p];
-            ci[e] = col[p];
+            ri[e] = (int)row[p];
+            ci[e] = (int)col[p];
         }
         float acc[EPG];
 #pragma unroll
@@ -587,7 +592,8 @@ int lanes_for_batch(int B) {
 
 
 int launch_ev_hop(const int32_t* rowptr, const int32_t* col, const int32_t* vidx, const float* wedge, const float* in, const float* add,
-                  float* out, int N, int B, int G, int C, int K1, int kidx, int64_t nnzp, int in_div, int add_div, hipStream_t st) {
+                  float* out, int N, int B, int G, int C, int K1, int kidx, int64_t nnzp, int in_div, int add_div, hipStream_t st,
+                  const uint16_t* col16 = nullptr) {
     const int64_t NB = (int64_t)N * B, CNB = (int64_t)C * NB;
     const int lbw = lanes_for_batch(B);
     const int rpw = std::max(kRowsPerWG, kThreads / lbw);  // rows per workgroup (RPW of ev_hop_lds_kernel)
@@ -601,8 +607,12 @@ int launch_ev_hop(const int32_t* rowptr, const int32_t* col, const int32_t* vidx
         const int64_t nblk4 = (int64_t)((C + 7) / 8) * 8 * nrb4;
         if (nblk4 < (int64_t)INT32_MAX) {
 #define GF_EVHOP4(LQV)                                                                                                        \
-    hipLaunchKernelGGL((ev_hop_lds4_kernel<LQV>), dim3((unsigned)nblk4), dim3(kThreads), 0, st, rowptr, col, vidx, wedge, in, add, out, \
-                       N, B, G, K1, kidx, nnzp, in_div, add_div, nrb4, C)
+    if (col16 && g_tune.evgf_idx16)                                                                                           \
+        hipLaunchKernelGGL((ev_hop_lds4_kernel<LQV, uint16_t>), dim3((unsigned)nblk4), dim3(kThreads), 0, st, rowptr, col16, vidx, wedge, in, \
+                           add, out, N, B, G, K1, kidx, nnzp, in_div, add_div, nrb4, C);                                      \
+    else                                                                                                                      \
+        hipLaunchKernelGGL((ev_hop_lds4_kernel<LQV, int32_t>), dim3((unsigned)nblk4), dim3(kThreads), 0, st, rowptr, col, vidx, wedge, in, \
+                           add, out, N, B, G, K1, kidx, nnzp, in_div, add_div, nrb4, C)
             switch (lq) {
                 case 1: GF_EVHOP4(1); break;
                 case 2: GF_EVHOP4(2); break;
@@ -708,6 +718,11 @@ extern "C" int gf_ev_plan_create(int32_t n, int64_t nnzp, const int32_t* rowptr,
             (rc = upload_vec(row, &pl->row, pl->device_bytes)) == GF_OK && (rc = upload_vec(trp, &pl->t_rowptr, pl->device_bytes)) == GF_OK &&
             (rc = upload_vec(tci, &pl->t_col, pl->device_bytes)) == GF_OK)
             rc = upload_vec(tvi, &pl->t_vidx, pl->device_bytes);
+        if (rc == GF_OK && n <= 65535) {
+            std::vector<uint16_t> c16(ci.begin(), ci.end()), r16(row.begin(), row.end()), t16(tci.begin(), tci.end());
+            if ((rc = upload_vec(c16, &pl->col16, pl->device_bytes)) == GF_OK && (rc = upload_vec(r16, &pl->row16, pl->device_bytes)) == GF_OK)
+                rc = upload_vec(t16, &pl->t_col16, pl->device_bytes);
+        }
     } catch (const std::bad_alloc&) {
         gf_set_error("gf_ev_plan_create: out of host memory");
         rc = GF_ERR_NOMEM;
@@ -723,6 +738,8 @@ extern "C" int gf_ev_plan_create(int32_t n, int64_t nnzp, const int32_t* rowptr,
 extern "C" int gf_ev_plan_destroy(gf_ev_plan* pl) {
     if (!pl) return GF_OK;
     for (int32_t* p : {pl->rowptr, pl->col, pl->row, pl->t_rowptr, pl->t_col, pl->t_vidx})
+        if (p) (void)hipFree(p);
+    for (uint16_t* p : {pl->col16, pl->row16, pl->t_col16})
         if (p) (void)hipFree(p);
     delete pl;
     return GF_OK;
@@ -762,7 +779,7 @@ extern "C" int gf_evgf_forward(const gf_ev_plan* plan, const float* x, const flo
     GF_LAUNCH_CHECK("ev_tap0_kernel");
     for (int k = 1; k < K; ++k) {
         rc = launch_ev_hop(plan->rowptr, plan->col, nullptr, wedge, V + (int64_t)(k - 1) * CNB, nullptr, V + (int64_t)k * CNB, N, B,
-                           G, C, K - 1, k - 1, plan->nnzp, 1, 1, st);
+                           G, C, K - 1, k - 1, plan->nnzp, 1, 1, st, plan->col16);
         if (rc != GF_OK) return rc;
     }
     const int64_t FNB = (int64_t)F * NB;
@@ -819,8 +836,12 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
                 const int lq = lanes_for_batch(B / 4);
                 const unsigned grid4 = sddmm_grid(lq);
 #define GF_SDDMM4(LQV)                                                                                                        \
-    hipLaunchKernelGGL((ev_sddmm4_kernel<LQV>), dim3(grid4), dim3(kThreads), 0, st, plan->row, plan->col, Ucur,                \
-                       V + (int64_t)(k - 1) * CNB, dwedge, N, B, G, K - 1, k - 1, plan->nnzp, udiv, (int64_t)C)
+    if (plan->col16 && g_tune.evgf_idx16)                                                                                     \
+        hipLaunchKernelGGL((ev_sddmm4_kernel<LQV, uint16_t>), dim3(grid4), dim3(kThreads), 0, st, plan->row16, plan->col16, Ucur, \
+                           V + (int64_t)(k - 1) * CNB, dwedge, N, B, G, K - 1, k - 1, plan->nnzp, udiv, (int64_t)C);          \
+    else                                                                                                                      \
+        hipLaunchKernelGGL((ev_sddmm4_kernel<LQV, int32_t>), dim3(grid4), dim3(kThreads), 0, st, plan->row, plan->col, Ucur,   \
+                           V + (int64_t)(k - 1) * CNB, dwedge, N, B, G, K - 1, k - 1, plan->nnzp, udiv, (int64_t)C)
                 switch (lq) {
                     case 1: GF_SDDMM4(1); break;
                     case 2: GF_SDDMM4(2); break;
@@ -852,7 +873,7 @@ extern "C" int gf_evgf_backward(const gf_ev_plan* plan, const float* dy, const f
         }
         if (k > 1 || dwdiag || dx) {  // u_{k-1} = Phi_k^T u_k + dy_f
             rc = launch_ev_hop(plan->t_rowptr, plan->t_col, plan->t_vidx, wedge, Ucur, Dyt, Ubuf[pp], N, B, G, C, K - 1, k - 1,
-                               plan->nnzp, udiv, G, st);
+                               plan->nnzp, udiv, G, st, plan->t_col16);
             if (rc != GF_OK) return rc;
             Ucur = Ubuf[pp];
             udiv = 1;

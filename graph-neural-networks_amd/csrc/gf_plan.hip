@@ -80,6 +80,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_rotate")) g_tune.panel_rotate = value;
     else if (!strcmp(key, "panel_chain")) g_tune.panel_chain = value;
     else if (!strcmp(key, "evgf_generic")) g_tune.evgf_generic = value;
+    else if (!strcmp(key, "evgf_idx16")) g_tune.evgf_idx16 = value;
     else {
         gf_set_error("gf_tune: unknown key '%s'", key);
         return GF_ERR_ARG;
