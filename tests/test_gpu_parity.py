@@ -89,6 +89,34 @@ def test_spmm_hop_against_scipy(W, B):
         assert relerr(out.cpu().numpy(), want) < 2e-6, (op, W, B)
 
 
+@pytest.mark.parametrize("uniform", [0, 1])
+@pytest.mark.parametrize("W,B", [(32, 5), (32, 40), (8, 17), (64, 3), (128, 2), (4, 9)])
+def test_spmm_hop_uniform_values_column_only_stream(W, B, uniform, pipeline_knob):
+    """A GSO whose stored values are all equal (S = A / lambda_max of an unweighted graph): the node-major kernel reads a column-only
+    entry stream and scales the row sums once; with the knob off it reads (column, value) pairs.  Both against scipy in float64;
+    hub rows, empty rows and a ragged last slice included."""
+    L = _lib.lib()
+    n = 1003
+    rng = np.random.RandomState(W + B)
+    A = sp.random(n, n, density=0.01, random_state=rng, format="lil")
+    A[5, :] = 1.0                      # a hub row (longer than one ring slot of the kernel)
+    A[:, 9] = 1.0
+    A[3, :] = 0
+    A[:, 2] = 0
+    A = sp.csr_matrix(A)
+    A.data[:] = 0.37
+    X = rng.randn(B, n, W).astype(np.float32)
+    Xt = cu(X)
+    pipeline_knob(panel_uniform=uniform)
+    gso = SparseGSO([A])               # (owns the plans: keep it alive)
+    plans = gso.plans(DEV)
+    for op, M in ((0, A.T.tocsr()), (1, A)):
+        out = torch.full((B, n, W), float("nan"), device=DEV)
+        _lib.check(L.gf_spmm_hop(plans[0], op, Xt.data_ptr(), out.data_ptr(), B, W, stream()))
+        want = np.stack([M.astype(np.float64) @ X[b].astype(np.float64) for b in range(B)])
+        assert relerr(out.cpu().numpy(), want) < 2e-6, (uniform, op, W, B)
+
+
 def test_spmm_hop_skewed_degrees_and_long_rows():
     """Rows far longer than the 2048-entry LDS chunk, a power-law tail, and empty rows."""
     L = _lib.lib()
