@@ -140,6 +140,7 @@ struct gf_tuning {
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
     int spmm_ucap = 0;          // 0/16 = up to 16 gathers in flight per lane, 8 = up to 8 (fewer registers, more waves)
     int spmm_pf = -1;           // workgroups per tile that prefetch the next tile's gather panel into L2 (-1 = heuristic, 0 = off)
+    int spmm_group = 1;         // 1 = rows of large graphs scheduled in locality groups (set BEFORE gf_plan_create)
     int spmm_load = 0;          // gather loads: 0 = plain, 1 = non-temporal
     int spmm_store = 2;         // output rows: 0 = plain stores, 1 = write-through (sc1), 2 = non-temporal
     int contract_generic = 0;   // 1 = force the generic contraction kernel
