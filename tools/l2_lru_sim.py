@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """L2 hit rate of the node-major hop's gather stream at config 4, simulated: an LRU cache of 4 MiB / 128 B rows over the sequence of source rows
 of one batch entry (destination rows in order).  Natural order: 0.32 (PMC on the production kernel: 0.31); after reverse Cuthill-McKee: 0.39 -- an ER
-graph has no locality for a bandwidth-reducing order to find.  What the library does since round 2 (locality_groups in gf_plan.hip: balanced
-label propagation, rows only): 0.38 simulated, 0.37 measured.  CPU only: python tools/l2_lru_sim.py"""
+graph has no locality for a bandwidth-reducing order to find.  What the library does since round 2 (locality_groups in gf_plan.hip: rows only --
+label propagation alone 0.38 simulated / 0.37 measured; with the spectral start 0.44 simulated).  CPU only: python tools/l2_lru_sim.py"""
 import sys, numpy as np, scipy.sparse as sp
 from scipy.sparse.csgraph import reverse_cuthill_mckee
 import os
