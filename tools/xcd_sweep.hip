@@ -1,0 +1,522 @@
+// xcd_sweep.hip -- go / no-go prototype for the node-major hop at N = 1e5 (config 4): "XCD-synchronous source sweep".
+//     hipcc -O3 --offload-arch=gfx950 tools/xcd_sweep.hip -o tools/xcd_sweep && tools/xcd_sweep [key=value ...]
+//
+// What round 2 left open ("next round" 1d): the gathers of a hop (nnz * B rows of 128 bytes = 16.4 GB) miss the 4 MiB L2
+// because a batch entry's rows are 12.8 MB; tools/l2window_bound.hip showed that source-sorted edge streams alone form only half a
+// window (hit rate 0.45) and that XCD BARRIERS cost more than they give (they serialise the store / zero / gather phases).
+// This prototype keeps that kernel's mechanics (destination tile accumulators in LDS, each 8-lane group owns rows and walks their
+// entries sorted by source, LDS read-modify-write, fixed order, no atomics) and changes what decides the hit rate:
+//   * PERSISTENT workgroups (LDS-limited residency: exactly wgPerCU per CU), an XCD walks its batch entries one at a time, P passes
+//     per entry, one destination tile per workgroup and pass;
+//   * padding is spread EVENLY over a stream (entry with source j sits near slot j * L / N), so "step s" means "sources around s*N/L"
+//     for every lane group of every workgroup, whatever its list length;
+//   * BOUNDED LAG instead of barriers: every workgroup publishes its step counter (one write-through dword), every wave polls the
+//     XCD's counters one step ahead of use (a 256/512-byte read) and only a wave that is more than `lag` steps ahead of the slowest
+//     workgroup waits (bounded spin: correctness never depends on the protocol, a broken protocol costs time only);
+//   * two COHORTS half a sweep apart (optional), so that one workgroup of a CU stores its tile while the other gathers;
+//   * optional FIRST-TOUCH PREFETCH: every wave reads one coalesced KB of the source block `pf` steps ahead, so the first gather of a
+//     row finds it in L2 (the fabric carries the same bytes, as full sequential lines instead of random demand misses).
+// Compared against: tools/l2window_bound (1.73 ms), the library's spmm_sell_kernel (1.60 ms), the algorithmic bound (0.41 ms).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+constexpr unsigned kPad = 0xffffffffu;
+constexpr int kWaves = 8;         // waves per workgroup
+constexpr int kSlots = 128;       // progress slots per XCD (>= workgroups per XCD)
+constexpr int kMaxSpin = 3000;
+
+__device__ __forceinline__ unsigned ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned wave_min(unsigned v) {
+#pragma unroll
+    for (int m = 32; m; m >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, m));
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// stream[((tile * kWaves + wave) * L4 + s) * 8 + lg] : u32x4 = 4 consecutive slots of lane group lg; slot = dest_local << 17 | src, or kPad
+// ACCUM: 0 = gather only, 1 = read-modify-write per entry in program order, 2 = the 4 entries of a word have distinct destinations
+//        (plan-time guarantee): 4 LDS reads, 4 adds, 4 LDS writes
+template <int ACCUM, int MINW>
+__global__ __launch_bounds__(kWaves * 64, MINW) void sweep_kernel(const u32x4* __restrict__ stream, const float* __restrict__ X,
+                                                                  float* __restrict__ Y, int N, int D, int L4, int P, int wgPerXcd,
+                                                                  int nTiles, int entriesPerXcd, int B, float uval,
+                                                                  unsigned* __restrict__ prog, unsigned base, int lag, int shift,
+                                                                  int pfAhead, int rowsPerStep, unsigned* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float4 accs[];   // [D + 8] rows of 32 floats (8 trash rows for padding slots)
+    __shared__ unsigned s_prog[kWaves];
+    f32x4* acc4 = reinterpret_cast<f32x4*>(accs);
+    volatile unsigned* vprog = s_prog;
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane & 7, lg = lane >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    unsigned* slots = prog + xcd * kSlots;
+    unsigned g = base + ((j & 1) ? (unsigned)shift : 0u);
+    unsigned pv0 = base, pv1 = base;
+    unsigned waited = 0, gaveup = 0;
+
+    auto publish = [&](unsigned gv) {
+        if (lane == 0) vprog[wave] = gv;
+        unsigned v = vprog[lane & (kWaves - 1)];
+        v = min(v, (unsigned)__shfl_xor((int)v, 1));
+        v = min(v, (unsigned)__shfl_xor((int)v, 2));
+        v = min(v, (unsigned)__shfl_xor((int)v, 4));
+        if (lane == 0) st_sc1(slots + j, v);
+    };
+    auto issue_poll = [&]() {
+        pv0 = ld_sc1(slots + lane);
+        pv1 = ld_sc1(slots + 64 + lane);
+    };
+
+    for (int i = tid; i < (D + 8) * 8; i += kWaves * 64) acc4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (lane == 0) vprog[wave] = g;
+    __syncthreads();
+    publish(g);
+    issue_poll();
+    f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+
+    for (int e = 0; e < entriesPerXcd; ++e) {
+        const int b = e * 8 + xcd;
+        for (int p = 0; p < P; ++p) {
+            const int tile = p * wgPerXcd + j;
+            if (tile >= nTiles || b >= B) {   // nothing to do in this pass: do not hold the others back
+                g += (unsigned)L4;
+                publish(g);
+                continue;
+            }
+            const float* Xb = X + (int64_t)b * N * 32;
+            const u32x4* st = stream + ((int64_t)(tile * kWaves + wave) * L4) * 8 + lg;
+            u32x4 ew = st[0];
+            for (int s = 0; s < L4; ++s) {
+                const u32x4 en = st[(int64_t)(s + 1 < L4 ? s + 1 : s) * 8];
+                if (lag >= 0) {   // the poll was issued a step ago: its value is (conservatively) old
+                    unsigned fl = wave_min(min(pv0, pv1));
+                    int guard = 0;
+                    while ((int)(g - fl) > lag) {
+                        if (++guard > kMaxSpin) { lag = -1; gaveup = 1; break; }
+                        __builtin_amdgcn_s_sleep(8);
+                        issue_poll();
+                        fl = wave_min(min(pv0, pv1));
+                    }
+                    waited += (unsigned)guard;
+                }
+                const unsigned ee[4] = {ew.x, ew.y, ew.z, ew.w};
+                f32x4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    x[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (ee[u] != kPad) x[u] = *reinterpret_cast<const f32x4*>(Xb + ((ee[u] & 0x1ffffu) * 32u + (unsigned)sub * 4u));
+                }
+                f32x4 pf = {0.f, 0.f, 0.f, 0.f};
+                if (pfAhead > 0) {
+                    const int r0 = (s + pfAhead) * rowsPerStep;
+                    const int row = r0 + (j * kWaves + wave) * 8 + lg;
+                    if (s + pfAhead < L4 && row < min(N, r0 + rowsPerStep))
+                        pf = *reinterpret_cast<const f32x4*>(Xb + ((unsigned)row * 32u + (unsigned)sub * 4u));
+                }
+                if (ACCUM == 2) {
+                    int d[4];
+                    f32x4 a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d[u] = (ee[u] != kPad ? (int)(ee[u] >> 17) : D + lg) * 8 + sub;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = acc4[d[u]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] += x[u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc4[d[u]] = a[u];
+                } else if (ACCUM == 1) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ee[u] != kPad) acc4[(int)(ee[u] >> 17) * 8 + sub] += x[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sink += x[u];
+                }
+                sink += pf;
+                g += 1u;
+                if (lag >= 0 || gaveup) {
+                    publish(g);
+                    if (lag >= 0) issue_poll();
+                }
+                ew = en;
+            }
+            __syncthreads();
+            float* Yb = Y + (int64_t)b * N * 32 + (int64_t)tile * D * 32;
+            const int rows = min(D, N - tile * D);
+            for (int i = tid; i < rows * 8; i += kWaves * 64) {
+                f32x4 v = acc4[i];
+                v *= uval;
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Yb) + i);
+                acc4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+        }
+    }
+    publish(0x7fffff00u);   // finished: never the minimum again (the host resets the slots before the next launch)
+    if (sink.x == 1.2345e30f && sink.y == -7.f) Y[0] = sink.z + sink.w;
+    if (stats && lane == 0) {
+        atomicAdd(stats + 0, waited);
+        atomicAdd(stats + 1, gaveup);
+    }
+}
+
+struct Graph {
+    int N;
+    std::vector<std::vector<int>> nbr;   // nbr[dest] = sorted sources
+    int64_t nnz;
+};
+
+static Graph make_er(int N, int64_t nnzTarget, unsigned seed) {
+    Graph G;
+    G.N = N;
+    G.nbr.resize(N);
+    std::mt19937 rng(seed);
+    std::uniform_int_distribution<int> pick(0, N - 1);
+    for (int64_t k = 0; k < nnzTarget / 2; ++k) {
+        const int i = pick(rng), j = pick(rng);
+        if (i == j) continue;
+        G.nbr[i].push_back(j);
+        G.nbr[j].push_back(i);
+    }
+    G.nnz = 0;
+    for (auto& v : G.nbr) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        G.nnz += (int64_t)v.size();
+    }
+    return G;
+}
+
+struct Streams {
+    int D, P, wgPerXcd, nTiles, L4;
+    double fill;
+    std::vector<unsigned> words;
+};
+
+// distinct = 1: the 4 slots of a word never hold the same destination twice (ACCUM == 2 may batch its LDS reads)
+static Streams build_streams(const Graph& G, int wgPerCU, int P, bool distinct) {
+    Streams S;
+    const int N = G.N;
+    S.wgPerXcd = 32 * wgPerCU;
+    S.P = P;
+    S.D = (N + P * S.wgPerXcd - 1) / (P * S.wgPerXcd);
+    S.nTiles = (N + S.D - 1) / S.D;
+    const int D = S.D, nLG = kWaves * 8;
+    // rows of a tile -> lane groups: even local rows to lane groups lg in {0,1,4,5}, odd ones to {2,3,6,7} (the two rows a
+    // ds_read_b128 service group touches then lie in different bank halves), dealt by degree, boustrophedon
+    std::vector<std::vector<unsigned>> lists((size_t)S.nTiles * nLG);
+    int maxLen = 0;
+    for (int t = 0; t < S.nTiles; ++t) {
+        for (int par = 0; par < 2; ++par) {
+            std::vector<int> rows;
+            for (int dl = par; dl < D && t * D + dl < N; dl += 2) rows.push_back(dl);
+            std::stable_sort(rows.begin(), rows.end(), [&](int a, int c) { return G.nbr[t * D + a].size() > G.nbr[t * D + c].size(); });
+            std::vector<int> groups;   // the 32 lane groups of this parity
+            for (int w = 0; w < kWaves; ++w)
+                for (int lgx : {0, 1, 4, 5}) groups.push_back(w * 8 + lgx + 2 * par);
+            const int ng = (int)groups.size();
+            for (size_t k = 0; k < rows.size(); ++k) {
+                const int round = (int)(k / ng), pos = (int)(k % ng);
+                const int q = groups[(round & 1) ? ng - 1 - pos : pos];
+                for (int src : G.nbr[t * D + rows[k]]) lists[(size_t)t * nLG + q].push_back(((unsigned)rows[k] << 17) | (unsigned)src);
+            }
+        }
+        for (int q = 0; q < nLG; ++q) {
+            auto& li = lists[(size_t)t * nLG + q];
+            std::sort(li.begin(), li.end(), [](unsigned a, unsigned c) { return (a & 0x1ffffu) < (c & 0x1ffffu); });
+            maxLen = std::max(maxLen, (int)li.size());
+        }
+    }
+    // even placement: entry with source j near slot j * alpha * (Lslots - 4) / N, never before its predecessor; alpha = the largest
+    // of 1, 0.96, 0.92, ... for which the list fits (a list that is dense near the end runs slightly ahead of its position)
+    for (int L4 = (maxLen + 3) / 4 + 1;; ++L4) {
+        const int Ls = L4 * 4;
+        std::vector<unsigned> words((size_t)S.nTiles * kWaves * L4 * 8 * 4, kPad);
+        bool ok = true;
+        std::vector<int> slotOf;
+        for (int t = 0; t < S.nTiles && ok; ++t)
+            for (int q = 0; q < nLG && ok; ++q) {
+                const auto& li = lists[(size_t)t * nLG + q];
+                const int w = q / 8, lgx = q % 8;
+                bool placed = false;
+                const int n = (int)li.size();
+                for (int ai = 25; ai >= 0 && !placed; --ai) {   // word by word: up to 4 pending entries whose nominal slot has come, distinct
+                    slotOf.assign(n, -1);                      // destinations inside a word (look-ahead of 12 pending entries)
+                    int head = 0, left = n;
+                    for (int wd = 0; wd < L4 && left > 0; ++wd) {
+                        unsigned dests[4];
+                        int c = 0;
+                        for (int k = head, seen = 0; k < n && c < 4 && seen < 12; ++k) {
+                            if (slotOf[k] >= 0) continue;
+                            ++seen;
+                            if ((int64_t)(li[k] & 0x1ffffu) * (Ls - 4) * ai / 25 / N > wd * 4 + 3) break;
+                            bool clash = false;
+                            if (distinct)
+                                for (int u = 0; u < c; ++u) clash |= dests[u] == (li[k] >> 17);
+                            if (clash) continue;
+                            dests[c] = li[k] >> 17;
+                            slotOf[k] = wd * 4 + c++;
+                            --left;
+                        }
+                        while (head < n && slotOf[head] >= 0) ++head;
+                    }
+                    if (left > 0) continue;
+                    placed = true;
+                    for (int k = 0; k < n; ++k)
+                        words[((((size_t)(t * kWaves + w) * L4 + slotOf[k] / 4) * 8 + lgx) * 4) + (slotOf[k] & 3)] = li[k];
+                }
+                if (!placed) ok = false;
+            }
+        if (ok) {
+            S.L4 = L4;
+            S.words.swap(words);
+            break;
+        }
+    }
+    S.fill = (double)G.nnz / ((double)S.nTiles * nLG * S.L4 * 4);
+    return S;
+}
+
+int main(int argc, char** argv) {
+    int N = 100000, B = 128, iters = 5, only = -1, hostcheck = 0;
+    int64_t nnzTarget = 1000000;
+    std::vector<int> wgs = {2, 3}, lags = {-1, 1, 2, 3, 4, 6}, shifts = {0, 1}, pfs = {0, 1, 2}, accums = {2};
+    int P = 3;
+    auto parse_list = [](const char* s) {
+        std::vector<int> v;
+        for (const char* p = s; *p;) {
+            v.push_back(atoi(p));
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        return v;
+    };
+    for (int a = 1; a < argc; ++a) {
+        std::string kv = argv[a];
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos) continue;
+        const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+        if (k == "N") N = atoi(v.c_str());
+        else if (k == "B") B = atoi(v.c_str());
+        else if (k == "nnz") nnzTarget = atoll(v.c_str());
+        else if (k == "iters") iters = atoi(v.c_str());
+        else if (k == "P") P = atoi(v.c_str());
+        else if (k == "wg") wgs = parse_list(v.c_str());
+        else if (k == "lag") lags = parse_list(v.c_str());
+        else if (k == "shift") shifts = parse_list(v.c_str());
+        else if (k == "pf") pfs = parse_list(v.c_str());
+        else if (k == "accum") accums = parse_list(v.c_str());
+        else if (k == "only") only = atoi(v.c_str());
+        else if (k == "hostcheck") hostcheck = atoi(v.c_str());
+    }
+    Graph G = make_er(N, nnzTarget, 0);
+    const float uval = 0.1f;
+    const double algBytes = 2.0 * B * N * 32 * 4 + G.nnz * 8.0 + (N + 1) * 4.0;
+    printf("ER graph N=%d nnz=%lld, B=%d batch entries x 32 columns (row = 128 B); algorithmic bytes/hop = %.3f GB (0.41 ms at 8 TB/s)\n", N,
+           (long long)G.nnz, B, algBytes / 1e9);
+
+    if (hostcheck) {   // no GPU needed: interpret the streams on the host (one column) and compare with the direct sums
+        for (int wgPerCU : wgs)
+            for (int distinct = 1; distinct >= 0; --distinct) {
+                Streams S = build_streams(G, wgPerCU, P, distinct != 0);
+                std::vector<double> xs(N), y(N, 0.0), yr(N, 0.0);
+                for (int i = 0; i < N; ++i) xs[i] = std::sin(0.001 * i) + 1.0;
+                int64_t cnt = 0, clash = 0;
+                double posErr = 0.0;
+                for (int t = 0; t < S.nTiles; ++t)
+                    for (int w = 0; w < kWaves; ++w)
+                        for (int s = 0; s < S.L4; ++s)
+                            for (int lgx = 0; lgx < 8; ++lgx) {
+                                const unsigned* wd = &S.words[((((size_t)(t * kWaves + w) * S.L4 + s) * 8 + lgx) * 4)];
+                                for (int u = 0; u < 4; ++u) {
+                                    if (wd[u] == kPad) continue;
+                                    const int dl = (int)(wd[u] >> 17), src = (int)(wd[u] & 0x1ffffu);
+                                    if ((dl & 1) != ((lgx >> 1) & 1)) { printf("parity violation\n"); return 1; }
+                                    y[(size_t)t * S.D + dl] += xs[src];
+                                    ++cnt;
+                                    posErr = std::max(posErr, std::fabs((double)src / N - (double)(s * 4 + u) / (S.L4 * 4)));
+                                    for (int u2 = 0; u2 < u; ++u2) if (wd[u2] != kPad && (wd[u2] >> 17) == (unsigned)dl) ++clash;
+                                }
+                            }
+                // LRU model of one XCD's L2 over one batch entry (P passes): every workgroup at step s + offset(wg), offsets uniform in
+                // [0, lagSim]; capacity in 128-byte lines
+                for (int lagSim : {0, 2, 4, 8})
+                    for (int capLines : {16384, 24576, 32768}) {
+                        std::vector<int> last(N, -1);          // last access time (in accesses)
+                        std::vector<int> order;                // access sequence
+                        std::mt19937 r2(7);
+                        for (int p = 0; p < S.P; ++p) {
+                            std::vector<int> off(S.wgPerXcd);
+                            for (auto& o : off) o = lagSim ? (int)(r2() % (unsigned)(lagSim + 1)) : 0;
+                            for (int s = 0; s < S.L4 + lagSim; ++s)
+                                for (int jj = 0; jj < S.wgPerXcd; ++jj) {
+                                    const int t = p * S.wgPerXcd + jj, ss = s - off[jj];
+                                    if (t >= S.nTiles || ss < 0 || ss >= S.L4) continue;
+                                    for (int w = 0; w < kWaves; ++w)
+                                        for (int lgx = 0; lgx < 8; ++lgx) {
+                                            const unsigned* wd = &S.words[((((size_t)(t * kWaves + w) * S.L4 + ss) * 8 + lgx) * 4)];
+                                            for (int u = 0; u < 4; ++u)
+                                                if (wd[u] != kPad) order.push_back((int)(wd[u] & 0x1ffffu));
+                                        }
+                                }
+                        }
+                        // exact LRU via reuse distance is costly; approximate with "distinct lines since last access" using a
+                        // time-stamped Fenwick tree
+                        const int M = (int)order.size();
+                        std::vector<int> fen(M + 1, 0);
+                        auto add = [&](int i, int v) { for (++i; i <= M; i += i & -i) fen[i] += v; };
+                        auto sum = [&](int i) { int r = 0; for (++i; i > 0; i -= i & -i) r += fen[i]; return r; };
+                        int64_t hits = 0;
+                        for (int i = 0; i < M; ++i) {
+                            const int a = order[i];
+                            if (last[a] >= 0) {
+                                const int distinctSince = sum(i - 1) - sum(last[a]);
+                                if (distinctSince < capLines) ++hits;
+                                add(last[a], -1);
+                            }
+                            add(i, 1);
+                            last[a] = i;
+                        }
+                        printf("   LRU model: lag %d steps, %5d lines (%.1f MB): hit rate %.3f\n", lagSim, capLines, capLines * 128 / 1048576.0, (double)hits / M);
+                    }
+                double err = 0.0;
+                for (int i = 0; i < N; ++i) {
+                    for (int src : G.nbr[i]) yr[i] += xs[src];
+                    err = std::max(err, std::fabs(yr[i] - y[i]));
+                }
+                printf("hostcheck wgPerCU=%d distinct=%d: D=%d tiles=%d L4=%d fill=%.3f entries=%lld (nnz %lld) same-word clashes=%lld maxerr=%.2e max|src/N - slot/L|=%.3f\n", wgPerCU,
+                       distinct, S.D, S.nTiles, S.L4, S.fill, (long long)cnt, (long long)G.nnz, (long long)clash, err, posErr);
+            }
+        return 0;
+    }
+    float *X, *Y;
+    CK(hipMalloc(&X, (size_t)B * N * 32 * 4));
+    CK(hipMalloc(&Y, (size_t)B * N * 32 * 4));
+    std::vector<float> hx((size_t)N * 32);
+    {
+        std::mt19937 rng(1);
+        for (auto& v : hx) v = (float)((rng() & 0xffff) / 65536.0 - 0.5);
+        std::vector<float> hb(hx.size());
+        for (int b = 0; b < B; ++b) {   // entry b = (1 + b / 256) * signal (exact in fp32 for these values up to rounding of the product)
+            const float sc = 1.0f + (float)b / 256.0f;
+            for (size_t i = 0; i < hx.size(); ++i) hb[i] = hx[i] * sc;
+            CK(hipMemcpy(X + (size_t)b * N * 32, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    unsigned *prog, *stats;
+    CK(hipMalloc(&prog, 8 * kSlots * 4));
+    CK(hipMalloc(&stats, 16));
+    int cfg = 0;
+    for (int wgPerCU : wgs) {
+        for (int distinct = 1; distinct >= 0; --distinct) {
+            bool need = false;
+            for (int ac : accums) need |= (distinct ? ac == 2 : ac != 2);
+            if (!need) continue;
+            Streams S = build_streams(G, wgPerCU, P, distinct != 0);
+            printf("# wgPerCU=%d P=%d D=%d tiles=%d L4=%d (steps per sweep) fill=%.3f stream=%.1f MB lds=%d B distinct=%d\n", wgPerCU, S.P, S.D, S.nTiles, S.L4,
+                   S.fill, S.words.size() * 4 / 1e6, (S.D + 8) * 128, distinct);
+            unsigned* dst;
+            CK(hipMalloc(&dst, S.words.size() * 4));
+            CK(hipMemcpy(dst, S.words.data(), S.words.size() * 4, hipMemcpyHostToDevice));
+            const int entriesPerXcd = (B + 7) / 8;
+            const size_t lds = (size_t)(S.D + 8) * 128;
+            const int rowsPerStep = (N + S.L4 - 1) / S.L4;
+            for (int ac : accums) {
+                if ((ac == 2) != (distinct != 0)) continue;
+                for (int lag : lags)
+                    for (int sh : shifts)
+                        for (int pf : pfs) {
+                            const int myc = cfg++;
+                            if (only >= 0 && myc != only) continue;
+                            if (lag < 0 && sh != 0) continue;   // the cohort offset only exists through the lag protocol
+                            const int shift = sh ? S.L4 / 2 : 0;
+                            const unsigned span = (unsigned)(entriesPerXcd * S.P * S.L4 + shift + 64);
+                            auto launch = [&](unsigned epoch) {
+                                std::vector<unsigned> init(8 * kSlots, 0xffffffffu);
+                                for (int x = 0; x < 8; ++x)
+                                    for (int jj = 0; jj < S.wgPerXcd; ++jj) init[x * kSlots + jj] = epoch * span;
+                                CK(hipMemcpyAsync(prog, init.data(), init.size() * 4, hipMemcpyHostToDevice, 0));
+                                CK(hipMemsetAsync(stats, 0, 16, 0));
+                                CK(hipStreamSynchronize(0));
+                                return epoch * span;
+                            };
+                            auto run = [&](unsigned base) {
+#define LAUNCH(AC, MW) hipLaunchKernelGGL((sweep_kernel<AC, MW>), dim3(8 * S.wgPerXcd), dim3(kWaves * 64), lds, 0, (const u32x4*)dst, X, Y, N, S.D, \
+                                          S.L4, S.P, S.wgPerXcd, S.nTiles, entriesPerXcd, B, uval, prog, base, lag, shift, pf, rowsPerStep, stats)
+                                if (wgPerCU >= 3) {
+                                    if (ac == 2) LAUNCH(2, 6); else if (ac == 1) LAUNCH(1, 6); else LAUNCH(0, 6);
+                                } else {
+                                    if (ac == 2) LAUNCH(2, 4); else if (ac == 1) LAUNCH(1, 4); else LAUNCH(0, 4);
+                                }
+                            };
+                            static bool attr = false;
+                            if (!attr) {
+                                attr = true;
+                                CK(hipFuncSetAttribute((const void*)sweep_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                CK(hipFuncSetAttribute((const void*)sweep_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                CK(hipFuncSetAttribute((const void*)sweep_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                CK(hipFuncSetAttribute((const void*)sweep_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                CK(hipFuncSetAttribute((const void*)sweep_kernel<1, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                CK(hipFuncSetAttribute((const void*)sweep_kernel<0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            }
+                            CK(hipMemset(Y, 0xff, (size_t)B * N * 32 * 4));
+                            unsigned epoch = 1;
+                            run(launch(epoch++));
+                            CK(hipDeviceSynchronize());
+                            CK(hipGetLastError());
+                            hipEvent_t e0, e1;
+                            CK(hipEventCreate(&e0));
+                            CK(hipEventCreate(&e1));
+                            float msTot = 0.f;
+                            unsigned hstats[4] = {0, 0, 0, 0};
+                            for (int it = 0; it < iters; ++it) {
+                                const unsigned base = launch(epoch++);
+                                CK(hipEventRecord(e0));
+                                run(base);
+                                CK(hipEventRecord(e1));
+                                CK(hipEventSynchronize(e1));
+                                float ms;
+                                CK(hipEventElapsedTime(&ms, e0, e1));
+                                msTot += ms;
+                            }
+                            CK(hipMemcpy(hstats, stats, 16, hipMemcpyDeviceToHost));
+                            const float ms = msTot / iters;
+                            double err = -1.0;
+                            if (ac) {
+                                err = 0.0;
+                                for (int b : {0, B - 1}) {
+                                    std::vector<float> hy((size_t)N * 32);
+                                    CK(hipMemcpy(hy.data(), Y + (size_t)b * N * 32, hy.size() * 4, hipMemcpyDeviceToHost));
+                                    const double sc = 1.0 + b / 256.0;
+                                    for (int row = 0; row < N; row += 7)
+                                        for (int c = 0; c < 32; ++c) {
+                                            double s = 0.0;
+                                            for (int src : G.nbr[row]) s += (double)(hx[(size_t)src * 32 + c] * (float)sc);
+                                            err = std::max(err, std::fabs(s * uval - hy[(size_t)row * 32 + c]));
+                                        }
+                                }
+                            }
+                            printf("cfg %d wg/CU=%d accum=%d lag=%d shift=%d pf=%d : %.3f ms/hop  %.1f %% of 8 TB/s  spins/wave=%.1f gaveup=%u  maxerr %.2e\n", myc,
+                                   wgPerCU, ac, lag, shift, pf, ms, algBytes / ms / 1e6 / 80.0, (double)hstats[0] / (8.0 * S.wgPerXcd * kWaves), hstats[1], err);
+                            fflush(stdout);
+                            CK(hipEventDestroy(e0));
+                            CK(hipEventDestroy(e1));
+                        }
+            }
+            CK(hipFree(dst));
+        }
+    }
+    return 0;
+}
