@@ -43,7 +43,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
 WORKLOADS = {
-    "cfg4": dict(kind="filter", graph="er", N=100_000, deg=10.0, B=128, G=32, F=32, K=5, steps=100, warmup=5, cpu_sample=6,
+    "cfg4": dict(kind="filter", graph="er", N=100_000, deg=10.0, B=128, G=32, F=32, K=5, steps=100, warmup=5, cpu_sample=32,
                  desc="ER N=100k nnz~1M, batch 128/GPU (1024 over 8 GPUs), K=5, F 32->32 (BASELINE configs[3], the north-star size)"),
     "cfg2": dict(kind="filter", graph="sbm", N=10_000, deg=10.0, B=256, G=32, F=32, K=5, steps=250, warmup=20, cpu_sample=64,
                  desc="SBM N=10k nnz~100k, batch 256/GPU, K=5, F 32->32 (BASELINE configs[1])"),
@@ -341,35 +341,62 @@ def _csr_t(A):
 
 
 def cpu_filter(w, wl, sample):
-    """The reference's own CPU path (dense S + matmul / cat / permute, oracle.graph_filter_step_dense) on `sample` batch entries
-    where dense S fits (N <= 20k), else the sparse-CSR restatement; all host cores."""
+    """CPU restatements of graphML.py:152-175 (fwd+bwd, fp32) on a bounded sample of the batch: every variant that can run is probed
+    on two batch entries, the FASTEST one is then timed on a sample sized for ~5 s and reported (`variant` says which; the probes of
+    the others are listed in `variants`).  Variants: the literal dense form (dense S fits: N <= 20k), the sparse-CSR restatement
+    through torch.sparse at several thread counts (all cores is rarely the fastest: the CSR product oversubscribes a 2-socket host),
+    and the scipy CSR restatement (one core)."""
     from oracle import lsigf_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    ncores = os.cpu_count() or 1
     wt, b = w.module.weight.detach().cpu(), w.module.bias.detach().cpu()
-    sample = min(sample, wl["B"])
-    xs = w.x.detach()[:sample].cpu()
-    N, K = wl["N"], wl["K"]
-    out = dict(cores=cores, kind="port", unit="edges*taps/s")
+    N, K, B = wl["N"], wl["K"], wl["B"]
+    xs = w.x.detach()[:min(B, max(2, sample))].cpu()
     St = _csr_t(w.A)
-    orc.graph_filter_step_sparse_torch(wt, b, St, xs[:2])
-    t0 = time.perf_counter()
-    orc.graph_filter_step_sparse_torch(wt, b, St, xs)
-    dt_sparse = time.perf_counter() - t0
-    out["sparse_port_value"] = sample * w.nnz * K / dt_sparse
+    variants = []
+
+    def torch_sparse(th):
+        def run(x):
+            torch.set_num_threads(th)
+            orc.graph_filter_step_sparse_torch(wt, b, St, x)
+        return run
+
+    def scipy_csr(x):
+        xn = x.numpy()
+        orc.lsigf_sparse(wt.numpy(), w.A, xn, b.numpy(), dtype=np.float32)
+        orc.lsigf_sparse_grads(wt.numpy(), w.A, xn, b.numpy(), np.ones((xn.shape[0], wt.shape[0], N), np.float32), dtype=np.float32)
+
+    cands = [(f"sparse-CSR restatement, torch.sparse_csr, {th} threads", th, torch_sparse(th))
+             for th in sorted({min(ncores, t) for t in (8, 16, 32, 64)} | {ncores})]
+    cands.append(("sparse-CSR restatement, scipy (analytic backward), 1 core", 1, scipy_csr))
     if N <= 20_000:                                           # dense S is N^2*4 bytes: 400 MB at N=10k, 40 GB at 100k
         S = torch.from_numpy(w.A.toarray().astype(np.float32))[None]
-        orc.graph_filter_step_dense(wt, b, S, xs[:2])          # warm-up
+
+        def dense(x):
+            torch.set_num_threads(ncores)
+            orc.graph_filter_step_dense(wt, b, S, x)
+        cands.append((f"literal dense restatement (the reference's own form), {ncores} threads", ncores, dense))
+    budget = time.perf_counter() + 12.0                        # probes stop here; the reported run adds ~5 s
+    best = None
+    for name, th, fn in cands:
+        if time.perf_counter() > budget:
+            break
+        fn(xs[:1])                                             # warm-up (thread pools, first-touch)
         t0 = time.perf_counter()
-        orc.graph_filter_step_dense(wt, b, S, xs)
+        fn(xs[:2])
         dt = time.perf_counter() - t0
-        out.update(value=sample * w.nnz * K / dt, seconds=round(dt, 3),
-                   sample=f"literal dense restatement of graphML.py:152-175 (fwd+bwd, fp32), {sample} of the batch's {wl['B']} entries")
-    else:
-        out.update(value=out["sparse_port_value"], seconds=round(dt_sparse, 3),
-                   sample=f"sparse-CSR CPU restatement of graphML.py:152-175 (dense S would be {N * N * 4 / 1e9:.0f} GB), fwd+bwd fp32, "
-                          f"{sample} of the batch's {wl['B']} entries")
-    return out
+        v = 2 * w.nnz * K / dt
+        variants.append(dict(variant=name, threads=th, value=v))
+        if best is None or v > best[3]:
+            best = (name, th, fn, v, dt / 2)
+    name, th, fn, _, per_entry = best
+    n = int(max(2, min(xs.shape[0], 5.0 / per_entry)))
+    t0 = time.perf_counter()
+    fn(xs[:n])
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(ncores)
+    return dict(value=n * w.nnz * K / dt, unit="edges*taps/s", cores=th, kind="port", variant=name, seconds=round(dt, 3), host_cores=ncores,
+                sample=f"fastest of {len(variants)} CPU variants of graphML.py:152-175 (fwd+bwd, fp32): {name}; {n} of the batch's {B} entries",
+                variants=variants)
 
 
 def cpu_selgnn(w, wl, sample):

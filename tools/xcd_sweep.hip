@@ -33,7 +33,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 constexpr unsigned kPad = 0xffffffffu;
-constexpr int kWaves = 8;         // waves per workgroup
+constexpr int kWaves = 7;         // WORKER waves per workgroup (+ one sync wave = 512 threads: 2 waves per SIMD and workgroup)
+constexpr int kThreads = (kWaves + 1) * 64;   // kWaves worker waves + the sync wave
 constexpr int kSlots = 128;       // progress slots per XCD (>= workgroups per XCD)
 constexpr int kMaxSpin = 3000;
 
@@ -46,125 +47,206 @@ __device__ __forceinline__ unsigned wave_min(unsigned v) {
 }
 
 // stream[((tile * kWaves + wave) * L4 + s) * 8 + lg] : u32x4 = 4 consecutive slots of lane group lg; slot = dest_local << 17 | src, or kPad
-// ACCUM: 0 = gather only, 1 = read-modify-write per entry in program order, 2 = the 4 entries of a word have distinct destinations
-//        (plan-time guarantee): 4 LDS reads, 4 adds, 4 LDS writes
-template <int ACCUM, int MINW>
-__global__ __launch_bounds__(kWaves * 64, MINW) void sweep_kernel(const u32x4* __restrict__ stream, const float* __restrict__ X,
+// LDS accumulators: row dl at byte dl * 128; plan-time rule "lane groups {0,1,4,5} own even rows, {2,3,6,7} odd rows": the two rows a
+// ds_read_b128 / ds_write_b128 service group touches then lie in different bank halves (conflict-free).
+// ACCUM: 0 = gather only, 1 = read-modify-write per entry in program order, 3 = the four rows of a word are read together, duplicates
+//        (two entries of a word with the same destination) are merged in registers, then written in order (the last write carries
+//        every contribution).  (ds_add_f32 was measured: 165 clocks per wave instruction, 26 ms per hop -- LDS float atomics serialise.)
+constexpr int kRow = 32;
+template <int ACCUM, int MINW, int DEPTH>
+__global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __restrict__ stream, const float* __restrict__ X,
                                                                   float* __restrict__ Y, int N, int D, int L4, int P, int wgPerXcd,
                                                                   int nTiles, int entriesPerXcd, int B, float uval,
-                                                                  unsigned* __restrict__ prog, unsigned base, int lag, int shift,
-                                                                  int pfAhead, int rowsPerStep, unsigned* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) float4 accs[];   // [D + 8] rows of 32 floats (8 trash rows for padding slots)
-    __shared__ unsigned s_prog[kWaves];
-    f32x4* acc4 = reinterpret_cast<f32x4*>(accs);
-    volatile unsigned* vprog = s_prog;
+                                                                  unsigned* __restrict__ prog, unsigned base, int lag,
+                                                                  unsigned* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float accs[];   // [(D + 8) * kRow]
+    __shared__ unsigned s_prog[kWaves + 1];   // [kWaves] = the XCD's floor as last seen by a polling wave of this workgroup
+    auto lds_st = [&](int i, unsigned v) { __hip_atomic_store(&s_prog[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto lds_ld = [&](int i) { return __hip_atomic_load(&s_prog[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & 7, lg = lane >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    unsigned* slots = prog + xcd * kSlots;
-    unsigned g = base + ((j & 1) ? (unsigned)shift : 0u);
-    unsigned pv0 = base, pv1 = base;
+    unsigned short* slots = reinterpret_cast<unsigned short*>(prog) + xcd * kSlots;   // 16-bit progress (steps since `base`) per workgroup
+    const unsigned* pollp = prog + xcd * (kSlots / 2) + (lane & (wgPerXcd > 64 ? 63 : 31));   // one dword = two slots per lane: 1-2 lines
+    unsigned gi = 0;                         // index (since launch) of the step whose gathers are issued next
+    unsigned pv = 0;
     unsigned waited = 0, gaveup = 0;
 
-    auto publish = [&](unsigned gv) {
-        if (lane == 0) vprog[wave] = gv;
-        unsigned v = vprog[lane & (kWaves - 1)];
+    // progress: a worker wave writes its own counter to LDS (lgkmcnt traffic) and polls the XCD's counters with ONE unconditional
+    // L1-bypassing load per step, issued ahead of its gathers and used a step later: its vmcnt queue holds loads only and every path
+    // issues the same number of them, so the compiler counts exactly and two steps of gathers stay in flight (a publish STORE inside the
+    // loop, or a load behind a branch, makes it wait with vmcnt(0..1)).  The SYNC wave (wave kWaves) of the workgroup does nothing but
+    // publish the workgroup's minimum whenever it changes (workgroup-scope 16-bit store: the line stays in this XCD's L2).
+    auto publish = [&]() {
+        if (lane == 0) lds_st(wave, gi);
+    };
+    auto wg_min = [&]() -> unsigned {
+        unsigned v = lds_ld(min(lane & 7, kWaves - 1));
         v = min(v, (unsigned)__shfl_xor((int)v, 1));
         v = min(v, (unsigned)__shfl_xor((int)v, 2));
         v = min(v, (unsigned)__shfl_xor((int)v, 4));
-        if (lane == 0) st_sc1(slots + j, v);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     };
-    auto issue_poll = [&]() {
-        pv0 = ld_sc1(slots + lane);
-        pv1 = ld_sc1(slots + 64 + lane);
+    auto issue_poll = [&]() { pv = ld_sc1(pollp); };
+    auto floor_of = [&]() { return wave_min(min(pv & 0xffffu, pv >> 16)); };
+    auto wait_floor = [&]() {   // gate the gathers of step gi: at most `lag` steps ahead of the slowest workgroup of the XCD
+        unsigned fl = floor_of();   // the poll issued a step ago (always consumed: keeps the load count uniform)
+        issue_poll();
+        if (lag < 0) return;
+        int guard = 0;
+        while ((int)(gi - fl) > lag) {
+            if (++guard > kMaxSpin) { lag = -1; gaveup = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+            fl = floor_of();
+            issue_poll();
+        }
+        waited += (unsigned)guard;
+    };
+    auto gather = [&](const float* Xb, const u32x4& w, f32x4 (&x)[4]) {
+        const unsigned ee[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)   // unconditional: a padding slot gathers row 0 (an L1 hit) into the lane group's trash row, so every
+            x[u] = *reinterpret_cast<const f32x4*>(Xb + ((ee[u] & 0x1ffffu) * 32u + (unsigned)sub * 4u));   // path issues the same number of loads and the compiler can count vmcnt exactly
+    };
+    f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+    f32x4* acc4 = reinterpret_cast<f32x4*>(accs);
+    auto accumulate = [&](const u32x4& w, const f32x4 (&x)[4]) {
+        const unsigned ee[4] = {w.x, w.y, w.z, w.w};
+        if (ACCUM == 3) {
+            int d[4];
+            f32x4 a[4], sx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = (int)(ee[u] >> 17) * 8 + sub;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = acc4[d[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sx[u] = x[u];
+#pragma unroll
+                for (int v = 0; v < u; ++v) {   // fixed order: contributions of earlier slots first
+                    const float m = (d[v] == d[u]) ? 1.f : 0.f;
+                    sx[u] += x[v] * m;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc4[d[u]] = a[u] + sx[u];
+        } else if (ACCUM == 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc4[(int)(ee[u] >> 17) * 8 + sub] += x[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sink += x[u];
+        }
     };
 
-    for (int i = tid; i < (D + 8) * 8; i += kWaves * 64) acc4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (lane == 0) vprog[wave] = g;
+    if (stats && tid == 0) {   // residency check: spread of the workgroups' start times (100 MHz ticks)
+        const unsigned long long t0 = wall_clock64();
+        atomicMin(reinterpret_cast<unsigned long long*>(stats + 4), t0);
+        atomicMax(reinterpret_cast<unsigned long long*>(stats + 6), t0);
+    }
+    for (int i = tid; i < (D + 8) * kRow; i += kThreads) accs[i] = 0.f;
+    if (lane == 0 && wave < kWaves) lds_st(wave, gi);
     __syncthreads();
-    publish(g);
     issue_poll();
-    f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long tsync = 0, rounds = 0;
 
     for (int e = 0; e < entriesPerXcd; ++e) {
         const int b = e * 8 + xcd;
         for (int p = 0; p < P; ++p) {
             const int tile = p * wgPerXcd + j;
-            if (tile >= nTiles || b >= B) {   // nothing to do in this pass: do not hold the others back
-                g += (unsigned)L4;
-                publish(g);
-                continue;
-            }
-            const float* Xb = X + (int64_t)b * N * 32;
-            const u32x4* st = stream + ((int64_t)(tile * kWaves + wave) * L4) * 8 + lg;
-            u32x4 ew = st[0];
-            for (int s = 0; s < L4; ++s) {
-                const u32x4 en = st[(int64_t)(s + 1 < L4 ? s + 1 : s) * 8];
-                if (lag >= 0) {   // the poll was issued a step ago: its value is (conservatively) old
-                    unsigned fl = wave_min(min(pv0, pv1));
-                    int guard = 0;
-                    while ((int)(g - fl) > lag) {
-                        if (++guard > kMaxSpin) { lag = -1; gaveup = 1; break; }
-                        __builtin_amdgcn_s_sleep(8);
-                        issue_poll();
-                        fl = wave_min(min(pv0, pv1));
+            const bool live = tile < nTiles && b < B;
+            if (wave == kWaves) {   // ---- the sync wave: publish until every worker has issued the last gathers of this sweep
+                const unsigned target = gi + (unsigned)L4;
+                if (lag >= 0) {
+                    unsigned last = 0xffffffffu;
+                    const unsigned long long t0 = wall_clock64();
+                    for (int guard = 0; guard < (1 << 22); ++guard) {
+                        const unsigned v = wg_min();
+                        if (v != last && lane == 0)
+                            __hip_atomic_store(slots + j, (unsigned short)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        last = v;
+                        ++rounds;
+                        if ((int)(v - target) >= 0) break;
+                        __builtin_amdgcn_s_sleep(2);
                     }
-                    waited += (unsigned)guard;
+                    tsync += wall_clock64() - t0;
                 }
-                const unsigned ee[4] = {ew.x, ew.y, ew.z, ew.w};
-                f32x4 x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    x[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (ee[u] != kPad) x[u] = *reinterpret_cast<const f32x4*>(Xb + ((ee[u] & 0x1ffffu) * 32u + (unsigned)sub * 4u));
-                }
-                f32x4 pf = {0.f, 0.f, 0.f, 0.f};
-                if (pfAhead > 0) {
-                    const int r0 = (s + pfAhead) * rowsPerStep;
-                    const int row = r0 + (j * kWaves + wave) * 8 + lg;
-                    if (s + pfAhead < L4 && row < min(N, r0 + rowsPerStep))
-                        pf = *reinterpret_cast<const f32x4*>(Xb + ((unsigned)row * 32u + (unsigned)sub * 4u));
-                }
-                if (ACCUM == 2) {
-                    int d[4];
-                    f32x4 a[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) d[u] = (ee[u] != kPad ? (int)(ee[u] >> 17) : D + lg) * 8 + sub;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) a[u] = acc4[d[u]];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) a[u] += x[u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc4[d[u]] = a[u];
-                } else if (ACCUM == 1) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (ee[u] != kPad) acc4[(int)(ee[u] >> 17) * 8 + sub] += x[u];
+                gi = target;
+            } else if (!live) {     // nothing to do in this pass: do not hold the others back
+                gi += (unsigned)L4;
+                publish();
+            } else {
+                const float* Xb = X + (int64_t)b * N * 32;
+                const u32x4* st = stream + ((int64_t)(tile * kWaves + wave) * L4) * 8 + lg;
+                if (DEPTH == 4) {   // three steps of gathers in flight behind the one being accumulated (16 loads per lane)
+                    u32x4 w0 = st[0], w1 = st[8], w2 = st[16];
+                    f32x4 xa[4], xb[4], xc[4], xd[4];
+                    wait_floor(); gather(Xb, w0, xa); gi += 1u; publish();
+                    wait_floor(); gather(Xb, w1, xb); gi += 1u; publish();
+                    wait_floor(); gather(Xb, w2, xc); gi += 1u; publish();
+                    for (int s = 0; s < L4; s += 4) {   // L4 is a multiple of 4
+                        const u32x4 w3 = st[(int64_t)(s + 3) * 8];
+                        const u32x4 w4 = st[(int64_t)(s + 4 < L4 ? s + 4 : L4 - 1) * 8];
+                        const u32x4 w5 = st[(int64_t)(s + 5 < L4 ? s + 5 : L4 - 1) * 8];
+                        const u32x4 w6 = st[(int64_t)(s + 6 < L4 ? s + 6 : L4 - 1) * 8];
+                        wait_floor(); gather(Xb, w3, xd); gi += 1u; publish();
+                        accumulate(w0, xa);
+                        wait_floor(); gather(Xb, w4, xa); gi += (s + 4 < L4) ? 1u : 0u; publish();
+                        accumulate(w1, xb);
+                        wait_floor(); gather(Xb, w5, xb); gi += (s + 5 < L4) ? 1u : 0u; publish();
+                        accumulate(w2, xc);
+                        wait_floor(); gather(Xb, w6, xc); gi += (s + 6 < L4) ? 1u : 0u; publish();
+                        accumulate(w3, xd);
+                        w0 = w4;
+                        w1 = w5;
+                        w2 = w6;
+                    }
                 } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) sink += x[u];
+                u32x4 w0 = st[0], w1 = st[8];
+                f32x4 xa[4], xb[4];
+                wait_floor();
+                gather(Xb, w0, xa);
+                gi += 1u;
+                publish();
+                for (int s = 0; s < L4; s += 2) {   // L4 is even; two steps per round, two gather buffers, no register copies of x and
+                    // no conditional loads (the last round gathers the last word once more and drops it): exact vmcnt counting
+                    const u32x4 w2 = st[(int64_t)(s + 2 < L4 ? s + 2 : L4 - 1) * 8];
+                    const u32x4 w3 = st[(int64_t)(s + 3 < L4 ? s + 3 : L4 - 1) * 8];
+                    wait_floor();
+                    gather(Xb, w1, xb);              // step s + 1 in flight ...
+                    gi += 1u;
+                    publish();
+                    accumulate(w0, xa);              // ... while step s is accumulated
+                    wait_floor();
+                    gather(Xb, w2, xa);
+                    gi += (s + 2 < L4) ? 1u : 0u;
+                    publish();
+                    accumulate(w1, xb);
+                    w0 = w2;
+                    w1 = w3;
                 }
-                sink += pf;
-                g += 1u;
-                if (lag >= 0 || gaveup) {
-                    publish(g);
-                    if (lag >= 0) issue_poll();
                 }
-                ew = en;
             }
+            if (!live) continue;
             __syncthreads();
             float* Yb = Y + (int64_t)b * N * 32 + (int64_t)tile * D * 32;
             const int rows = min(D, N - tile * D);
-            for (int i = tid; i < rows * 8; i += kWaves * 64) {
+            for (int i = tid; i < rows * 8; i += kThreads) {
                 f32x4 v = acc4[i];
+                acc4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 v *= uval;
                 __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Yb) + i);
-                acc4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();
         }
     }
-    publish(0x7fffff00u);   // finished: never the minimum again (the host resets the slots before the next launch)
+    __syncthreads();   // finished: never the minimum again (the host resets the slots before the next launch)
+    if (wave == kWaves && lane == 0) __hip_atomic_store(slots + j, (unsigned short)0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    sink.x += (float)(pv & 1u) * 1e-30f;
+    if (stats && wave == kWaves && lane == 0) {
+        atomicAdd(stats + 2, (unsigned)rounds);
+        atomicAdd(stats + 3, (unsigned)(tsync >> 4));
+    }
     if (sink.x == 1.2345e30f && sink.y == -7.f) Y[0] = sink.z + sink.w;
     if (stats && lane == 0) {
         atomicAdd(stats + 0, waited);
@@ -211,11 +293,11 @@ static Streams build_streams(const Graph& G, int wgPerCU, int P, bool distinct) 
     const int N = G.N;
     S.wgPerXcd = 32 * wgPerCU;
     S.P = P;
-    S.D = (N + P * S.wgPerXcd - 1) / (P * S.wgPerXcd);
+    S.D = ((N + P * S.wgPerXcd - 1) / (P * S.wgPerXcd) + 1) & ~1;   // even: the trash rows D .. D + 7 keep the bank rule
     S.nTiles = (N + S.D - 1) / S.D;
     const int D = S.D, nLG = kWaves * 8;
-    // rows of a tile -> lane groups: even local rows to lane groups lg in {0,1,4,5}, odd ones to {2,3,6,7} (the two rows a
-    // ds_read_b128 service group touches then lie in different bank halves), dealt by degree, boustrophedon
+    // rows of a tile -> lane groups: even local rows to lane groups lg in {0,1,4,5}, odd ones to {2,3,6,7} (bank rule of the LDS
+    // accumulators), dealt by degree, boustrophedon
     std::vector<std::vector<unsigned>> lists((size_t)S.nTiles * nLG);
     int maxLen = 0;
     for (int t = 0; t < S.nTiles; ++t) {
@@ -223,7 +305,7 @@ static Streams build_streams(const Graph& G, int wgPerCU, int P, bool distinct) 
             std::vector<int> rows;
             for (int dl = par; dl < D && t * D + dl < N; dl += 2) rows.push_back(dl);
             std::stable_sort(rows.begin(), rows.end(), [&](int a, int c) { return G.nbr[t * D + a].size() > G.nbr[t * D + c].size(); });
-            std::vector<int> groups;   // the 32 lane groups of this parity
+            std::vector<int> groups;
             for (int w = 0; w < kWaves; ++w)
                 for (int lgx : {0, 1, 4, 5}) groups.push_back(w * 8 + lgx + 2 * par);
             const int ng = (int)groups.size();
@@ -241,7 +323,7 @@ static Streams build_streams(const Graph& G, int wgPerCU, int P, bool distinct) 
     }
     // even placement: entry with source j near slot j * alpha * (Lslots - 4) / N, never before its predecessor; alpha = the largest
     // of 1, 0.96, 0.92, ... for which the list fits (a list that is dense near the end runs slightly ahead of its position)
-    for (int L4 = (maxLen + 3) / 4 + 1;; ++L4) {
+    for (int L4 = ((maxLen + 3) / 4 + 4) & ~3;; L4 += 4) {
         const int Ls = L4 * 4;
         std::vector<unsigned> words((size_t)S.nTiles * kWaves * L4 * 8 * 4, kPad);
         bool ok = true;
@@ -280,6 +362,11 @@ static Streams build_streams(const Graph& G, int wgPerCU, int P, bool distinct) 
                 if (!placed) ok = false;
             }
         if (ok) {
+            for (size_t i = 0; i < words.size(); ++i)   // padding slot of lane group lg: gather row 0 into trash row D + lg
+                if (words[i] == kPad) {
+                    static const int trash[8] = {0, 2, 1, 3, 4, 6, 5, 7};   // even trash rows for lane groups 0,1,4,5, odd ones for 2,3,6,7
+                    words[i] = (unsigned)(D + trash[(i / 4) % 8]) << 17;
+                }
             S.L4 = L4;
             S.words.swap(words);
             break;
@@ -290,9 +377,9 @@ static Streams build_streams(const Graph& G, int wgPerCU, int P, bool distinct) 
 }
 
 int main(int argc, char** argv) {
-    int N = 100000, B = 128, iters = 5, only = -1, hostcheck = 0;
+    int N = 100000, B = 128, iters = 5, only = -1, hostcheck = 0, depth = 4;
     int64_t nnzTarget = 1000000;
-    std::vector<int> wgs = {2, 3}, lags = {-1, 1, 2, 3, 4, 6}, shifts = {0, 1}, pfs = {0, 1, 2}, accums = {2};
+    std::vector<int> wgs = {2, 3}, lags = {-1, 1, 2, 3, 4, 6, 8}, shifts = {0}, pfs = {0}, accums = {3, 1, 0};
     int P = 3;
     auto parse_list = [](const char* s) {
         std::vector<int> v;
@@ -319,6 +406,7 @@ int main(int argc, char** argv) {
         else if (k == "pf") pfs = parse_list(v.c_str());
         else if (k == "accum") accums = parse_list(v.c_str());
         else if (k == "only") only = atoi(v.c_str());
+        else if (k == "depth") depth = atoi(v.c_str());
         else if (k == "hostcheck") hostcheck = atoi(v.c_str());
     }
     Graph G = make_er(N, nnzTarget, 0);
@@ -329,7 +417,7 @@ int main(int argc, char** argv) {
 
     if (hostcheck) {   // no GPU needed: interpret the streams on the host (one column) and compare with the direct sums
         for (int wgPerCU : wgs)
-            for (int distinct = 1; distinct >= 0; --distinct) {
+            for (int distinct = 0; distinct >= 0; --distinct) {
                 Streams S = build_streams(G, wgPerCU, P, distinct != 0);
                 std::vector<double> xs(N), y(N, 0.0), yr(N, 0.0);
                 for (int i = 0; i < N; ++i) xs[i] = std::sin(0.001 * i) + 1.0;
@@ -341,13 +429,13 @@ int main(int argc, char** argv) {
                             for (int lgx = 0; lgx < 8; ++lgx) {
                                 const unsigned* wd = &S.words[((((size_t)(t * kWaves + w) * S.L4 + s) * 8 + lgx) * 4)];
                                 for (int u = 0; u < 4; ++u) {
-                                    if (wd[u] == kPad) continue;
+                                    if ((int)(wd[u] >> 17) >= S.D) continue;
                                     const int dl = (int)(wd[u] >> 17), src = (int)(wd[u] & 0x1ffffu);
-                                    if ((dl & 1) != ((lgx >> 1) & 1)) { printf("parity violation\n"); return 1; }
+                                    if ((dl & 1) != ((lgx >> 1) & 1)) { printf("bank-rule violation\n"); return 1; }
                                     y[(size_t)t * S.D + dl] += xs[src];
                                     ++cnt;
                                     posErr = std::max(posErr, std::fabs((double)src / N - (double)(s * 4 + u) / (S.L4 * 4)));
-                                    for (int u2 = 0; u2 < u; ++u2) if (wd[u2] != kPad && (wd[u2] >> 17) == (unsigned)dl) ++clash;
+                                    for (int u2 = 0; u2 < u; ++u2) if ((wd[u2] >> 17) == (unsigned)dl) ++clash;
                                 }
                             }
                 // LRU model of one XCD's L2 over one batch entry (P passes): every workgroup at step s + offset(wg), offsets uniform in
@@ -368,7 +456,7 @@ int main(int argc, char** argv) {
                                         for (int lgx = 0; lgx < 8; ++lgx) {
                                             const unsigned* wd = &S.words[((((size_t)(t * kWaves + w) * S.L4 + ss) * 8 + lgx) * 4)];
                                             for (int u = 0; u < 4; ++u)
-                                                if (wd[u] != kPad) order.push_back((int)(wd[u] & 0x1ffffu));
+                                                if ((int)(wd[u] >> 17) < S.D) order.push_back((int)(wd[u] & 0x1ffffu));
                                         }
                                 }
                         }
@@ -417,24 +505,23 @@ int main(int argc, char** argv) {
     }
     unsigned *prog, *stats;
     CK(hipMalloc(&prog, 8 * kSlots * 4));
-    CK(hipMalloc(&stats, 16));
+    CK(hipMalloc(&stats, 32));
     int cfg = 0;
     for (int wgPerCU : wgs) {
         for (int distinct = 1; distinct >= 0; --distinct) {
             bool need = false;
-            for (int ac : accums) need |= (distinct ? ac == 2 : ac != 2);
-            if (!need) continue;
+            if (distinct) continue;
             Streams S = build_streams(G, wgPerCU, P, distinct != 0);
             printf("# wgPerCU=%d P=%d D=%d tiles=%d L4=%d (steps per sweep) fill=%.3f stream=%.1f MB lds=%d B distinct=%d\n", wgPerCU, S.P, S.D, S.nTiles, S.L4,
-                   S.fill, S.words.size() * 4 / 1e6, (S.D + 8) * 128, distinct);
+                   S.fill, S.words.size() * 4 / 1e6, (S.D + 8) * kRow * 4, distinct);
             unsigned* dst;
             CK(hipMalloc(&dst, S.words.size() * 4));
             CK(hipMemcpy(dst, S.words.data(), S.words.size() * 4, hipMemcpyHostToDevice));
             const int entriesPerXcd = (B + 7) / 8;
-            const size_t lds = (size_t)(S.D + 8) * 128;
+            const size_t lds = (size_t)(S.D + 8) * kRow * 4;
             const int rowsPerStep = (N + S.L4 - 1) / S.L4;
             for (int ac : accums) {
-                if ((ac == 2) != (distinct != 0)) continue;
+                if (distinct) continue;
                 for (int lag : lags)
                     for (int sh : shifts)
                         for (int pf : pfs) {
@@ -444,32 +531,33 @@ int main(int argc, char** argv) {
                             const int shift = sh ? S.L4 / 2 : 0;
                             const unsigned span = (unsigned)(entriesPerXcd * S.P * S.L4 + shift + 64);
                             auto launch = [&](unsigned epoch) {
-                                std::vector<unsigned> init(8 * kSlots, 0xffffffffu);
+                                std::vector<unsigned short> init(8 * kSlots, 0xffffu);
                                 for (int x = 0; x < 8; ++x)
-                                    for (int jj = 0; jj < S.wgPerXcd; ++jj) init[x * kSlots + jj] = epoch * span;
-                                CK(hipMemcpyAsync(prog, init.data(), init.size() * 4, hipMemcpyHostToDevice, 0));
-                                CK(hipMemsetAsync(stats, 0, 16, 0));
+                                    for (int jj = 0; jj < S.wgPerXcd; ++jj) init[x * kSlots + jj] = 0;
+                                CK(hipMemcpyAsync(prog, init.data(), init.size() * 2, hipMemcpyHostToDevice, 0));
+                                { const unsigned init8[8] = {0, 0, 0, 0, 0xffffffffu, 0xffffffffu, 0, 0}; CK(hipMemcpyAsync(stats, init8, 32, hipMemcpyHostToDevice, 0)); }
                                 CK(hipStreamSynchronize(0));
                                 return epoch * span;
                             };
                             auto run = [&](unsigned base) {
-#define LAUNCH(AC, MW) hipLaunchKernelGGL((sweep_kernel<AC, MW>), dim3(8 * S.wgPerXcd), dim3(kWaves * 64), lds, 0, (const u32x4*)dst, X, Y, N, S.D, \
-                                          S.L4, S.P, S.wgPerXcd, S.nTiles, entriesPerXcd, B, uval, prog, base, lag, shift, pf, rowsPerStep, stats)
+#define LAUNCH(AC, MW, DP) hipLaunchKernelGGL((sweep_kernel<AC, MW, DP>), dim3(8 * S.wgPerXcd), dim3(kThreads), lds, 0, (const u32x4*)dst, X, Y, N, S.D, \
+                                          S.L4, S.P, S.wgPerXcd, S.nTiles, entriesPerXcd, B, uval, prog, base, lag, stats)
                                 if (wgPerCU >= 3) {
-                                    if (ac == 2) LAUNCH(2, 6); else if (ac == 1) LAUNCH(1, 6); else LAUNCH(0, 6);
+                                    if (ac == 1) LAUNCH(1, 6, 2); else LAUNCH(0, 6, 2);
                                 } else {
-                                    if (ac == 2) LAUNCH(2, 4); else if (ac == 1) LAUNCH(1, 4); else LAUNCH(0, 4);
+                                    if (depth == 4) {
+                                        if (ac == 3) LAUNCH(3, 4, 4); else if (ac == 1) LAUNCH(1, 4, 4); else LAUNCH(0, 4, 4);
+                                    } else {
+                                        if (ac == 3) LAUNCH(3, 4, 2); else if (ac == 1) LAUNCH(1, 4, 2); else LAUNCH(0, 4, 2);
+                                    }
                                 }
                             };
                             static bool attr = false;
                             if (!attr) {
                                 attr = true;
-                                CK(hipFuncSetAttribute((const void*)sweep_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                                CK(hipFuncSetAttribute((const void*)sweep_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                                CK(hipFuncSetAttribute((const void*)sweep_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                                CK(hipFuncSetAttribute((const void*)sweep_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                                CK(hipFuncSetAttribute((const void*)sweep_kernel<1, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                                CK(hipFuncSetAttribute((const void*)sweep_kernel<0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define SETATTR(AC, MW, DP) CK(hipFuncSetAttribute((const void*)sweep_kernel<AC, MW, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024))
+                                SETATTR(3, 4, 4); SETATTR(1, 4, 4); SETATTR(0, 4, 4); SETATTR(3, 4, 2); SETATTR(1, 4, 2); SETATTR(0, 4, 2);
+                                SETATTR(1, 6, 2); SETATTR(0, 6, 2);
                             }
                             CK(hipMemset(Y, 0xff, (size_t)B * N * 32 * 4));
                             unsigned epoch = 1;
@@ -480,7 +568,7 @@ int main(int argc, char** argv) {
                             CK(hipEventCreate(&e0));
                             CK(hipEventCreate(&e1));
                             float msTot = 0.f;
-                            unsigned hstats[4] = {0, 0, 0, 0};
+                            unsigned hstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                             for (int it = 0; it < iters; ++it) {
                                 const unsigned base = launch(epoch++);
                                 CK(hipEventRecord(e0));
@@ -491,7 +579,7 @@ int main(int argc, char** argv) {
                                 CK(hipEventElapsedTime(&ms, e0, e1));
                                 msTot += ms;
                             }
-                            CK(hipMemcpy(hstats, stats, 16, hipMemcpyDeviceToHost));
+                            CK(hipMemcpy(hstats, stats, 32, hipMemcpyDeviceToHost));
                             const float ms = msTot / iters;
                             double err = -1.0;
                             if (ac) {
@@ -508,8 +596,10 @@ int main(int argc, char** argv) {
                                         }
                                 }
                             }
-                            printf("cfg %d wg/CU=%d accum=%d lag=%d shift=%d pf=%d : %.3f ms/hop  %.1f %% of 8 TB/s  spins/wave=%.1f gaveup=%u  maxerr %.2e\n", myc,
-                                   wgPerCU, ac, lag, shift, pf, ms, algBytes / ms / 1e6 / 80.0, (double)hstats[0] / (8.0 * S.wgPerXcd * kWaves), hstats[1], err);
+                            printf("cfg %d wg/CU=%d accum=%d lag=%d shift=%d pf=%d : %.3f ms/hop  %.1f %% of 8 TB/s  spins/wave=%.1f gaveup=%u startspread=%.1fus syncround=%.2fus  maxerr %.2e\n", myc,
+                                   wgPerCU, ac, lag, shift, pf, ms, algBytes / ms / 1e6 / 80.0, (double)hstats[0] / (8.0 * S.wgPerXcd * (kWaves + 1)), hstats[1],
+                                   (double)((((unsigned long long)hstats[7] << 32) | hstats[6]) - (((unsigned long long)hstats[5] << 32) | hstats[4])) / 100.0,
+                                   hstats[2] ? (double)hstats[3] * 16.0 / 100.0 / hstats[2] : 0.0, err);
                             fflush(stdout);
                             CK(hipEventDestroy(e0));
                             CK(hipEventDestroy(e1));
