@@ -219,6 +219,7 @@ def main():
 
     L = _lib.lib()
     roofline = ROOFLINES[wl["kind"]](L, w, wl)                      # every rank runs it: keeps the ranks in step
+    mfma = mfma_filter(L, w, wl) if wl["kind"] == "filter" else None
     detail = None
     if args.detail and rank == 0 and wl["kind"] == "filter":
         detail = kernel_breakdown(L, w, wl)
@@ -236,6 +237,8 @@ def main():
         out = dict(metric="edges*taps/sec (GraphFilter fwd+bwd)", value=value, unit="edges*taps/s", n_gpus=world, steps=steps,
                    warmup=warmup, ms_per_step=ms_per_step, ms_per_step_median=ms_median, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic", config=cfg, roofline=roofline, cpu_baseline=cpu)
+        if mfma is not None:
+            out["mfma"] = mfma
         if detail:
             out["breakdown_ms"] = detail
         print(json.dumps(out), flush=True)
@@ -246,17 +249,44 @@ def main():
 # ------------------------------------------------------------------------------------------------------------------------------
 # roofline of the dominant kernel of each workload kind
 # ------------------------------------------------------------------------------------------------------------------------------
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch from the committed PMC summaries (profiles/*_pmc.json, newest round last)."""
-    traffic = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+def kernel_source_sha():
+    """sha256 over the library's sources (csrc/*.hip, gf_common.h, include/gfhip.h): what a PMC summary is valid for.  The GPU box has
+    no .git, so provenance is tied to the bytes of the kernel sources, not to a commit id."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "graph-neural-networks_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "gfhip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary(workload, kernel, suffix="_pmc.json"):
+    """Newest committed PMC summary (profiles/*<suffix>) for this workload and kernel, with whether it was taken on the kernel sources
+    that are running now."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix))):
         try:
             pm = json.load(open(f))
         except Exception:
             continue
         if pm.get("workload") == workload and pm.get("kernel") == kernel:
-            traffic = pm.get("hbm_bytes_per_launch")
-    return traffic
+            best = (f, pm)
+    if best is None:
+        return None, None
+    f, pm = best
+    src = dict(file=os.path.relpath(f, ROOT), kernel_src_sha=pm.get("kernel_src_sha"), running_src_sha=kernel_source_sha())
+    src["matches_running_sources"] = src["kernel_src_sha"] == src["running_src_sha"]
+    return pm, src
+
+
+def pmc_traffic(workload, kernel):
+    """(HBM bytes per launch, provenance): the bytes are reported only when the summary was taken on the kernel sources running now
+    (else null: a stale counter next to a live timing is worse than none)."""
+    pm, src = pmc_summary(workload, kernel)
+    if pm is None:
+        return None, None
+    return (pm.get("hbm_bytes_per_launch") if src["matches_running_sources"] else None), src
 
 
 def hop_bytes(B, N, W, nnz):
@@ -290,13 +320,43 @@ def filter_hop_roofline(L, plans, name, B, N, W, K, nnz, dev):
     nbytes = hops * hop_bytes(B, N, W, nnz)
     achieved = nbytes / (ms.value * 1e-3) / 1e9
     return dict(bound="hbm", kernel=kern, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name, kern), algorithmic_bytes=nbytes,
-                launch_ms=round(ms.value, 5), hops_per_launch=hops, pipeline=int(pipe), note=note)
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name, kern)[0], traffic_source=pmc_traffic(name, kern)[1],
+                algorithmic_bytes=nbytes, launch_ms=round(ms.value, 5), hops_per_launch=hops, pipeline=int(pipe), note=note)
 
 
 def roofline_filter(L, w, wl):
     plans = w.module._gso.plans(w.dev)
     return filter_hop_roofline(L, plans, w.name, wl["B"], wl["N"], wl["G"], wl["K"], w.nnz, w.dev)
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak of MI355X (MI355X_MICROARCH.md)
+
+
+def mfma_filter(L, w, wl):
+    """The filter-bank contraction [B*N, K*G] x [K*G, F] (graphML.py:170-171 + bias) of the forward: achieved fp32 MFMA flop/s from a live
+    HIP-event timing of the kernel the layer runs, and the MFMA pipe's busy share from the committed counter summary (MfmaUtil =
+    sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE * SIMDs), tools/pmc_mfma.sh), reported only when it was taken on these sources."""
+    from alegnn_amd import _lib
+    layer, dev = w.module, w.dev
+    B, N, G, F, K = wl["B"], wl["N"], wl["G"], wl["F"], wl["K"]
+    plans = layer._gso.plans(dev)
+    wt, b = layer.weight.detach(), layer.bias.detach()
+    y = torch.empty((B, F, N), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    panel = L.gf_lsigf_pipeline(plans, 1, G, F, K) == 2
+    Z = torch.randn((K, B * G // 4, N, 4) if panel else (K, B, N, G), device=dev)
+    fn = (L.gf_contract_panel if panel else L.gf_contract)
+    call = lambda: _lib.check(fn(Z.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), B, N, N, G, F, 1, K, 0, st), "contract")
+    ms = float(np.median(timed_hip_events(call, 12)[2:]))
+    flops = 2.0 * B * N * K * G * F
+    kern = "contract_panel_kernel" if panel else "contract_mfma_kernel"
+    pm, src = pmc_summary(w.name, kern, "_mfma_pmc.json")
+    util = pm.get("mfma_util_pct") if (pm is not None and src["matches_running_sources"]) else None
+    nbytes = 4 * (K * B * N * G + B * N * F + K * G * F)
+    return dict(bound="mfma", kernel=kern, achieved=round(flops / (ms * 1e-3) / 1e12, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), launch_ms=round(ms, 4), flops=flops,
+                mfma_busy_pct=util, mfma_busy_source=src, hbm_gbs=round(nbytes / (ms * 1e-3) / 1e9, 1),
+                note="AI = 13 flop/B < machine balance 20: this contraction sits on the HBM roof (hbm_gbs), the MFMA pipe is busy mfma_busy_pct of the launch")
 
 
 def roofline_selgnn(L, w, wl):
@@ -323,7 +383,8 @@ def roofline_evgf(L, w, wl):
     fwd = (F * G * N * 4 + B * G * N * 4 + state) + (K - 1) * tap + (K * state + B * F * N * 4)   # diag tap + edge taps + sum
     achieved = fwd / (ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel="gf_evgf_forward (ev_diag + (K-1) x ev_hop_lds4_kernel + ev_sum)", achieved=round(achieved, 1),
-                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(w.name, "ev_hop_lds4_kernel"),
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(w.name, "ev_hop_lds4_kernel")[0],
+                traffic_source=pmc_traffic(w.name, "ev_hop_lds4_kernel")[1],
                 algorithmic_bytes=fwd, algorithmic_bytes_per_tap=tap, launch_ms=round(ms, 4), nnzp=nnzp,
                 note="whole forward timed with HIP events on the launch stream; per-kernel split: profiles/*cfg5*_kernel_stats.csv")
 

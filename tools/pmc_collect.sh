@@ -3,7 +3,7 @@
 # domains in the same run), reduced to profiles/<tag>_<workload>_pmc.json in the form bench.py's roofline.traffic reads.
 #   usage: bash tools/pmc_collect.sh <workload> <kernel-name-substring> <tag>        e.g.  cfg4 spmm_sell_kernel r02
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp
-WL=${1:-cfg4}; KN=${2:-spmm_sell_kernel}; TAG=${3:-r02}
+WL=${1:-cfg4}; KN=${2:-spmm_sell_kernel}; TAG=${3:-r03}
 O=gpurun_out/pmc_$WL; rm -rf $O; mkdir -p $O
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
@@ -24,7 +24,7 @@ for d in sorted(glob.glob(f"{O}/pmc*/**/*counter_collection.csv", recursive=True
         tot[k] = sum(v) / len(v); nl = len(v)
 import bench
 w = bench.WORKLOADS[wl]
-out = dict(workload=wl, kernel=kn, launches_averaged=nl, raw=tot,
+out = dict(workload=wl, kernel=kn, kernel_src_sha=bench.kernel_source_sha(), launches_averaged=nl, raw=tot,
            command=f"rocprofv3 --pmc <group> -- python tools/hop_probe.py {wl} 3   (tools/pmc_collect.sh: one pass per counter group)",
            correction="FETCH_SIZE is reported in KiB and, on gfx950, at exactly half the bytes of a 16-B/lane streaming read (MI355X_MICROARCH.md, "
                       "HBM section: TCC_EA0_RDREQ x 64 B for 128-byte requests): read bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 is taken as is")
