@@ -144,6 +144,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     distributed = world > 1 or "RANK" in os.environ       # under torch.distributed.run even N = 1 goes through RCCL
+    # host side of W ranks on one box: an equal share of the cores each (graph generation, plan creation and the framework's own
+    # helper threads would otherwise oversubscribe W-fold), and ONE clustering of the graph per machine instead of one per rank
+    # (gf_plan_create's locality groups, ~2 s of one core at config 4: shared through GFHIP_PLAN_CACHE_DIR, see gf_plan.hip)
+    cores = os.cpu_count() or 1
+    if world > 1:
+        torch.set_num_threads(max(1, cores // world))
+    os.environ.setdefault("GFHIP_PLAN_CACHE_DIR", os.path.join(ROOT, "gpurun_out", "plan_cache"))
+    os.makedirs(os.environ["GFHIP_PLAN_CACHE_DIR"], exist_ok=True)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -73,6 +73,9 @@ class SparseGSO:
         return SparseGSO(out)
 
     # ---- construction --------------------------------------------------------------------------------
+    # CONTRACT of the dense-tensor cache below: a GSO tensor handed to the functional calls is not modified in place through views that
+    # bypass torch's version counter (S.data[...] = v, numpy arrays sharing its memory): such writes do not change the key and the
+    # cached operator would be used.  Build a new tensor (or call SparseGSO.from_any on a clone) after such an edit.
     _dense_cache = {}            # (data_ptr, version, shape, dtype, device) -> SparseGSO: functional calls LSIGF(h, S_dense, x) in a loop
     _DENSE_CACHE_MAX = 8         # (GatedGRNN per time step, jARMA) must not rebuild host CSR + device plans on every call
 

@@ -119,9 +119,16 @@ class Trainer:
         # A captured step embeds raw device pointers of the GSO plans and the per-rank loss weight: both are part of the key, and the
         # entry keeps the GSO objects alive (their finalizer frees the plans) -- changeGSO() simply leads to a new capture.
         gsos = tuple(m._gso for m in self.model.archit.modules() if getattr(m, "_gso", None) is not None)
-        key = (tuple(xTrain.shape), tuple(yTrain.shape), xTrain.dtype, yTrain.dtype, float(weight), tuple(id(g_) for g_ in gsos))
+        gso_ids = tuple(id(g_) for g_ in gsos)
+        key = (tuple(xTrain.shape), tuple(yTrain.shape), xTrain.dtype, yTrain.dtype, float(weight), gso_ids)
         g = self._graphs.get(key)
         if g is None:
+            # captures taken for GSOs the architecture no longer uses (changeGSO) would pin their static buffers and device plans for
+            # the life of the trainer: drop them; the few batch shapes of the current GSO set stay (bounded: oldest first beyond 8)
+            for k in [k for k in self._graphs if k[5] != gso_ids]:
+                del self._graphs[k]
+            while len(self._graphs) >= 8:
+                del self._graphs[next(iter(self._graphs))]
             dev = self.model.device
             sx = torch.empty(xTrain.shape, dtype=xTrain.dtype, device=dev)
             sy = torch.empty(yTrain.shape, dtype=yTrain.dtype, device=dev)

@@ -8,7 +8,10 @@
 // hopping the F-wide dY and contracting once costs 2(K-1)+K+1 signal passes instead of the K+3(K-1) of the
 // Horner form on dZ, and reuses the forward kernels unchanged.
 //
-// Two interchangeable pipelines produce bit-for-bit the same interface (x, dy, y, dx in the reference layout; Z / P opaque):
+// Two interchangeable pipelines expose the SAME INTERFACE (x, dy, y, dx in the reference layout; Z / P opaque).  Their floating-point
+// summation orders differ (different ELL images / neighbour orders), and within the panel pipeline the chain kernel and the per-hop
+// kernel (chosen from the panel count B * W / 4, see use_chain) differ too: results are bitwise reproducible for a given
+// (shape, batch size), and agree across pipelines / batch sizes to fp32 rounding (tests compare those with the stated tolerance):
 //   node-major  Z[T][B][N][G]        gathers served by L2            (gf_spmm.hip)     any N, any widths
 //   panels      Z[T][B*G/4][N][4]    gathers served by LDS           (gf_panel.hip)    N <= 10239, G and F in {8,16,32,64,128}
 // gf_lsigf_pipeline() tells which one a (plans, G, F, K) combination runs; forward and backward always agree because the rule

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unistd.h>
 #include <set>
 #include <utility>
 #include <new>
@@ -159,6 +160,7 @@ constexpr int32_t kScheduleWindow = 8192;
 constexpr int32_t kGroupMinNodes = 32768;   // below this a 128-byte-row panel fits L2 anyway
 constexpr int32_t kGroupRows = 6250;        // rows per group: their own 128-byte rows are 0.8 MB of the 4 MB L2
 constexpr int kGroupPowerIters = 50;        // power-iteration steps per bisection level
+constexpr int64_t kGroupWorkCap = 400'000'000;   // entry visits per bisection level: large graphs get fewer power iterations (>= 8)
 
 std::vector<int32_t> locality_groups(int32_t n, const HostCsr& a, int32_t& P) {
     // Start: recursive spectral bisection.  Per level, kGroupPowerIters steps of power iteration on (d_max I - L) of the symmetrised
@@ -192,7 +194,8 @@ std::vector<int32_t> locality_groups(int32_t n, const HostCsr& a, int32_t& P) {
                 for (int32_t v = 0; v < n; ++v) z[v] /= std::sqrt(std::max(norm[label[v]], 1e-300));
             };
             deflate(x);
-            for (int it = 0; it < kGroupPowerIters; ++it) {
+            const int iters = (int)std::max<int64_t>(8, std::min<int64_t>(kGroupPowerIters, kGroupWorkCap / std::max<int64_t>(1, (int64_t)a.col.size())));
+            for (int it = 0; it < iters; ++it) {
                 for (int32_t v = 0; v < n; ++v) y[v] = (dmax[label[v]] - dsum[v]) * x[v];
                 for (int32_t v = 0; v < n; ++v)
                     for (int32_t q = a.rowptr[v]; q < a.rowptr[v + 1]; ++q) {
@@ -243,6 +246,73 @@ std::vector<int32_t> locality_groups(int32_t n, const HostCsr& a, int32_t& P) {
         }
         if (moved == 0) break;
     }
+    return label;
+}
+
+// The clustering costs ~2 s of one host core at N = 1e5 / nnz = 1e6 and depends on the sparsity pattern only.  It is therefore
+// computed once per pattern and process (every device of a multi-GPU process, every edge feature with the same pattern, every
+// deep copy / unpickled module re-creates plans from the same CSR), and -- when the caller names a directory in
+// GFHIP_PLAN_CACHE_DIR -- once per pattern and machine (the ranks of a data-parallel job, repeated runs): labels are stored as
+// <dir>/groups_<hash>_<n>_<nnz>.bin, written to a temporary name and renamed.
+uint64_t pattern_hash(int32_t n, const HostCsr& a) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t bytes) {
+        const unsigned char* c = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ull;
+    };
+    mix(&n, sizeof(n));
+    mix(a.rowptr.data(), a.rowptr.size() * sizeof(int32_t));
+    mix(a.col.data(), a.col.size() * sizeof(int32_t));
+    return h;
+}
+
+std::vector<int32_t> locality_groups_cached(int32_t n, const HostCsr& a, int32_t& P) {
+    struct Entry { uint64_t h; int32_t n; int64_t nnz; int32_t P; std::vector<int32_t> label; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;   // newest last, at most 16 patterns
+    const uint64_t h = pattern_hash(n, a);
+    const int64_t nnz = (int64_t)a.col.size();
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Entry& e : cache)
+            if (e.h == h && e.n == n && e.nnz == nnz) {
+                P = e.P;
+                return e.label;
+            }
+    }
+    std::vector<int32_t> label;
+    char path[1024] = "";
+    if (const char* dir = getenv("GFHIP_PLAN_CACHE_DIR")) {
+        snprintf(path, sizeof(path), "%s/groups_%016llx_%d_%lld.bin", dir, (unsigned long long)h, n, (long long)nnz);
+        if (FILE* f = fopen(path, "rb")) {
+            int32_t hdr[2] = {0, 0};
+            label.resize(n);
+            if (fread(hdr, sizeof(int32_t), 2, f) == 2 && hdr[0] == n && hdr[1] > 0 && fread(label.data(), sizeof(int32_t), n, f) == (size_t)n) {
+                P = hdr[1];
+                for (int32_t v = 0; v < n && !label.empty(); ++v)
+                    if (label[v] < 0 || label[v] >= P) label.clear();   // a damaged file is recomputed, never trusted
+            } else {
+                label.clear();
+            }
+            fclose(f);
+        }
+    }
+    if (label.empty()) {
+        label = locality_groups(n, a, P);
+        if (path[0]) {
+            char tmp[1100];
+            snprintf(tmp, sizeof(tmp), "%s.%d.tmp", path, (int)getpid());
+            if (FILE* f = fopen(tmp, "wb")) {
+                const int32_t hdr[2] = {n, P};
+                const bool ok = fwrite(hdr, sizeof(int32_t), 2, f) == 2 && fwrite(label.data(), sizeof(int32_t), n, f) == (size_t)n;
+                fclose(f);
+                if (!ok || rename(tmp, path) != 0) remove(tmp);
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache.size() >= 16) cache.erase(cache.begin());
+    cache.push_back(Entry{h, n, nnz, P, label});
     return label;
 }
 
@@ -613,7 +683,7 @@ extern "C" int gf_plan_create(int32_t n, int64_t nnz, const int32_t* rowptr, con
         std::vector<int32_t> groups;
         if (sorted && n >= kGroupMinNodes && g_tune.spmm_group) {
             int32_t P = 0;
-            groups = locality_groups(n, S, P);
+            groups = locality_groups_cached(n, S, P);
         }
         const std::vector<int32_t>* gp = groups.empty() ? nullptr : &groups;
         int rc = upload_csr(n, St, sorted, gp, pl->mat[GF_OP_FWD], pl->device_bytes);

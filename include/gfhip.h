@@ -17,7 +17,9 @@
  *   - return value: 0 = GF_OK, negative = error (see enum); gf_last_error() gives a thread-local message.
  *     Shape violations that the reference reports with `assert` (graphML.py:135-140, 2118-2122) come back
  *     as GF_ERR_SHAPE so the Python layer can re-raise AssertionError.
- *   - results are bitwise run-to-run deterministic (no floating-point atomics).
+ *   - results are bitwise run-to-run deterministic for a given call shape (no floating-point atomics).  The kernel
+ *     (and with it the summation order) is chosen from the shapes, batch size included: the same sample evaluated at
+ *     B = 1 and inside a batch of 256 agrees to fp32 rounding, not bit for bit.
  *
  * Layouts
  *   reference layout   x [B, G, N]  (node index contiguous)          graphML.py:108-109

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-neural-networks_amd"), os.path.join(ROOT, "tools")]
 import numpy as np, torch
 from alegnn_amd import graphgen
-from alegnn_amd.modules import evaluation, loss, model, training
+from alegnn_amd.modules import evaluation, model, training
 from alegnn_amd.modules.architectures import SelectionGNN
 from alegnn_amd.utils import graphML as gml
 from _dense_torch import dense_lsigf, dense_nvgf
@@ -101,7 +101,7 @@ def trainer(N, nTrain, batchSize, epochs, hipGraph=False, F=(1, 32, 32)):
     net = SelectionGNN(list(F), [5, 5], True, torch.nn.ReLU, [N, N], gml.NoPool, [1, 1], [5], A)
     optim = torch.optim.Adam(net.parameters(), lr=1e-3)
     with tempfile.TemporaryDirectory() as tmp:
-        m = model.Model(net, loss.adaptExtraDimensionLoss(torch.nn.CrossEntropyLoss), optim, training.Trainer, evaluation.evaluate,
+        m = model.Model(net, torch.nn.CrossEntropyLoss(), optim, training.Trainer, evaluation.evaluate,
                         dev, "bench", tmp)
         np.random.seed(0)
         m.train(Data(), 1, batchSize, printInterval=0, doSaveVars=False, hipGraph=hipGraph)   # warm-up epoch (plans, allocator, capture)
