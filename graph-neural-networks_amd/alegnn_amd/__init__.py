@@ -34,4 +34,9 @@ def install(reference_graphML_module):
     reference_graphML_module.TimeGatedHiddenState = amd_gml.TimeGatedHiddenState      # architectures.py:4812
     reference_graphML_module.NodeGatedHiddenState = amd_gml.NodeGatedHiddenState      # architectures.py:4816
     reference_graphML_module.jARMA = amd_gml.jARMA                      # graphML.py:2826 (GraphFilterARMA.forward)
+    reference_graphML_module.EdgeGatedHiddenState = amd_gml.EdgeGatedHiddenState      # architectures.py (GatedGCRNN edge gating)
+    reference_graphML_module.LSIGF_DB = amd_gml.LSIGF_DB                # graphML.py:1164, 3366
+    reference_graphML_module.GRNN_DB = amd_gml.GRNN_DB                  # graphML.py:3502
+    reference_graphML_module.GraphFilter_DB = amd_gml.GraphFilter_DB    # architectures.py (LocalActivationGNN_DB / GraphRecurrentNN_DB)
+    reference_graphML_module.HiddenState_DB = amd_gml.HiddenState_DB
     return reference_graphML_module

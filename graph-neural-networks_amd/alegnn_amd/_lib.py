@@ -55,6 +55,12 @@ _SIGNATURES = {
     "gf_lsigf_forward_relu": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_lsigf_backward_relu": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                           _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gf_db_hop": (_c.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gf_db_grad_gso": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gf_stack_adjoint": (_c.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "gf_lsigf_db_forward": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gf_lsigf_db_backward": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                        _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_maxpool_forward": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_maxpool_backward": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gf_nvgf_scratch_floats": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),

@@ -10,6 +10,8 @@ Drop-in for the symbols SelectionGNN binds from alegnn/utils/graphML.py:
     jARMA          (graphML.py:490-638)    ARMA filter by Jacobi iterations: sparse hops instead of dense [F,E,P,G,N,N] products
     NVGF           (graphML.py:293-387)    -> alegnn_amd.functional.NVGF  (HIP: LSIGF's tap stack, per-node bank)
     NodeVariantGF  (graphML.py:2317-2509)  the module around it (NodeVariantGNN's layer)
+    LSIGF_DB / GRNN_DB / GraphFilter_DB / HiddenState_DB (graphML.py:977-1290, 3278-3538)  per-sample, delayed GSOs (gf_db.hip)
+    EdgeGatedHiddenState (graphML.py:4033-4208) and the edge-gated branches of GatedGRNN (:1394-1419, :1434-1456)
     NoPool         (graphML.py:1850-1888)  identity pooling
     MaxPoolLocal   (graphML.py:1890-2028)  alpha-hop neighbourhood max, keep the first nOutputNodes nodes
 Checkpoints are interchangeable with the reference: ``weight [F,E,K,G]``, ``bias [F,1]``; the GSO is a plain attribute
@@ -25,11 +27,13 @@ import torch
 import torch.nn as nn
 
 from ..functional import EVGF_edges, LSIGF, NVGF, expand_node_taps, max_pool_local
+from ..functional_db import GRNN_DB, LSIGF_DB, filter_per_sample
 from ..gso import EdgePattern, SparseGSO
 from . import graphTools
 
 __all__ = ["LSIGF", "GraphFilter", "EdgeVariantGF", "NoPool", "MaxPoolLocal", "FusedReLU", "GatedGRNN", "HiddenState", "TimeGatedHiddenState",
-           "NodeGatedHiddenState", "jARMA", "NVGF", "NodeVariantGF"]
+           "NodeGatedHiddenState", "EdgeGatedHiddenState", "jARMA", "NVGF", "NodeVariantGF", "LSIGF_DB", "GRNN_DB", "GraphFilter_DB",
+           "HiddenState_DB", "learnAttentionGSO", "GraphAttentional"]
 
 
 class FusedReLU(nn.Identity):
@@ -367,18 +371,28 @@ def _check_gate(q, B, T, N, name):
     if q.dim() > 1:
         assert q.shape[1] == T and q.shape[2] == 1 and (q.shape[3] == 1 or q.shape[3] == N), name
     if q.dim() > 4:
-        raise NotImplementedError("edge gating (%s of shape B x T x 1 x N x N, graphML.py:1394-1419) turns the GSO into a "
-                                  "dense per-sample matrix; that is a batched dense product, not this sparse path" % name)
+        assert q.shape[4] == N, name                                # :1372-1373 / :1379-1380  edge gate: B x T x 1 x N x N
+
+
+def _dense_on(gso, like):
+    """The GSO as the reference's dense [E,N,N] tensor on the device of `like` (edge gating multiplies it entrywise, :1397-1399)."""
+    key = (str(like.device), like.dtype)
+    cache = gso.__dict__.setdefault("_dense_dev", {})
+    if key not in cache:
+        cache[key] = gso.to_dense(like.dtype).to(like.device)
+    return cache[key]
 
 
 def GatedGRNN(a, b, S, x, z0, sigma, q_hat=None, q_check=None, xBias=None, zBias=None):
     """Hidden states z_t = sigma(q_hat_t * A(S) x_t + q_check_t * B(S) z_{t-1}), t = 1..T -- graphML.py:1292-1527.
 
     a [H,E,K,F] input-to-hidden taps, b [H,E,K,H] hidden-to-hidden taps, S the GSO (dense [E,N,N] or SparseGSO),
-    x [B,T,F,N], z0 [B,H,N]; gates: None / ones(1) (no gating), [B|1,T,1,1] (time) or [B|1,T,1,N] (node);
+    x [B,T,F,N], z0 [B,H,N]; gates: None / ones(1) (no gating), [B|1,T,1,1] (time), [B|1,T,1,N] (node) or [B,T,1,N,N] (edge);
     xBias / zBias [H,1].  Returns z [B,T,H,N].
-    A(S)x for all B*T inputs is ONE LSIGF call (:1389-1391); the recursion is one LSIGF call per time step (:1424) --
-    T+1 launches of the HIP filter instead of (T+1)(K-1) dense N x N products."""
+    Time / node gating: A(S)x for all B*T inputs is ONE LSIGF call (:1389-1391), the recursion one LSIGF call per time step (:1424).
+    Edge gating (:1394-1419, :1434-1456): the gate multiplies the GSO entrywise, so every (b, t) has its own operator q * S_e; the
+    filter with a per-sample operator is one HIP call for all B*T inputs (A) and one per time step (B) -- the reference multiplies all
+    B*T signals with all B*T operators and keeps the diagonal (:1407-1413)."""
     H, E, K, F = a.shape
     assert b.shape[0] == H and b.shape[1] == E and b.shape[2] == K and b.shape[3] == H      # :1354-1357
     gso = SparseGSO.from_any(S)
@@ -390,15 +404,26 @@ def GatedGRNN(a, b, S, x, z0, sigma, q_hat=None, q_check=None, xBias=None, zBias
         _check_gate(q_hat, B, T, N, "q_hat")
     if q_check is not None:
         _check_gate(q_check, B, T, N, "q_check")
-    Ax = LSIGF(a, gso, x.reshape(B * T, F, N), xBias).reshape(B, T, H, N)
-    if q_hat is not None:
-        Ax = q_hat * Ax                                             # :1392
+    edge_hat = q_hat is not None and q_hat.dim() > 4
+    edge_check = q_check is not None and q_check.dim() > 4
+    Sd = _dense_on(gso, x) if (edge_hat or edge_check) else None
+    if edge_hat:
+        edgeS = q_hat.reshape(B, T, E, N, N) * Sd                   # :1395-1399  (the reference's reshape needs E == 1 as well)
+        Ax = filter_per_sample(a, edgeS, x, xBias)                  # :1400-1419  B x T x H x N
+    else:
+        Ax = LSIGF(a, gso, x.reshape(B * T, F, N), xBias).reshape(B, T, H, N)
+        if q_hat is not None:
+            Ax = q_hat * Ax                                         # :1392
     zt = z0
     states = []
     for t in range(T):
-        Bz = LSIGF(b, gso, zt.reshape(B, H, N), zBias)              # :1424
-        if q_check is not None:                                     # :1426-1432  [B|1,1,1|N] broadcasts over H
-            Bz = (q_check[:, t] if q_check.dim() > 1 else q_check) * Bz
+        if edge_check:
+            edgeS = (q_check[:, t] * Sd).reshape(B, 1, E, N, N)     # :1437-1443  this step's gate: B x 1 x N x N
+            Bz = filter_per_sample(b, edgeS, zt.reshape(B, 1, H, N), zBias).reshape(B, H, N)     # :1444-1459
+        else:
+            Bz = LSIGF(b, gso, zt.reshape(B, H, N), zBias)          # :1424
+            if q_check is not None:                                 # :1426-1432  [B|1,1,1|N] broadcasts over H
+                Bz = (q_check[:, t] if q_check.dim() > 1 else q_check) * Bz
         zt = sigma(Ax[:, t] + Bz)                                   # :1462
         states.append(zt)
     return torch.stack(states, dim=1)                               # B x T x H x N
@@ -566,6 +591,192 @@ class NodeGatedHiddenState(_GatedHiddenStateBase):
         zCheck, _ = self.forgetGateGRNN(x, z0)                       # :3976-3979
         qCheck = torch.sigmoid(self.forgetGateGraphFilter(zCheck.reshape((B * T, self.H, N)))).reshape((B, T, 1, N))
         return self._state(x, z0, qHat, qCheck, T)
+
+
+_ZERO_TOLERANCE = 1e-9      # graphML.py:72
+_INFINITE_NUMBER = 1e12     # graphML.py:73
+
+
+def learnAttentionGSO(x, a, W, S, negative_slope=0.2):
+    """Attention coefficients as a GSO -- graphML.py:640-737 (the gate network of EdgeGatedHiddenState, :4159-4168).
+
+        alpha_ij^{pe} = softmax_j( LeakyReLU( a2^{pe} . W^{pe} x_i + a1^{pe} . W^{pe} x_j ) )   over the neighbourhood of i (S + I)
+        (as coded at :706-712: the first half of the mixing vector multiplies the neighbour j)
+
+    x [B,G,N], a [P,E,2F], W [P,E,F,G], S [E,N,N] dense or SparseGSO -> alpha [B,P,E,N,N] (dense: that is what an edge gate is).
+    Host logic in torch: elementwise + softmax on the [N,N] support, no graph filter inside."""
+    gso = SparseGSO.from_any(S)
+    B, N = x.shape[0], x.shape[2]
+    P, E = a.shape[0], a.shape[1]
+    assert W.shape[0] == P and W.shape[1] == E                       # :681-682
+    F = W.shape[2]
+    assert a.shape[2] == 2 * F                                       # :684
+    assert gso.E == E and gso.N == N                                 # :686-687
+    Sd = _dense_on(gso, x)
+    mask = ((Sd + torch.eye(N, dtype=x.dtype, device=x.device)).abs().sum(dim=0) > _ZERO_TOLERANCE).to(x.dtype)   # :692, :726-728
+    Wx = torch.matmul(W.reshape(1, P, E, F, W.shape[3]), x.reshape(B, 1, 1, x.shape[1], N))      # B x P x E x F x N   (:701-703)
+    a1Wx = torch.matmul(a[:, :, :F].reshape(1, P, E, 1, F), Wx)      # B x P x E x 1 x N   (:706-709)
+    a2Wx = torch.matmul(a[:, :, F:].reshape(1, P, E, 1, F), Wx)
+    e = nn.functional.leaky_relu(a1Wx + a2Wx.permute(0, 1, 2, 4, 3), negative_slope=negative_slope)   # :712-718
+    alpha = nn.functional.softmax(e * mask - (1 - mask) * _INFINITE_NUMBER, dim=4)               # :730-733
+    return alpha * mask                                              # :737
+
+
+class GraphAttentional(nn.Module):
+    """Parameter holder of the attention gate networks: ``mixer [K,E,2F]`` and ``weight [K,E,F,G]`` with the reference's names, shapes
+    and initialisation (graphML.py:2899-2933), so that EdgeGatedHiddenState checkpoints interchange.  The attention ARCHITECTURES are
+    out of scope; only ``learnAttentionGSO`` on these parameters is used here."""
+
+    def __init__(self, G, F, K, E=1, nonlinearity=nn.functional.relu, concatenate=True):
+        super().__init__()
+        self.G, self.F, self.K, self.E = G, F, K, E
+        self.S = None
+        self.nonlinearity = nonlinearity
+        self.concatenate = concatenate
+        self.mixer = nn.parameter.Parameter(torch.Tensor(K, E, 2 * F))
+        self.weight = nn.parameter.Parameter(torch.Tensor(K, E, F, G))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.G * self.K)                      # :2922-2924
+        self.weight.data.uniform_(-stdv, stdv)
+        self.mixer.data.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        assert len(S.shape) == 3 and S.shape[0] == self.E           # :2928-2930
+        self.N = S.shape[1]
+        assert S.shape[2] == self.N
+        self.S = S
+
+    def forward(self, x):
+        raise NotImplementedError("GraphAttentional.forward (graph attention layer) is outside the accelerated path; "
+                                  "EdgeGatedHiddenState only uses learnAttentionGSO on its parameters")
+
+
+class EdgeGatedHiddenState(_GatedHiddenStateBase):
+    """EdgeGatedHiddenState(signal_features, hidden_features, filter_taps, nonlinearity=torch.tanh, edge_features=1, bias=True)
+    -- graphML.py:4033-4208.  One input gate and one forget gate per (sample, time step, EDGE): attention coefficients computed from
+    the states of an ungated recurrent layer (``inputGateGAT`` / ``forgetGateGAT`` = GraphAttentional(H, 1, 1), created by ``addGSO``,
+    :4189-4190) multiply the GSO entrywise inside GatedGRNN.  forward as TimeGatedHiddenState."""
+
+    def addGSO(self, S):
+        self._set_gso(S)
+        dt, dev = self.aWeights.dtype, self.aWeights.device
+        self.inputGateGAT = GraphAttentional(self.H, 1, 1).to(device=dev, dtype=dt)
+        self.forgetGateGAT = GraphAttentional(self.H, 1, 1).to(device=dev, dtype=dt)
+        self.inputGateGAT.addGSO(self._gso)
+        self.forgetGateGAT.addGSO(self._gso)
+
+    def forward(self, x, z0):
+        B, T, N = self._check(x, z0)
+        zHat, _ = self.inputGateGRNN(x, z0)                          # :4157-4158
+        qHat = learnAttentionGSO(zHat.reshape((B * T, self.H, N)), self.inputGateGAT.mixer, self.inputGateGAT.weight,
+                                 self._gso).reshape((B, T, 1, N, N))                              # :4159-4161
+        zCheck, _ = self.forgetGateGRNN(x, z0)                       # :4164-4165
+        qCheck = learnAttentionGSO(zCheck.reshape((B * T, self.H, N)), self.forgetGateGAT.mixer, self.forgetGateGAT.weight,
+                                   self._gso).reshape((B, T, 1, N, N))                            # :4166-4168
+        return self._state(x, z0, qHat, qCheck, T)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Per-sample, delayed GSOs (the flocking models): GraphFilter_DB / HiddenState_DB around LSIGF_DB / GRNN_DB
+# ---------------------------------------------------------------------------------------------------------------
+class GraphFilter_DB(nn.Module):
+    """GraphFilter_DB(in_features, out_features, filter_taps, edge_features=1, bias=True) -- graphML.py:3278-3393.
+    Parameters ``weight [F,E,K,G]``, ``bias [F,1]`` (reference names / shapes / initialisation: checkpoints interchange);
+    ``addGSO(S [B,T,E,N,N])`` stores the per-sample, per-time-step operators; ``forward(x [B,T,G,N]) -> [B,T,F,N]`` = LSIGF_DB on
+    the HIP path (one launch per tap for all B*T operators)."""
+
+    def __init__(self, G, F, K, E=1, bias=True):
+        super().__init__()
+        self.G, self.F, self.K, self.E = G, F, K, E
+        self.S = None
+        self.weight = nn.parameter.Parameter(torch.Tensor(F, E, K, G))
+        if bias:
+            self.bias = nn.parameter.Parameter(torch.Tensor(F, 1))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.G * self.K)                      # :3341-3345
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        assert len(S.shape) == 5                                    # :3349
+        assert S.shape[2] == self.E                                 # :3351
+        self.N = S.shape[3]
+        assert S.shape[4] == self.N
+        self.S = S
+
+    def forward(self, x):
+        assert len(x.shape) == 4                                    # :3358
+        B, T = x.shape[0], x.shape[1]
+        assert self.S.shape[0] == B and self.S.shape[1] == T        # :3360-3362
+        assert x.shape[3] == self.N
+        return LSIGF_DB(self.weight, self.S, x, self.bias)          # :3366
+
+    def extra_repr(self):
+        reprString = "in_features=%d, out_features=%d, " % (self.G, self.F) + "filter_taps=%d, " % (self.K) + \
+                     "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias is not None)
+        reprString += "GSO stored" if self.S is not None else "no GSO stored"
+        return reprString
+
+
+class HiddenState_DB(nn.Module):
+    """HiddenState_DB(signal_features, hidden_features, filter_taps, nonlinearity=torch.tanh, edge_features=1, bias=True)
+    -- graphML.py:3395-3538.  Parameters ``aWeights [H,E,K,F]``, ``bWeights [H,E,K,H]``, ``xBias`` / ``zBias [H,1]``;
+    ``addGSO(S [B,T,E,N,N])``; ``forward(x [B,T,F,N], z0 [B,H,N]) -> (z [B,T,H,N], z_T [B,1,1,H,N])`` = GRNN_DB on the HIP path."""
+
+    def __init__(self, F, H, K, nonlinearity=torch.tanh, E=1, bias=True):
+        super().__init__()
+        self.F, self.H, self.K, self.E = F, H, K, E
+        self.S = None
+        self.bias = bias
+        self.sigma = nonlinearity
+        self.aWeights = nn.parameter.Parameter(torch.Tensor(H, E, K, F))
+        self.bWeights = nn.parameter.Parameter(torch.Tensor(H, E, K, H))
+        if self.bias:
+            self.xBias = nn.parameter.Parameter(torch.Tensor(H, 1))
+            self.zBias = nn.parameter.Parameter(torch.Tensor(H, 1))
+        else:
+            self.register_parameter('xBias', None)
+            self.register_parameter('zBias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.F * self.K)                      # :3469-3475
+        self.aWeights.data.uniform_(-stdv, stdv)
+        self.bWeights.data.uniform_(-stdv, stdv)
+        if self.bias:
+            self.xBias.data.uniform_(-stdv, stdv)
+            self.zBias.data.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        assert len(S.shape) == 5                                    # :3519
+        assert S.shape[2] == self.E
+        self.N = S.shape[3]
+        assert S.shape[4] == self.N
+        self.S = S
+
+    def forward(self, x, z0):
+        assert self.S is not None                                   # :3479
+        assert len(x.shape) == 4                                    # :3489
+        B, T = x.shape[0], x.shape[1]
+        assert self.S.shape[0] == B and self.S.shape[1] == T        # :3491-3493
+        assert x.shape[2] == self.F
+        N = x.shape[3]
+        assert len(z0.shape) == 3 and z0.shape[0] == B and z0.shape[1] == self.H and z0.shape[2] == N   # :3497-3500
+        z = GRNN_DB(self.aWeights, self.bWeights, self.S, x, z0, self.sigma, xBias=self.xBias, zBias=self.zBias)
+        return z, z[:, T - 1:T].unsqueeze(1)                        # :3506-3510
+
+    def extra_repr(self):
+        reprString = "in_features=%d, hidden_features=%d, " % (self.F, self.H) + "filter_taps=%d, " % (self.K) + \
+                     "edge_features=%d, " % (self.E) + "bias=%s, " % (self.bias) + "nonlinearity=%s" % (self.sigma)
+        reprString += "GSO stored" if self.S is not None else "no GSO stored"
+        return reprString
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -200,6 +200,33 @@ int gf_lsigf_backward_relu(const gf_plan* const* plans, int32_t E, const float* 
                            float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes,
                            int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream);
 
+/* ---- filters whose GSO differs per sample and time step: the reference's "_DB" family and edge gating ----------------------------
+ * S is the reference's dense tensor [B, T, E, N, N] (LSIGF_DB graphML.py:977-1094: `torch.matmul(x, S)` at :1069 with the time
+ * shift of :1062-1067), on the device; signals are node-major [nb * nt, N, W] rows (W % 4 == 0, W <= 256).
+ * gf_db_hop: one hop of every (b, t) in one launch.  S points at edge feature e of (b = 0, t = 0); s_stride_b / s_stride_t are the
+ *   element strides between samples / time steps (T*E*N*N and E*N*N for the full tensor; pass a pointer offset by t0 time steps and
+ *   nt = 1 for the per-time-step hop of GRNN_DB :1224-1262 or of the edge-gated recursion :1434-1456).
+ *     op = GF_OP_FWD:  X_out[b,t] = X_in[b,t-shift] @ S[b,t]       (zero for t - shift < 0)            x S_t of :1069 / :1407 / :1445
+ *     op = GF_OP_BWD:  X_out[b,t] = X_in[b,t+shift] @ S[b,t+shift]^T (zero for t + shift >= nt)          its adjoint (autograd)
+ * gf_db_grad_gso: dS[b,t,m,n] (+)= sum_w X_in[b,t-shift,m,w] * dOut[b,t,n,w] -- gradient of the hop with respect to the operator,
+ *   needed only when S is a function of learnable gates (edge gating: S = q * S_e, :1397-1399).
+ * gf_stack_adjoint: dZ[t,b,n,g] = sum_f P0[b,n,f] h[f,e(t),k(t),g] -- adjoint of gf_contract per tap (tap 0 sums h over e). */
+int gf_db_hop(const float* S, int64_t s_stride_b, int64_t s_stride_t, const float* X_in, float* X_out, int32_t nb, int32_t nt, int32_t N,
+              int32_t W, int32_t op, int32_t shift, void* stream);
+int gf_db_grad_gso(const float* X_in, const float* dOut, float* dS, int64_t s_stride_b, int64_t s_stride_t, int32_t nb, int32_t nt, int32_t N,
+                   int32_t W, int32_t shift, int32_t accumulate, void* stream);
+int gf_stack_adjoint(const float* P0, const float* h, float* dZ, int64_t BN, int32_t G, int32_t F, int32_t E, int32_t K, void* stream);
+/* whole layer (GraphFilter_DB.forward graphML.py:3356-3369 -> LSIGF_DB :977-1094, and its autograd):
+ *   forward:  S [B,T,E,N,N], x [B,T,G,N], h [F,E,K,G], bias [F]|NULL -> y [B,T,F,N]; Z [1+E(K-1), B*T, N, G] is written (save it).
+ *             shift = 1: the delayed filter z_k(t) = z_{k-1}(t-1) S(t); shift = 0: per-(b,t) operator without delay (edge gating).
+ *   backward: dy [B,T,F,N] -> dx [B,T,G,N], dh, dbias, dS [B,T,E,N,N] (each nullable = skipped); scratch: P0 [B*T,N,F],
+ *             dZ [1+E(K-1), B*T, N, G], hop [B*T,N,G]; workspace as for gf_grad_taps with batch B*T. */
+int gf_lsigf_db_forward(const float* S, const float* x, const float* h, const float* bias, float* Z, float* y, int32_t B, int32_t T, int32_t G,
+                        int32_t F, int32_t E, int32_t K, int32_t N, int32_t shift, void* stream);
+int gf_lsigf_db_backward(const float* S, const float* dy, const float* Z, const float* h, float* P0, float* dZ, float* hop_scratch, float* dx,
+                         float* dh, float* dbias, float* dS, void* workspace, size_t workspace_bytes, int32_t B, int32_t T, int32_t G,
+                         int32_t F, int32_t E, int32_t K, int32_t N, int32_t shift, void* stream);
+
 /* ---- measurement hook: run ONE hop `iters` times on `stream` bracketed by HIP events on that stream and return
  * the average milliseconds per launch (bench.py's roofline leg; hipEvents see the launch stream, torch events may not). */
 int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* X_out, int32_t B, int32_t W,

@@ -461,6 +461,149 @@ def evgf_case(name, S, B, G, F, K, M, Nin=None, bias=True, seed=0):
     print(f"evgf_{name}: N={N} E={E} M={M} Nin={Nin} B={B} G={G} F={F} K={K} max|y|={np.abs(out['y']).max():.3g}")
 
 
+def _radius_gsos(rng, B, T, E, N, radius=0.45, speed=0.05):
+    """Per-sample, per-time-step operators as the flocking data set builds them (dataTools.py Flocking: agents move, the graph is the
+    communication-radius graph of the current positions, normalised): B trajectories of N agents in the unit square."""
+    pos = rng.rand(B, 1, N, 2)
+    vel = speed * rng.randn(B, T, N, 2)
+    pos = pos + np.cumsum(vel, axis=1)
+    S = np.zeros((B, T, E, N, N))
+    for b in range(B):
+        for t in range(T):
+            d = np.linalg.norm(pos[b, t][:, None, :] - pos[b, t][None, :, :], axis=2)
+            A = ((d < radius) & (d > 0)).astype(np.float64)
+            for e in range(E):
+                W = A * (1.0 if e == 0 else np.exp(-d))          # second edge feature: distance-weighted, asymmetric after scaling
+                if e == 1:
+                    W = W * (1.0 + 0.3 * rng.rand(N, 1))
+                lam = max(1e-9, np.max(np.abs(np.linalg.eigvals(W))))
+                S[b, t, e] = W / lam
+    return S
+
+
+def lsigf_db_case(name, B, T, E, N, G, F, K, bias=True, seed=0):
+    """gml.LSIGF_DB (graphML.py:977-1094) forward + autograd wrt taps, input and bias; S [B,T,E,N,N] from moving agents."""
+    rng = np.random.RandomState(seed)
+    S = _radius_gsos(rng, B, T, E, N)
+    h = rng.uniform(-1, 1, (F, E, K, G)) / np.sqrt(G * K)
+    x = rng.randn(B, T, G, N)
+    b = rng.uniform(-1, 1, (F, 1)) if bias else None
+    dy = rng.randn(B, T, F, N)
+    ht, xt = torch.tensor(h, requires_grad=True), torch.tensor(x, requires_grad=True)
+    bt = torch.tensor(b, requires_grad=True) if bias else None
+    y = gml.LSIGF_DB(ht, torch.tensor(S), xt, bt)
+    y.backward(torch.tensor(dy))
+    out = dict(S=S, h=h, x=x, dy=dy, y=y.detach().numpy(), dx=xt.grad.numpy(), dh=ht.grad.numpy())
+    if bias:
+        out.update(b=b, db=bt.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, f"lsigfdb_{name}.npz"), **out)
+    print(f"lsigfdb_{name}: S{S.shape} density={np.mean(S != 0):.2f} y{tuple(y.shape)} max|y|={np.abs(out['y']).max():.3g}")
+
+
+def grnn_db_case(name, B, T, E, N, F, H, K, seed=0):
+    """gml.HiddenState_DB / GRNN_DB (graphML.py:1096-1290, 3395-3538): module forward + autograd."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    S = _radius_gsos(rng, B, T, E, N)
+    layer = gml.HiddenState_DB(F, H, K, nonlinearity=torch.tanh, E=E, bias=True)
+    layer.addGSO(torch.tensor(S))
+    x, z0, dz = rng.randn(B, T, F, N), rng.randn(B, H, N), rng.randn(B, T, H, N)
+    xt, z0t = torch.tensor(x, requires_grad=True), torch.tensor(z0, requires_grad=True)
+    z, zT = layer(xt, z0t)
+    (z * torch.tensor(dz)).sum().backward()
+    out = dict(S=S, x=x, z0=z0, dz=dz, z=z.detach().numpy(), zT_shape=np.array(zT.shape), dx=xt.grad.numpy(), dz0=z0t.grad.numpy(),
+               dims=np.array([F, H, K, E]))
+    for k, v in layer.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in layer.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"grnndb_{name}.npz"), **out)
+    print(f"grnndb_{name}: z{tuple(z.shape)} zT{tuple(zT.shape)}")
+
+
+def edge_gated_grnn_case(name, S, B, T, F, H, K, which="both", seed=0):
+    """gml.GatedGRNN with EDGE gates q [B,T,1,N,N] (graphML.py:1394-1419, :1434-1456), gradients with respect to the gates included
+    (in EdgeGatedHiddenState they come out of the attention networks).  which: 'both' | 'hat' (forget gate absent) | 'check'."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    E, N = S.shape[0], S.shape[1]
+    layer = gml.HiddenState(F, H, K, nonlinearity=torch.tanh, E=E, bias=True)
+    layer.addGSO(torch.tensor(S))
+    x, z0, dz = rng.randn(B, T, F, N), rng.randn(B, H, N), rng.randn(B, T, H, N)
+    xt, z0t = torch.tensor(x, requires_grad=True), torch.tensor(z0, requires_grad=True)
+    out = dict(x=x, z0=z0, dz=dz, which=np.array(which), **coo(S))
+    kw = {}
+    gates = {}
+    for nm in ("q_hat", "q_check"):
+        if which == "both" or which == nm[2:]:
+            out[nm] = rng.rand(B, T, 1, N, N)
+            gates[nm] = torch.tensor(out[nm], requires_grad=True)
+            kw[nm] = gates[nm]
+    z = gml.GatedGRNN(layer.aWeights, layer.bWeights, layer.S, xt, z0t, torch.tanh, xBias=layer.xBias, zBias=layer.zBias, **kw)
+    (z * torch.tensor(dz)).sum().backward()
+    out.update(z=z.detach().numpy(), dx=xt.grad.numpy(), dz0=z0t.grad.numpy())
+    for nm, g in gates.items():
+        out["d" + nm] = g.grad.numpy()
+    for k, v in layer.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in layer.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"edgegrnn_{name}.npz"), **out)
+    print(f"edgegrnn_{name}: z{tuple(z.shape)} which={which}")
+
+
+def edge_gated_hidden_state_case(name, S, B, T, F, H, K, seed=0):
+    """gml.EdgeGatedHiddenState (graphML.py:4033-4208): module forward + autograd, with the attention gate networks it creates."""
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    E, N = S.shape[0], S.shape[1]
+    layer = gml.EdgeGatedHiddenState(F, H, K, nonlinearity=torch.tanh, E=E, bias=True)
+    layer.addGSO(torch.tensor(S))
+    x, z0, dz = rng.randn(B, T, F, N), rng.randn(B, H, N), rng.randn(B, T, H, N)
+    xt, z0t = torch.tensor(x, requires_grad=True), torch.tensor(z0, requires_grad=True)
+    z, zT = layer(xt, z0t)
+    (z * torch.tensor(dz)).sum().backward()
+    out = dict(x=x, z0=z0, dz=dz, z=z.detach().numpy(), zT_shape=np.array(zT.shape), dx=xt.grad.numpy(), dz0=z0t.grad.numpy(),
+               dims=np.array([F, H, K, E]), **coo(S))
+    for k, v in layer.state_dict().items():
+        out["sd:" + k] = v.numpy()
+    for k, p in layer.named_parameters():
+        out["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"edgehs_{name}.npz"), **out)
+    print(f"edgehs_{name}: z{tuple(z.shape)} keys={list(layer.state_dict())}")
+
+
+def attention_case(name, S, B, G, F, P, seed=0):
+    """gml.learnAttentionGSO (graphML.py:640-737) forward + autograd: the edge-gate network of EdgeGatedHiddenState."""
+    rng = np.random.RandomState(seed)
+    E, N = S.shape[0], S.shape[1]
+    x, a, W = rng.randn(B, G, N), rng.randn(P, E, 2 * F), rng.randn(P, E, F, G)
+    dq = rng.randn(B, P, E, N, N)
+    xt, at, Wt = (torch.tensor(v, requires_grad=True) for v in (x, a, W))
+    q = gml.learnAttentionGSO(xt, at, Wt, torch.tensor(S))
+    (q * torch.tensor(dq)).sum().backward()
+    np.savez_compressed(os.path.join(HERE, f"attention_{name}.npz"), x=x, a=a, W=W, dq=dq, q=q.detach().numpy(), dx=xt.grad.numpy(),
+                        da=at.grad.numpy(), dW=Wt.grad.numpy(), **coo(S))
+    print(f"attention_{name}: q{tuple(q.shape)}")
+
+
+def db_cases(sbm, asym37):
+    attention_case("asym37", asym37, B=3, G=4, F=1, P=1)
+    attention_case("asym37_P2_F3", asym37, B=2, G=5, F=3, P=2, seed=1)
+    lsigf_db_case("radius_E1", B=3, T=6, E=1, N=20, G=4, F=6, K=3)
+    lsigf_db_case("radius_E2_K4", B=2, T=5, E=2, N=16, G=3, F=5, K=4)
+    lsigf_db_case("radius_K1_nobias", B=2, T=3, E=1, N=12, G=2, F=3, K=1, bias=False)
+    lsigf_db_case("radius_T2_K4", B=2, T=2, E=1, N=33, G=8, F=8, K=4, seed=3)       # more taps than time steps
+    grnn_db_case("radius_E1", B=3, T=6, E=1, N=20, F=3, H=5, K=3)
+    grnn_db_case("radius_E2", B=2, T=5, E=2, N=16, F=2, H=4, K=4, seed=1)
+    grnn_db_case("radius_K1", B=2, T=3, E=1, N=12, F=2, H=8, K=1, seed=2)
+    edge_gated_grnn_case("asym37_both", asym37, B=2, T=3, F=3, H=4, K=3)
+    edge_gated_grnn_case("asym37_hat", asym37, B=2, T=3, F=2, H=8, K=2, which="hat", seed=1)
+    edge_gated_grnn_case("sbm100_check", sbm[None], B=2, T=2, F=2, H=4, K=3, which="check", seed=2)
+    edge_gated_hidden_state_case("asym37", asym37, B=2, T=3, F=2, H=4, K=3)
+    edge_gated_hidden_state_case("sbm100", sbm[None], B=2, T=2, F=3, H=8, K=2, seed=1)
+
+
 def main():
     # ---- graphs --------------------------------------------------------------------------
     # directed ring with distinct weights + one chord: maximally asymmetric (catches S vs S^T)
@@ -484,6 +627,9 @@ def main():
 
     if "--nvgf-only" in sys.argv:
         nvgf_cases(sbm, asym, asym37, ring)
+        return
+    if "--db-only" in sys.argv:
+        db_cases(sbm, asym37)
         return
     if "--grnn-only" in sys.argv:
         grnn_cases(sbm, asym, fb)
@@ -528,6 +674,7 @@ def main():
         return
     selection_gnn_coarsen_case("sbm100_L2", sbm, [1, 8, 16], [3, 4], [5], B=4, seed=3)
     selection_gnn_coarsen_case("fbego_L3", fb[0], [2, 8, 8, 16], [3, 3, 2], [4], B=3, seed=1)
+    db_cases(sbm, asym37)
     # ---- LSIGF -----------------------------------------------------------------------------
     lsigf_case("ring_dir", ring, B=2, G=2, F=3, K=3)
     lsigf_case("asym_E2", asym, B=3, G=3, F=5, K=4)

@@ -10,7 +10,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from _util import GOLDEN, load
+from _util import GOLDEN, case_id, golden_files, load, relerr
 
 from alegnn_amd import SparseGSO, _lib, graphgen
 from alegnn_amd.modules.architectures import SelectionGNN
@@ -674,3 +674,17 @@ def test_edge_variant_gnn_has_the_reference_surface():
     with pytest.raises(AssertionError):
         EdgeVariantGNN([2, 4, 4], [3], [20, 10], True, torch.nn.ReLU, [20, 10], gml.MaxPoolLocal, [2, 2], [3], d["S"][0])
 
+
+
+@pytest.mark.parametrize("path", golden_files("attention"), ids=case_id)
+def test_learn_attention_gso_host_logic(path):
+    """learnAttentionGSO (graphML.py:640-737) is pure host logic (elementwise + softmax on the [N,N] support): runs on the CPU and
+    must reproduce the reference's coefficients and gradients exactly (float64)."""
+    from alegnn_amd.utils import graphML as amd_gml
+    d = load(path)
+    x, a, W = (torch.tensor(d[k], requires_grad=True) for k in ("x", "a", "W"))
+    q = amd_gml.learnAttentionGSO(x, a, W, torch.tensor(d["S"]))
+    (q * torch.tensor(d["dq"])).sum().backward()
+    assert relerr(q.detach().numpy(), d["q"]) < 1e-12
+    for t, k in ((x, "dx"), (a, "da"), (W, "dW")):
+        assert relerr(t.grad.numpy(), d[k]) < 1e-11, k
