@@ -484,9 +484,22 @@ def test_graph_recurrent_surface_matches_reference():
     net.load_state_dict(ref, strict=True)
     hs = gml.HiddenState(3, 8, 3)
     assert [tuple(p.shape) for p in hs.parameters()] == [(8, 1, 3, 3), (8, 1, 3, 8), (8, 1), (8, 1)]
-    with pytest.raises(NotImplementedError):                         # edge gating is a dense per-sample GSO
+    with pytest.raises(RuntimeError, match="no CPU fallback"):       # edge gating runs on the HIP path (gf_db.hip) like everything else
         gml.GatedGRNN(hs.aWeights, hs.bWeights, sp.identity(4, format="csr"), torch.zeros(2, 3, 3, 4), torch.zeros(2, 8, 4),
                       torch.tanh, q_hat=torch.ones(2, 3, 1, 4, 4))
+    with pytest.raises(AssertionError):                              # an edge gate must be B x T x 1 x N x N (graphML.py:1372-1373)
+        gml.GatedGRNN(hs.aWeights, hs.bWeights, sp.identity(4, format="csr"), torch.zeros(2, 3, 3, 4), torch.zeros(2, 8, 4),
+                      torch.tanh, q_hat=torch.ones(2, 3, 1, 4, 5))
+    eg = gml.EdgeGatedHiddenState(3, 8, 3)
+    eg.addGSO(torch.eye(4).reshape(1, 4, 4))
+    assert [k for k in eg.state_dict() if "GAT" in k] == ["inputGateGAT.mixer", "inputGateGAT.weight", "forgetGateGAT.mixer", "forgetGateGAT.weight"]
+    assert tuple(eg.inputGateGAT.mixer.shape) == (1, 1, 2) and tuple(eg.inputGateGAT.weight.shape) == (1, 1, 1, 8)   # GraphAttentional(H,1,1)
+    db = gml.HiddenState_DB(3, 8, 3, E=2)
+    assert [tuple(p.shape) for p in db.parameters()] == [(8, 2, 3, 3), (8, 2, 3, 8), (8, 1), (8, 1)]
+    with pytest.raises(AssertionError):
+        db.addGSO(torch.zeros(2, 5, 1, 4, 4))                        # E mismatch (graphML.py:3521)
+    gfdb = gml.GraphFilter_DB(3, 6, 4, 2)
+    assert tuple(gfdb.weight.shape) == (6, 2, 4, 3) and tuple(gfdb.bias.shape) == (6, 1) and "no GSO stored" in gfdb.extra_repr()
 
 
 def test_node_variant_gnn_surface_matches_reference():
