@@ -47,5 +47,32 @@ PY
     done
   done 2>&1 | tee $O/pmc_sweep_cfgs.log
   ;;
+suite)   # the whole GPU suite as the driver runs it (product configuration: no GFHIP_EXPERIMENTS) + smoke
+  timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -5 $O/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+  # the same kernels in the PRODUCT configuration (gf_tune refused): full-size parity + the per-sample GSO family
+  GFHIP_EXPERIMENTS=0 timeout 1500 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_db.py -x -q -m gpu > $O/pytest_product_mode.log 2>&1; tail -3 $O/pytest_product_mode.log
+  ;;
+bench)   # the driver's bench line + the other BASELINE workloads (CPU baselines included)
+  for w in cfg4 cfg2 cfg1 cfg3 cfg5; do timeout 900 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; tail -2 $O/bench_$w.err | cut -c1-300; cut -c1-1800 $O/bench_$w.json; done
+  ;;
+pmc)     # counters of the dominant kernels on the sources of this snapshot (own passes, no tracing domains)
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_collect.sh cfg4 spmm_sell_kernel r03 > $O/pmc_cfg4.log 2>&1; tail -1 $O/pmc_cfg4.log | cut -c1-600; cp gpurun_out/pmc_cfg4/r03_cfg4_pmc.json $O/
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_collect.sh cfg2 spmm_chain_kernel r03 > $O/pmc_cfg2.log 2>&1; tail -1 $O/pmc_cfg2.log | cut -c1-600; cp gpurun_out/pmc_cfg2/r03_cfg2_pmc.json $O/
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_collect.sh cfg5 ev_hop_lds4_kernel r03 > $O/pmc_cfg5.log 2>&1; tail -1 $O/pmc_cfg5.log | cut -c1-600; cp gpurun_out/pmc_cfg5/r03_cfg5_pmc.json $O/
+  bash tools/pmc_mfma.sh cfg4 r03 > $O/pmc_mfma_cfg4.log 2>&1; tail -3 $O/pmc_mfma_cfg4.log | cut -c1-500; cp gpurun_out/pmc_mfma_cfg4/*.json $O/
+  bash tools/pmc_mfma.sh cfg2 r03 > $O/pmc_mfma_cfg2.log 2>&1; tail -3 $O/pmc_mfma_cfg2.log | cut -c1-500; cp gpurun_out/pmc_mfma_cfg2/*.json $O/
+  ;;
+stats)   # rocprofv3 --kernel-trace --stats of the bench command, per workload (own runs: no counters here)
+  for w in cfg4 cfg2 cfg5 cfg3; do
+    rm -rf $O/kt_$w; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o bench -- python bench.py --workload $w --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/bench_prof_$w.err
+    f=$(find $O/kt_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_${w}_kernel_stats.csv && head -8 $f | cut -c1-200
+    rm -rf $O/kt_$w
+  done
+  ;;
+scale)   # multi-GPU rehearsal as far as one GPU allows: single process vs torchrun N=1 vs forced collective
+  bash tools/scale.sh cfg4 1 > $O/scale_cfg4.log 2>&1; cat $O/scale_cfg4.log; cp gpurun_out/scale/*.json $O/ 2>/dev/null
+  bash tools/scale.sh cfg2 1 > $O/scale_cfg2.log 2>&1; cat $O/scale_cfg2.log; cp gpurun_out/scale/cfg2*.json $O/ 2>/dev/null
+  ;;
 *) echo "unknown stage $S"; exit 2;;
 esac

@@ -17,6 +17,18 @@ dev = torch.device("cuda:0")
 wl = dict(bench.WORKLOADS[name])
 if os.environ.get("PROBE_B"):  # same workload at another batch size (row width of the EVGF gathers = 4*B bytes)
     wl["B"] = int(os.environ["PROBE_B"])
+if os.environ.get("PROBE_GRAPH") == "band":   # same N / degree, every neighbour within +-64 rows: the gather panel of a row block is L2-resident
+    import numpy as np, scipy.sparse as sp
+    from alegnn_amd import graphgen
+    def band(N, avg_degree=10.0, seed=0, **kw):
+        rng = np.random.RandomState(seed)
+        r = np.repeat(np.arange(N), int(avg_degree) // 2)
+        c = np.clip(r + rng.randint(1, 65, size=r.size), 0, N - 1)
+        A = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(N, N))
+        A = ((A + A.T) > 0).astype(np.float64)
+        A.setdiag(0); A.eliminate_zeros()
+        return sp.csr_matrix(A / 20.0)
+    graphgen.er = band
 w = bench.Workload(name, wl, dev, 0)
 st = torch.cuda.current_stream().cuda_stream
 if wl["kind"] == "evgf":
@@ -41,6 +53,7 @@ else:
             _lib.check(L.gf_khop_panel(plans, 1, 0, Z.data_ptr(), B, W, K, st))
     else:
         X0 = torch.randn(B, N, W, device=dev); X1 = torch.empty_like(X0)
-        for _ in range(iters):
-            _lib.check(L.gf_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, W, st))
+        ms = ctypes.c_float()
+        _lib.check(L.gf_time_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, W, max(iters, 3), st, ctypes.byref(ms)))
+        print(f"spmm hop {name} graph={os.environ.get('PROBE_GRAPH', 'default')} nnz={w.nnz} {' '.join(sys.argv[3:])}: {ms.value:.4f} ms")
 torch.cuda.synchronize()
