@@ -435,7 +435,7 @@ def cpu_filter(w, wl, sample):
         orc.lsigf_sparse_grads(wt.numpy(), w.A, xn, b.numpy(), np.ones((xn.shape[0], wt.shape[0], N), np.float32), dtype=np.float32)
 
     cands = [(f"sparse-CSR restatement, torch.sparse_csr, {th} threads", th, torch_sparse(th))
-             for th in sorted({min(ncores, t) for t in (8, 16, 32, 64)} | {ncores})]
+             for th in sorted({min(ncores, t) for t in (8, 16, 32, 64)})]     # (all 256 hardware threads: 100x slower than 32, measured)
     cands.append(("sparse-CSR restatement, scipy (analytic backward), 1 core", 1, scipy_csr))
     if N <= 20_000:                                           # dense S is N^2*4 bytes: 400 MB at N=10k, 40 GB at 100k
         S = torch.from_numpy(w.A.toarray().astype(np.float32))[None]

@@ -307,9 +307,10 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     const size_t pair = 2 * (size_t)(N + 1) * 16;
     int np = (pair <= 80 * 1024 || (!uniform && pair <= 160 * 1024)) ? 2 : 1;
     if (g_tune.panel_np == 1 || (g_tune.panel_np == 2 && pair <= 160 * 1024)) np = g_tune.panel_np;
-    if (nPanels < 2 * num_cus()) np = 1;  // not enough panels to keep every CU busy with pairs
+    if (g_tune.panel_np == 4 && 2 * pair <= 160 * 1024) np = 4;   // experiments: four panels per pass (one workgroup per CU from N = 1279 on)
+    if (nPanels < np * num_cus()) np = 1;  // not enough panels to keep every CU busy with pairs
     const size_t lds = (size_t)np * (N + 1) * 16;
-    const int threads = N > 5120 ? 1024 : ((N > 2560 || (np == 2 && N > 1280)) ? 512 : 256);
+    const int threads = N > 5120 ? 1024 : ((N > 2560 || (np >= 2 && N > 1280)) ? 512 : 256);
     const int thr = (lds > 80 * 1024) ? 1024 : threads;  // one workgroup per CU: give it all 16 waves
     int wgPerCU = (int)((160 * 1024) / (lds < 1024 ? 1024 : lds));
     const int waveCap = 32 / (thr / 64);
@@ -331,8 +332,9 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     if (g_tune.panel_grid > 0 && grid > g_tune.panel_grid) grid = g_tune.panel_grid / split * split;  // experiments: fewer workgroups than CUs
     typedef void (*kern_t)(const int2*, const int32_t*, const void*, const float4*, float, const float*, float*, int, int, int, int, int,
                            int, int, int);
-    kern_t kern = np == 2 ? (uniform ? (kern_t)spmm_panel_kernel<1, 2> : (kern_t)spmm_panel_kernel<0, 2>)
-                          : (uniform ? (kern_t)spmm_panel_kernel<1, 1> : (kern_t)spmm_panel_kernel<0, 1>);
+    kern_t kern = np == 4 ? (uniform ? (kern_t)spmm_panel_kernel<1, 4> : (kern_t)spmm_panel_kernel<0, 4>)
+                  : np == 2 ? (uniform ? (kern_t)spmm_panel_kernel<1, 2> : (kern_t)spmm_panel_kernel<0, 2>)
+                            : (uniform ? (kern_t)spmm_panel_kernel<1, 1> : (kern_t)spmm_panel_kernel<0, 1>);
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
                        Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, m.pn_ushift, g_tune.panel_rotate, split);
