@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -125,6 +126,15 @@ void run(const char* label, const float* X, int rows, long panel_floats, int blo
 }
 
 int main(int argc, char** argv) {
+    if (argc > 2 && !strcmp(argv[1], "one")) {   // `gather_ceiling one <rows per panel>`: one shape only (counter collection)
+        const int rows = atoi(argv[2]);
+        const long pf = (long)rows * 32;
+        float *X, *sink;
+        CK(hipMalloc(&X, pf * 8 * sizeof(float))); CK(hipMalloc(&sink, 64));
+        CK(hipMemset(X, 0, pf * 8 * sizeof(float)));
+        run<0, 8>("plain  8 in flight", X, rows, pf, 4096, sink);
+        return 0;
+    }
     if (argc > 1) {   // `gather_ceiling narrow`: row-width sweep for the EVGF tap analysis (profiles/r02_c_evgf)
         float *X, *sink;
         CK(hipMalloc(&X, (size_t)8 * 262144 * 128)); CK(hipMalloc(&sink, 64));

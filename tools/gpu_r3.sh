@@ -74,5 +74,36 @@ scale)   # multi-GPU rehearsal as far as one GPU allows: single process vs torch
   bash tools/scale.sh cfg4 1 > $O/scale_cfg4.log 2>&1; cat $O/scale_cfg4.log; cp gpurun_out/scale/*.json $O/ 2>/dev/null
   bash tools/scale.sh cfg2 1 > $O/scale_cfg2.log 2>&1; cat $O/scale_cfg2.log; cp gpurun_out/scale/cfg2*.json $O/ 2>/dev/null
   ;;
+diag)    # where do the gather kernels lose time?  TA / TCP / TLB / SQ counters of four targets, own passes per group
+  run_pmc() {  # $1 = tag, $2 = kernel substring, rest = command
+    tag=$1; kn=$2; shift 2
+    for grp in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+               "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" \
+               "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum" \
+               "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+               "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+               "TCC_REQ_sum TCC_TAG_STALL_sum TCC_BUSY_sum TCC_HIT_sum TCC_MISS_sum"; do
+      rm -rf $O/pm; timeout 300 rocprofv3 --pmc $grp --output-format csv -d $O/pm -o pmc -- "$@" > $O/pm.log 2>&1
+      python - "$O" "$tag" "$kn" <<'PY'
+import csv, glob, sys, collections
+O, tag, kn = sys.argv[1:4]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"{O}/pm/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if kn in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in agg.items():
+    print(f"{tag:28s} {k:42s} {sum(v[len(v)//2:]) / max(1, len(v) - len(v)//2):16.0f}   ({len(v)} launches, second half averaged)")
+PY
+    done
+  }
+  export GFHIP_EXPERIMENTS=1
+  run_pmc "microbench 4 MB panel" gather_kernel tools/gather_ceiling one 32768 | tee $O/diag_microbench_4MB.log
+  run_pmc "microbench 8 MB panel" gather_kernel tools/gather_ceiling one 65536 | tee $O/diag_microbench_8MB.log
+  run_pmc "hop ER" spmm_sell_kernel python tools/hop_probe.py cfg4 4 | tee $O/diag_hop_er.log
+  PROBE_GRAPH=band run_pmc "hop band" spmm_sell_kernel python tools/hop_probe.py cfg4 4 | tee $O/diag_hop_band.log
+  run_pmc "sweep lag=8 depth=2" sweep_kernel tools/xcd_sweep wg=2 accum=1 lag=8 depth=2 iters=3 | tee $O/diag_sweep.log
+  rm -rf $O/pm
+  ;;
 *) echo "unknown stage $S"; exit 2;;
 esac

@@ -110,13 +110,14 @@ __global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __re
     };
     f32x4 sink = {0.f, 0.f, 0.f, 0.f};
     f32x4* acc4 = reinterpret_cast<f32x4*>(accs);
-    auto accumulate = [&](const u32x4& w, const f32x4 (&x)[4]) {
-        const unsigned ee[4] = {w.x, w.y, w.z, w.w};
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto pack_dst = [&](const u32x4& w) -> u32x2 {   // the 4 destination rows of a word in 2 registers: a step in flight keeps 18 VGPRs, not 20
+        return (u32x2){(w.x >> 17) | ((w.y >> 17) << 16), (w.z >> 17) | ((w.w >> 17) << 16)};
+    };
+    auto accumulate = [&](const u32x2& dp, const f32x4 (&x)[4]) {
+        const int d[4] = {(int)(dp.x & 0xffffu) * 8 + sub, (int)(dp.x >> 16) * 8 + sub, (int)(dp.y & 0xffffu) * 8 + sub, (int)(dp.y >> 16) * 8 + sub};
         if (ACCUM == 3) {
-            int d[4];
             f32x4 a[4], sx[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) d[u] = (int)(ee[u] >> 17) * 8 + sub;
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[u] = acc4[d[u]];
 #pragma unroll
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __re
             for (int u = 0; u < 4; ++u) acc4[d[u]] = a[u] + sx[u];
         } else if (ACCUM == 1) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc4[(int)(ee[u] >> 17) * 8 + sub] += x[u];
+            for (int u = 0; u < 4; ++u) acc4[d[u]] += x[u];
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) sink += x[u];
@@ -178,28 +179,31 @@ __global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __re
             } else {
                 const float* Xb = X + (int64_t)b * N * 32;
                 const u32x4* st = stream + ((int64_t)(tile * kWaves + wave) * L4) * 8 + lg;
-                if (DEPTH == 4) {   // three steps of gathers in flight behind the one being accumulated (16 loads per lane)
-                    u32x4 w0 = st[0], w1 = st[8], w2 = st[16];
+                if (DEPTH == 4) {   // three steps of gathers in flight behind the one being accumulated (16 loads per lane); a step in
+                    // flight keeps its 16 data registers and its destinations packed in 2 -- the source words are dead once the gathers are issued
                     f32x4 xa[4], xb[4], xc[4], xd[4];
-                    wait_floor(); gather(Xb, w0, xa); gi += 1u; publish();
-                    wait_floor(); gather(Xb, w1, xb); gi += 1u; publish();
-                    wait_floor(); gather(Xb, w2, xc); gi += 1u; publish();
+                    u32x2 da, db, dc, dd;
+                    {
+                        const u32x4 w0 = st[0], w1 = st[8], w2 = st[16];
+                        wait_floor(); gather(Xb, w0, xa); da = pack_dst(w0); gi += 1u; publish();
+                        wait_floor(); gather(Xb, w1, xb); db = pack_dst(w1); gi += 1u; publish();
+                        wait_floor(); gather(Xb, w2, xc); dc = pack_dst(w2); gi += 1u; publish();
+                    }
+                    u32x4 w3 = st[24];
                     for (int s = 0; s < L4; s += 4) {   // L4 is a multiple of 4
-                        const u32x4 w3 = st[(int64_t)(s + 3) * 8];
                         const u32x4 w4 = st[(int64_t)(s + 4 < L4 ? s + 4 : L4 - 1) * 8];
                         const u32x4 w5 = st[(int64_t)(s + 5 < L4 ? s + 5 : L4 - 1) * 8];
+                        wait_floor(); gather(Xb, w3, xd); dd = pack_dst(w3); gi += 1u; publish();
+                        accumulate(da, xa);
                         const u32x4 w6 = st[(int64_t)(s + 6 < L4 ? s + 6 : L4 - 1) * 8];
-                        wait_floor(); gather(Xb, w3, xd); gi += 1u; publish();
-                        accumulate(w0, xa);
-                        wait_floor(); gather(Xb, w4, xa); gi += (s + 4 < L4) ? 1u : 0u; publish();
-                        accumulate(w1, xb);
-                        wait_floor(); gather(Xb, w5, xb); gi += (s + 5 < L4) ? 1u : 0u; publish();
-                        accumulate(w2, xc);
-                        wait_floor(); gather(Xb, w6, xc); gi += (s + 6 < L4) ? 1u : 0u; publish();
-                        accumulate(w3, xd);
-                        w0 = w4;
-                        w1 = w5;
-                        w2 = w6;
+                        wait_floor(); gather(Xb, w4, xa); da = pack_dst(w4); gi += (s + 4 < L4) ? 1u : 0u; publish();
+                        accumulate(db, xb);
+                        const u32x4 w7 = st[(int64_t)(s + 7 < L4 ? s + 7 : L4 - 1) * 8];
+                        wait_floor(); gather(Xb, w5, xb); db = pack_dst(w5); gi += (s + 5 < L4) ? 1u : 0u; publish();
+                        accumulate(dc, xc);
+                        wait_floor(); gather(Xb, w6, xc); dc = pack_dst(w6); gi += (s + 6 < L4) ? 1u : 0u; publish();
+                        accumulate(dd, xd);
+                        w3 = w7;
                     }
                 } else {
                 u32x4 w0 = st[0], w1 = st[8];
@@ -216,12 +220,12 @@ __global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __re
                     gather(Xb, w1, xb);              // step s + 1 in flight ...
                     gi += 1u;
                     publish();
-                    accumulate(w0, xa);              // ... while step s is accumulated
+                    accumulate(pack_dst(w0), xa);    // ... while step s is accumulated
                     wait_floor();
                     gather(Xb, w2, xa);
                     gi += (s + 2 < L4) ? 1u : 0u;
                     publish();
-                    accumulate(w1, xb);
+                    accumulate(pack_dst(w1), xb);
                     w0 = w2;
                     w1 = w3;
                 }
