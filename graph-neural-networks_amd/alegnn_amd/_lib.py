@@ -61,6 +61,9 @@ _SIGNATURES = {
     "gf_lsigf_db_forward": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_lsigf_db_backward": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                         _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gf_lsigf_forward_ex": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gf_lsigf_backward_ex": (_c.c_int, [_c.POINTER(_vp), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                        _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "gf_maxpool_forward": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gf_maxpool_backward": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gf_nvgf_scratch_floats": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),

@@ -145,6 +145,129 @@ def LSIGF(h, S, x, b=None, activation=None):
     return y
 
 
+_HANDOVER = os.environ.get("GFHIP_LAYER_HANDOVER", "1") != "0"
+
+
+class _LSIGFChainFunction(torch.autograd.Function):
+    """Consecutive ReLU graph-filter layers on ONE graph with the signals handed over in the internal column-panel layout
+    (gf_lsigf_forward_ex / gf_lsigf_backward_ex): layer l's contraction writes relu(y_l) straight into tap 0 of layer l+1's stack and,
+    in the backward, layer l+1 writes its dx -- masked by relu'(y_l) -- straight into tap 0 of layer l's adjoint stack.  Per inner
+    boundary one reference-layout tensor, one pack pass forward and one backward disappear (the reference permutes at every layer,
+    graphML.py:170-171; SelectionGNN strings the blocks together, architectures.py:286-294).  Arithmetic and summation orders are
+    those of the separate layers: outputs and gradients are bitwise the same."""
+
+    @staticmethod
+    def forward(ctx, x, gso, relu_last, *params):
+        L = _lib.lib()
+        nl = len(params) // 2
+        hs = [params[2 * l].contiguous() for l in range(nl)]
+        bs = [None if params[2 * l + 1] is None else params[2 * l + 1].contiguous() for l in range(nl)]
+        B, G0, N = x.shape
+        E = hs[0].shape[1]
+        x = x.contiguous()
+        dev = x.device
+        stacks = []
+        with torch.cuda.device(dev):
+            plans = gso.plans(dev)
+            st = torch.cuda.current_stream().cuda_stream
+            for l in range(nl):
+                F_, _, K, G = hs[l].shape
+                stacks.append(torch.empty((1 + E * (K - 1), B * G // 4, N, 4), dtype=torch.float32, device=dev))
+            y = torch.empty((B, hs[-1].shape[0], N), dtype=torch.float32, device=dev)
+            for l in range(nl):
+                F_, _, K, G = hs[l].shape
+                last = l == nl - 1
+                flags = (1 if (not last or relu_last) else 0) | (2 if l > 0 else 0) | (0 if last else 4)
+                out = y if last else stacks[l + 1]
+                _lib.check(L.gf_lsigf_forward_ex(plans, E, x.data_ptr() if l == 0 else None, hs[l].data_ptr(), _ptr(bs[l]), stacks[l].data_ptr(),
+                                                 out.data_ptr(), B, G, F_, K, N, flags, st), "gf_lsigf_forward_ex")
+        ctx.gso, ctx.nl, ctx.relu_last, ctx.B, ctx.N, ctx.E = gso, nl, bool(relu_last), B, N, E
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.save_for_backward(y if relu_last else None, *hs, *stacks)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        nl, B, N, E = ctx.nl, ctx.B, ctx.N, ctx.E
+        saved = ctx.saved_tensors
+        y_act, hs, stacks = saved[0], saved[1:1 + nl], saved[1 + nl:1 + 2 * nl]
+        dy = dy.contiguous()
+        dev = dy.device
+        grads = [None] * (2 * nl)
+        dx = None
+        with torch.cuda.device(dev):
+            plans = ctx.gso.plans(dev)
+            st = torch.cuda.current_stream().cuda_stream
+            Ps = [torch.empty((1 + E * (hs[l].shape[2] - 1), B * hs[l].shape[0] // 4, N, 4), dtype=torch.float32, device=dev) for l in range(nl)]
+            need_x = ctx.needs_input_grad[0]
+            for l in range(nl - 1, -1, -1):
+                F_, _, K, G = hs[l].shape
+                last, first = l == nl - 1, l == 0
+                need_dh = ctx.needs_input_grad[3 + 2 * l]
+                need_db = ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
+                dh = torch.empty_like(hs[l]) if need_dh else None
+                db = torch.empty((F_, 1), dtype=torch.float32, device=dev) if need_db else None
+                ws, ws_bytes = None, 0
+                if need_dh or need_db:
+                    ws_bytes = L.gf_grad_taps_workspace_bytes(B, N, G, F_, E, K)
+                    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+                if first:
+                    dx = torch.empty((B, G, N), dtype=torch.float32, device=dev) if need_x else None
+                    out, mask, oflag = dx, None, 0
+                else:                                   # hand the gradient to the layer below, masked by ITS ReLU: relu(y_{l-1}) is tap 0 here
+                    out, mask, oflag = Ps[l - 1], stacks[l], 4
+                flags = (0 if last else 2) | oflag
+                _lib.check(L.gf_lsigf_backward_ex(plans, E, dy.data_ptr() if last else None, _ptr(y_act) if last else None, stacks[l].data_ptr(),
+                                                  hs[l].data_ptr(), Ps[l].data_ptr(), _ptr(out), _ptr(dh), _ptr(db), _ptr(ws), ws_bytes, B, G, F_, K, N,
+                                                  flags, _ptr(mask), st), "gf_lsigf_backward_ex")
+                grads[2 * l], grads[2 * l + 1] = dh, db
+        return (dx, None, None, *grads)
+
+
+def lsigf_chain_supported(gso, x, layers):
+    """True when `layers` = [(h, b, relu), ...] (consecutive GraphFilter layers on `gso`) can hand their signals over in the panel
+    layout: every layer on the column-panel pipeline with per-feature bias, ReLU after every layer but possibly the last, Nin == N."""
+    if not _HANDOVER or len(layers) < 2 or x.dim() != 3 or x.device.type != "cuda" or x.shape[2] != gso.N:
+        return False
+    L = _lib.lib()
+    plans = gso.plans(x.device)
+    for l, (h, b, relu) in enumerate(layers):
+        F_, E, K, G = h.shape
+        if E != gso.E or (b is not None and (b.dim() != 2 or b.shape[1] != 1)) or (l < len(layers) - 1 and not relu):
+            return False
+        if l > 0 and layers[l - 1][0].shape[0] != G:
+            return False
+        if L.gf_lsigf_pipeline(plans, E, _padded_width(G), _padded_width(F_), K) != 2:
+            return False
+    return True
+
+
+def LSIGF_chain(layers, S, x):
+    """relu(LSIGF(h_L, S, ... relu(LSIGF(h_1, S, x, b_1)) ..., b_L)) for consecutive filter layers on one graph, with the intermediate
+    signals kept in the internal layout (see _LSIGFChainFunction).  layers = [(h [F,E,K,G], b [F,1]|None, relu: bool), ...]; the caller
+    checks ``lsigf_chain_supported`` first.  Feature counts that are not multiples of 8 are zero-padded exactly as LSIGF does."""
+    gso = SparseGSO.from_any(S)
+    _require_f32_cuda("x", x)
+    params = []
+    G0 = layers[0][0].shape[3]
+    Gp = _padded_width(G0)
+    if Gp != G0:
+        x = torch.nn.functional.pad(x, (0, 0, 0, Gp - G0))
+    for (h, b, _) in layers:
+        _require_f32_cuda("h", h)
+        F_, E, K, G = h.shape
+        Gp, Fp = _padded_width(G), _padded_width(F_)
+        if Gp != G or Fp != F_:
+            h = torch.nn.functional.pad(h, (0, Gp - G, 0, 0, 0, 0, 0, Fp - F_))
+            if b is not None and Fp != F_:
+                b = torch.nn.functional.pad(b, (0, 0, 0, Fp - F_))
+        params += [h, b]
+    y = _LSIGFChainFunction.apply(x, gso, bool(layers[-1][2]), *params)
+    F_last = layers[-1][0].shape[0]
+    return y[:, :F_last].contiguous() if y.shape[1] != F_last else y
+
+
 class _NVGFFunction(torch.autograd.Function):
     """Node-variant filter: gf_nvgf_forward / gf_nvgf_backward.  h is the expanded bank [F,E,K,G,N]; the bias is added by the
     kernel when it is per-feature ([F,1]), its gradient is a plain reduction of dy (left to autograd of the caller's add when

@@ -226,13 +226,40 @@ class SelectionGNN(nn.Module):
             x = x[:, :, self._order_index]                          # :437
         return x
 
+    def _run_gfl(self, x):
+        """self.GFL(x) (architectures.py:445) -- with runs of [GraphFilter, ReLU, NoPool] blocks on the same graph executed as ONE chain
+        whose intermediate signals stay in the library's internal layout (functional.LSIGF_chain): per inner boundary the
+        reference-layout round trip (graphML.py:170-171 + the next layer's re-layout) disappears.  Same values, bit for bit."""
+        from ..functional import LSIGF_chain, lsigf_chain_supported
+        mods = list(self.GFL)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            run = []
+            j = i
+            while (isinstance(mods[j], gml.GraphFilter) and mods[j]._gso is not None and (not run or mods[j]._gso is run[0]._gso)):
+                run.append(mods[j])
+                # the block continues only through a fused ReLU and a pooling stage that keeps every node
+                if not (mods[j].fused_activation == "relu" and j + 3 < len(mods) and isinstance(mods[j + 1], gml.FusedReLU)
+                        and isinstance(mods[j + 2], gml.NoPool) and mods[j + 2].nInputNodes == mods[j + 2].nOutputNodes == mods[j]._gso.N):
+                    break
+                j += 3
+            layers = [(f.weight, f.bias, f.fused_activation == "relu") for f in run]
+            if len(run) >= 2 and lsigf_chain_supported(run[0]._gso, x, layers):
+                x = LSIGF_chain(layers, run[0]._gso, x)
+                i += 3 * (len(run) - 1) + 1      # continue with the modules that follow the run's last filter (its FusedReLU is an identity)
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def splitForward(self, x):
         x = self._reorder(x)
         assert len(x.shape) == 3                                    # :440-443
         batchSize = x.shape[0]
         assert x.shape[1] == self.F[0]
         assert x.shape[2] == self.N[0]
-        y = self.GFL(x)                                             # :445
+        y = self._run_gfl(x)                                        # :445
         yFlat = y.reshape(batchSize, self.F[-1] * self.N[-1])       # :447
         return self.MLP(yFlat), y
 

@@ -118,9 +118,11 @@ extern "C" int gf_time_khop_panel(const gf_plan* const* plans, int32_t E, int32_
     return rc;
 }
 
+// lx: layer-to-layer hand-over inside the panel pipeline (gf_lsigf_forward_ex / gf_lsigf_backward_ex): bit 1 = tap 0 of the stack already
+// holds the input as column panels (the previous call wrote it there: no pack pass), bit 2 = the result goes out as column panels.
 static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z,
-                              float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream, int relu) {
-    GF_REQUIRE_ARG(plans && x && h && Z && y, "gf_lsigf_forward: NULL argument");
+                              float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream, int relu, int lx = 0) {
+    GF_REQUIRE_ARG(plans && (x || (lx & 2)) && h && Z && y, "gf_lsigf_forward: NULL argument");
     GF_REQUIRE_SHAPE(E > 0 && B > 0 && G > 0 && F > 0 && K > 0 && Nin > 0, "gf_lsigf_forward: bad shape E=%d B=%d G=%d F=%d K=%d Nin=%d",
                      E, B, G, F, K, Nin);
     GF_REQUIRE_ARG(plans[0] != nullptr, "gf_lsigf_forward: plan 0 is NULL");
@@ -132,12 +134,17 @@ static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const floa
     }
     const int pipe = pick_pipeline(plans, E, G, F, K);
     if (pipe < 0) return pipe;
+    if ((lx & 6) && (pipe != 2 || Nin != N)) {
+        gf_set_error("gf_lsigf_forward_ex: the panel hand-over needs the column-panel pipeline and Nin == N (pipeline %d, Nin %d, N %d)", pipe, Nin, N);
+        return GF_ERR_UNSUPPORTED;
+    }
     if (pipe == 2) {
-        int rc = gf_pack_panels_launch(x, Z, B, G, Nin, N, gf_stream(stream), nullptr);
+        int rc = (lx & 2) ? GF_OK : gf_pack_panels_launch(x, Z, B, G, Nin, N, gf_stream(stream), nullptr);
         if (rc != GF_OK) return rc;
         rc = khop_panel(plans, E, GF_OP_FWD, Z, B, G, K, gf_stream(stream));
         if (rc != GF_OK) return rc;
-        return gf_contract_panel_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream));
+        return gf_contract_panel_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream),
+                                        (lx & 4) ? 1 : 0, nullptr);
     }
     int rc = gf_layout_bgn_to_bng(x, Z, B, G, Nin, N, stream);
     if (rc != GF_OK) return rc;
@@ -148,8 +155,8 @@ static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const floa
 
 static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const float* dy, const float* Z, const float* h, float* P,
                                float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes, int32_t B, int32_t G,
-                               int32_t F, int32_t K, int32_t Nin, void* stream, const float* y_relu) {
-    GF_REQUIRE_ARG(plans && dy && h && P, "gf_lsigf_backward: NULL argument");
+                               int32_t F, int32_t K, int32_t Nin, void* stream, const float* y_relu, int lx = 0, const float* dx_mask = nullptr) {
+    GF_REQUIRE_ARG(plans && (dy || (lx & 2)) && h && P, "gf_lsigf_backward: NULL argument");
     GF_REQUIRE_SHAPE(E > 0 && B > 0 && G > 0 && F > 0 && K > 0 && Nin > 0, "gf_lsigf_backward: bad shape E=%d B=%d G=%d F=%d K=%d Nin=%d",
                      E, B, G, F, K, Nin);
     GF_REQUIRE_ARG(plans[0] != nullptr, "gf_lsigf_backward: plan 0 is NULL");
@@ -161,15 +168,22 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
     }
     const int pipe = pick_pipeline(plans, E, G, F, K);
     if (pipe < 0) return pipe;
+    if ((lx & 6) && (pipe != 2 || Nin != N)) {
+        gf_set_error("gf_lsigf_backward_ex: the panel hand-over needs the column-panel pipeline and Nin == N (pipeline %d, Nin %d, N %d)", pipe, Nin, N);
+        return GF_ERR_UNSUPPORTED;
+    }
     if (pipe == 2) {
-        int rc = gf_pack_panels_launch(dy, P, B, F, Nin, N, gf_stream(stream), y_relu);  // P[0] = dy (masked by y > 0) as panels, rows >= Nin zero
+        // P[0] = dy (masked by y > 0) as panels, rows >= Nin zero -- unless the next layer's backward already wrote it there (lx bit 1)
+        int rc = (lx & 2) ? GF_OK : gf_pack_panels_launch(dy, P, B, F, Nin, N, gf_stream(stream), y_relu);
         if (rc != GF_OK) return rc;
+        const int dxp = (lx & 4) ? 1 : 0;
         if (dx && dh && g_tune.bwd_fuse && gf_bwd_fused_supported(G, F, E, K)) {
             // dh_t = X0^T P_t: the tap gradient reads the adjoint stack the data path builds anyway (and tap 0 of the saved stack)
             GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
             rc = khop_panel(plans, E, GF_OP_BWD, P, B, F, K, gf_stream(stream));
             if (rc != GF_OK) return rc;
-            return gf_bwd_fused_panel_launch(P, Z, h, dx, dh, dbias, workspace, workspace_bytes, B, N, Nin, G, F, E, K, gf_stream(stream));
+            return gf_bwd_fused_panel_launch(P, Z, h, dx, dh, dbias, workspace, workspace_bytes, B, N, Nin, G, F, E, K, gf_stream(stream),
+                                             /*node_major=*/0, dxp, dx_mask);
         }
         if (dh || dbias) {
             GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
@@ -179,7 +193,7 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
         if (dx) {
             rc = khop_panel(plans, E, GF_OP_BWD, P, B, F, K, gf_stream(stream));
             if (rc != GF_OK) return rc;
-            rc = gf_contract_panel_launch(P, h, nullptr, dx, B, N, Nin, G, F, E, K, /*transpose_bank=*/1, gf_stream(stream));
+            rc = gf_contract_panel_launch(P, h, nullptr, dx, B, N, Nin, G, F, E, K, /*transpose_bank=*/1, gf_stream(stream), dxp, dx_mask);
         }
         return rc;
     }
@@ -232,4 +246,23 @@ extern "C" int gf_lsigf_backward_relu(const gf_plan* const* plans, int32_t E, co
                                       size_t workspace_bytes, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream) {
     GF_REQUIRE_ARG(y != nullptr, "gf_lsigf_backward_relu: y (the saved forward output) is NULL");
     return lsigf_backward_impl(plans, E, dy, Z, h, P, dx, dh, dbias, workspace, workspace_bytes, B, G, F, K, Nin, stream, y);
+}
+
+// Consecutive filter layers on the same graph (SelectionGNN with NoPool, architectures.py:286-294: GFL = [filter, sigma, rho, filter, ...])
+// hand their signals over in the internal column-panel layout: layer l's contraction writes sigma(y_l) straight into tap 0 of layer
+// l+1's stack (no reference-layout round trip: one unpack-transpose in the epilogue and one pack pass less per boundary), and in
+// the backward layer l+1 writes dx, masked by sigma'(y_l) = [tap 0 of its own stack > 0], straight into tap 0 of layer l's adjoint stack.
+extern "C" int gf_lsigf_forward_ex(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z, float* y,
+                                   int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, int32_t flags, void* stream) {
+    GF_REQUIRE_ARG((flags & ~7) == 0, "gf_lsigf_forward_ex: flags = %d", flags);
+    return lsigf_forward_impl(plans, E, x, h, bias, Z, y, B, G, F, K, Nin, stream, flags & 1, flags & 6);
+}
+
+extern "C" int gf_lsigf_backward_ex(const gf_plan* const* plans, int32_t E, const float* dy, const float* y_relu, const float* Z, const float* h,
+                                    float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes, int32_t B, int32_t G,
+                                    int32_t F, int32_t K, int32_t Nin, int32_t flags, const float* dx_mask, void* stream) {
+    GF_REQUIRE_ARG((flags & ~6) == 0, "gf_lsigf_backward_ex: flags = %d", flags);
+    GF_REQUIRE_ARG(!(flags & 2) || y_relu == nullptr, "gf_lsigf_backward_ex: a handed-over gradient is already masked (y_relu must be NULL)");
+    GF_REQUIRE_ARG(dx_mask == nullptr || (flags & 4), "gf_lsigf_backward_ex: dx_mask is only defined for a panel dx");
+    return lsigf_backward_impl(plans, E, dy, Z, h, P, dx, dh, dbias, workspace, workspace_bytes, B, G, F, K, Nin, stream, y_relu, flags & 6, dx_mask);
 }

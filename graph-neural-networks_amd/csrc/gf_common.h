@@ -169,7 +169,8 @@ int gf_contract_launch(const float* Z, const float* h, const float* bias, float*
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)
 bool gf_bwd_fused_supported(int G, int F, int E, int K);
 int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
-                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st, int node_major = 0);
+                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st, int node_major = 0,
+                              int dx_panels = 0, const float* maskp = nullptr);
 bool gf_panel_supported(const gf_plan* const* plans, int E, int G, int F, int K);
 bool gf_contract_panel_fits(int Cin, int Cout, int T);
 bool gf_chain_available(const gf_plan* plan, int op);
@@ -181,4 +182,4 @@ int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int 
 int gf_layout_masked_launch(const float* dy, const float* y, float* X, int B, int G, int Nin, int N, hipStream_t st);
 int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st);
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
-                             int F, int E, int K, int transpose_bank, hipStream_t st);
+                             int F, int E, int K, int transpose_bank, hipStream_t st, int out_panels = 0, const float* maskp = nullptr);

@@ -191,7 +191,12 @@ template <int NT, int CIN8>
 __global__ __launch_bounds__(kThreads) void contract_panel_kernel(const float* __restrict__ Zp, BankView bank,
                                                                   const float* __restrict__ bias, float* __restrict__ out, int B,
                                                                   int N, int Nout, int Cout, int T, int tilesPerB,
-                                                                  int64_t totalTiles) {
+                                                                  int64_t totalTiles, int out_panels, const float* __restrict__ maskp) {
+    // out_panels = 1 (layer-to-layer hand-over): the result is written as column panels out[b * Cout/4 + o/4][n][o % 4] -- the layout
+    // the NEXT layer's K-hop kernels read (its tap 0), or, for the transposed bank, the previous layer's adjoint tap 0 -- instead of the
+    // reference layout [B, Cout, Nout].  A lane's accumulators are 4 consecutive outputs of one node per register quad: exactly one
+    // 16-byte panel entry, consecutive lanes = consecutive nodes.  maskp (panels of the same shape, nullable): entries whose mask
+    // value is <= 0 are written as 0 (the ReLU mask of the layer the gradient is handed to: its activation IS that panel tensor).
     constexpr int Cin = CIN8 * 8;
     constexpr int Cop = NT * 32;
     constexpr int Q = Cin / 4;
@@ -249,7 +254,28 @@ __global__ __launch_bounds__(kThreads) void contract_panel_kernel(const float* _
             }
         }
 
-        if (nvalid) {
+        if (nvalid && out_panels) {
+            const int QO = Cout >> 2;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = nt * 8 + 2 * j + half;   // outputs 4q .. 4q + 3
+                    if (q < QO) {
+                        const int64_t at = (((int64_t)b * QO + q) * N + (n0 + l31)) * 4;
+                        float4 v = make_float4(bank.act(acc[nt][4 * j]), bank.act(acc[nt][4 * j + 1]), bank.act(acc[nt][4 * j + 2]),
+                                               bank.act(acc[nt][4 * j + 3]));
+                        if (maskp) {
+                            const float4 m = *reinterpret_cast<const float4*>(maskp + at);
+                            v.x = m.x > 0.f ? v.x : 0.f;
+                            v.y = m.y > 0.f ? v.y : 0.f;
+                            v.z = m.z > 0.f ? v.z : 0.f;
+                            v.w = m.w > 0.f ? v.w : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(out + at) = v;
+                    }
+                }
+        } else if (nvalid) {
             float* ob = out + (int64_t)b * Cout * Nout + n0 + l31;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -264,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void contract_panel_kernel(const float* _
 
 template <int NT, int CIN8>
 int launch_panel(const float* Zp, const BankView& bank, const float* bias, float* out, int B, int N, int Nout, int Cout, int T,
-                 hipStream_t st) {
+                 hipStream_t st, int out_panels, const float* maskp) {
     constexpr int Cin = CIN8 * 8;
     const size_t lds = (size_t)T * Cin * NT * 32 * sizeof(float);
     const int tilesPerB = (Nout + 31) / 32;
@@ -275,20 +301,20 @@ int launch_panel(const float* Zp, const BankView& bank, const float* bias, float
     auto kern = contract_panel_kernel<NT, CIN8>;
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, st, Zp, bank, bias, out, B, N, Nout, Cout, T, tilesPerB,
-                       totalTiles);
+                       totalTiles, out_panels, maskp);
     GF_LAUNCH_CHECK("contract_panel_kernel");
     return GF_OK;
 }
 
 template <int NT>
 int dispatch_cin_panel(int cin8, const float* Zp, const BankView& bank, const float* bias, float* out, int B, int N, int Nout,
-                       int Cout, int T, hipStream_t st) {
+                       int Cout, int T, hipStream_t st, int out_panels, const float* maskp) {
     switch (cin8) {
-        case 1: return launch_panel<NT, 1>(Zp, bank, bias, out, B, N, Nout, Cout, T, st);
-        case 2: return launch_panel<NT, 2>(Zp, bank, bias, out, B, N, Nout, Cout, T, st);
-        case 4: return launch_panel<NT, 4>(Zp, bank, bias, out, B, N, Nout, Cout, T, st);
-        case 8: return launch_panel<NT, 8>(Zp, bank, bias, out, B, N, Nout, Cout, T, st);
-        default: return launch_panel<NT, 16>(Zp, bank, bias, out, B, N, Nout, Cout, T, st);
+        case 1: return launch_panel<NT, 1>(Zp, bank, bias, out, B, N, Nout, Cout, T, st, out_panels, maskp);
+        case 2: return launch_panel<NT, 2>(Zp, bank, bias, out, B, N, Nout, Cout, T, st, out_panels, maskp);
+        case 4: return launch_panel<NT, 4>(Zp, bank, bias, out, B, N, Nout, Cout, T, st, out_panels, maskp);
+        case 8: return launch_panel<NT, 8>(Zp, bank, bias, out, B, N, Nout, Cout, T, st, out_panels, maskp);
+        default: return launch_panel<NT, 16>(Zp, bank, bias, out, B, N, Nout, Cout, T, st, out_panels, maskp);
     }
 }
 
@@ -300,7 +326,7 @@ bool gf_contract_panel_fits(int Cin, int Cout, int T) {
 }
 
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G, int F,
-                             int E, int K, int transpose_bank, hipStream_t st) {
+                             int E, int K, int transpose_bank, hipStream_t st, int out_panels, const float* maskp) {
     const int T = gf_num_taps(E, K);
     const int Cin = (transpose_bank & 1) ? F : G, Cout = (transpose_bank & 1) ? G : F;
     BankView bank{h, E, K, G, F, (transpose_bank & 1) ? 1 : 0, (transpose_bank >> 1) & 1};  // bit 0: transposed bank, bit 1: ReLU epilogue
@@ -310,10 +336,12 @@ int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias,
     const size_t lds = (size_t)T * Cin * nt * 32 * sizeof(float);
     GF_REQUIRE_SHAPE(cin_ok && Cout <= 128 && lds <= 160 * 1024,
                      "gf_contract_panel: unsupported widths Cin=%d Cout=%d T=%d (Cin in {8,16,32,64,128}, Cout <= 128)", Cin, Cout, T);
+    GF_REQUIRE_SHAPE(!out_panels || (Nout == N && Cout % 8 == 0), "gf_contract_panel: panel output needs Nout == N and Cout %% 8 == 0 (Nout=%d N=%d Cout=%d)",
+                     Nout, N, Cout);
     switch (nt) {
-        case 1: return dispatch_cin_panel<1>(cin8, Zp, bank, bias, out, B, N, Nout, Cout, T, st);
-        case 2: return dispatch_cin_panel<2>(cin8, Zp, bank, bias, out, B, N, Nout, Cout, T, st);
-        default: return dispatch_cin_panel<4>(cin8, Zp, bank, bias, out, B, N, Nout, Cout, T, st);
+        case 1: return dispatch_cin_panel<1>(cin8, Zp, bank, bias, out, B, N, Nout, Cout, T, st, out_panels, maskp);
+        case 2: return dispatch_cin_panel<2>(cin8, Zp, bank, bias, out, B, N, Nout, Cout, T, st, out_panels, maskp);
+        default: return dispatch_cin_panel<4>(cin8, Zp, bank, bias, out, B, N, Nout, Cout, T, st, out_panels, maskp);
     }
 }
 

@@ -379,7 +379,10 @@ template <int T, int GIN8, int FIN8, int NM>
 __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* __restrict__ Pp, const float* __restrict__ X0p,
                                                                    const float* __restrict__ h, float* __restrict__ dx,
                                                                    float* __restrict__ partial, float* __restrict__ partial_b, int R,
-                                                                   int N, int Nout, int B, int E, int K, int rowsPerWave) {
+                                                                   int N, int Nout, int B, int E, int K, int rowsPerWave, int dx_panels,
+                                                                   const float* __restrict__ maskp) {
+    // dx_panels = 1 (layer-to-layer hand-over, panel stacks only): dx goes out as column panels dx[b * G/4 + g/4][n][g % 4], masked by
+    // maskp (nullable; the activation panels of the layer the gradient is handed to: entries <= 0 give 0) -- see contract_panel_kernel
     constexpr int G = GIN8 * 8, F = FIN8 * 8, QG = G / 4, QF = F / 4;
     constexpr int TS = 36;  // padded row stride of the wave-private tiles (floats): 16-byte aligned rows, conflict-free column reads
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -470,7 +473,24 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
 #pragma unroll
             for (int u = 0; u < FIN8; ++u) cur[u] = nxt[u];
         }
-        if (rv && n < Nout) {
+        if (rv && dx_panels) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = 2 * j + half;   // g = 4q .. 4q + 3
+                if (q < QG) {
+                    const int64_t at = (((int64_t)b * QG + q) * N + n) * 4;
+                    float4 v = make_float4(acc_x[4 * j], acc_x[4 * j + 1], acc_x[4 * j + 2], acc_x[4 * j + 3]);
+                    if (maskp) {
+                        const float4 m = *reinterpret_cast<const float4*>(maskp + at);
+                        v.x = m.x > 0.f ? v.x : 0.f;
+                        v.y = m.y > 0.f ? v.y : 0.f;
+                        v.z = m.z > 0.f ? v.z : 0.f;
+                        v.w = m.w > 0.f ? v.w : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(dx + at) = v;
+                }
+            }
+        } else if (rv && n < Nout) {
             float* ob = dx + (int64_t)b * G * Nout + n;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -520,8 +540,10 @@ bool gf_bwd_fused_supported(int G, int F, int E, int K) {
 }
 
 int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
-                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st, int node_major) {
+                              size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st, int node_major,
+                              int dx_panels, const float* maskp) {
     const Geo g = make_geo(B, N, G, F, E, K);
+    GF_REQUIRE_SHAPE(!dx_panels || (!node_major && Nout == N), "gf_lsigf_backward: panel hand-over of dx needs the panel pipeline and Nin == N");
     GF_REQUIRE_SHAPE(g.R < (int64_t)INT32_MAX - 4096, "gf_lsigf_backward: B*N = %lld too large", (long long)g.R);
     GF_REQUIRE_ARG(workspace && workspace_bytes >= g.bytes, "gf_lsigf_backward: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
     GF_REQUIRE_SHAPE(g.passes == 1 && g.ctp == g.T, "gf_lsigf_backward: fused backward geometry");
@@ -533,7 +555,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
         auto kern = node_major ? bwd_fused_panel_kernel<TT, GG, FF, 1> : bwd_fused_panel_kernel<TT, GG, FF, 0>;                 \
         if (lds > 64 * 1024) attr = gf_grant_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, dim3(g.strips), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
-                           Nout, B, E, K, g.rowsPerWave);                                                                       \
+                           Nout, B, E, K, g.rowsPerWave, dx_panels, maskp);                                                     \
     } while (0)
 #define GF_BF_F(TT, GG)                                                                                                         \
     switch (F / 8) {                                                                                                            \

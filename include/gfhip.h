@@ -227,6 +227,21 @@ int gf_lsigf_db_backward(const float* S, const float* dy, const float* Z, const 
                          float* dh, float* dbias, float* dS, void* workspace, size_t workspace_bytes, int32_t B, int32_t T, int32_t G,
                          int32_t F, int32_t E, int32_t K, int32_t N, int32_t shift, void* stream);
 
+/* ---- layer-to-layer hand-over in the internal layout (no reference counterpart: the reference permutes at every layer,
+ * graphML.py:170-171; SelectionGNN strings [filter, sigma, rho] blocks together, architectures.py:286-294).  Column-panel pipeline
+ * only (gf_lsigf_pipeline() == 2) and Nin == N, else GF_ERR_UNSUPPORTED.
+ *   flags bit 0 (forward): fused ReLU epilogue, as gf_lsigf_forward_relu
+ *   flags bit 1: tap 0 of the stack (Z for forward, P for backward) ALREADY holds the input as column panels -- x / dy are ignored
+ *                (NULL allowed): the neighbouring layer's call wrote it there
+ *   flags bit 2: the result (y, resp. dx) is written as column panels [B*C/4][N][4] -- pass the neighbouring layer's tap 0;
+ *                backward: masked by dx_mask (panels of the same shape, nullable; entries <= 0 give 0 = the ReLU of the layer below,
+ *                whose activation is tap 0 of THIS layer's forward stack). */
+int gf_lsigf_forward_ex(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z, float* y,
+                        int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, int32_t flags, void* stream);
+int gf_lsigf_backward_ex(const gf_plan* const* plans, int32_t E, const float* dy, const float* y_relu, const float* Z, const float* h,
+                         float* P, float* dx, float* dh, float* dbias, void* workspace, size_t workspace_bytes, int32_t B, int32_t G,
+                         int32_t F, int32_t K, int32_t Nin, int32_t flags, const float* dx_mask, void* stream);
+
 /* ---- measurement hook: run ONE hop `iters` times on `stream` bracketed by HIP events on that stream and return
  * the average milliseconds per launch (bench.py's roofline leg; hipEvents see the launch stream, torch events may not). */
 int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* X_out, int32_t B, int32_t W,

@@ -1244,3 +1244,47 @@ def test_training_step_is_hip_graph_capturable():
         for a, p in zip(graph_grads, params):
             assert torch.equal(a, p.grad)
     assert abs(eager_loss - eager_loss) == 0 and len(eager_grads) == len(params)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# layer-to-layer hand-over in the internal layout (gf_lsigf_forward_ex / gf_lsigf_backward_ex)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dimF,K,N,B", [([1, 64, 32], [5, 5], 234, 5), ([3, 8, 16, 8], [3, 2, 4], 500, 7), ([32, 32, 32], [5, 5], 2000, 16),
+                                        ([2, 16, 8], [3, 3], 97, 3), ([2, 24, 40], [3, 3], 97, 3)])
+def test_layer_handover_is_bitwise_the_separate_layers(dimF, K, N, B, monkeypatch):
+    """Runs of [GraphFilter, ReLU, NoPool] blocks keep their signals in the column-panel layout between layers: the same kernels do the
+    same arithmetic in the same order, only one reference-layout round trip per inner boundary is gone -- outputs, input gradient and
+    every parameter gradient must be BITWISE those of the separate layers (which the golden tests pin to the reference)."""
+    from alegnn_amd import functional
+    A = graphgen.sbm(N, avg_degree=8.0, seed=3)
+    torch.manual_seed(1)
+    net = SelectionGNN(dimF, K, True, torch.nn.ReLU, [N] * len(K), gml.NoPool, [1] * len(K), [4], A).to(DEV)
+    x = torch.randn(B, dimF[0], N, device=DEV)
+    w = torch.randn(B, 4, device=DEV)
+    outs = {}
+    for mode in (True, False):
+        monkeypatch.setattr(functional, "_HANDOVER", mode)
+        xr = x.clone().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        calls = []
+        orig = functional._LSIGFChainFunction.apply
+        monkeypatch.setattr(functional._LSIGFChainFunction, "apply", staticmethod(lambda *a, **k: (calls.append(1), orig(*a, **k))[1]))
+        y, ygnn = net.splitForward(xr)
+        (y * w).sum().backward()
+        monkeypatch.setattr(functional._LSIGFChainFunction, "apply", orig)
+        chainable = all(w in (8, 16, 32, 64, 128) for w in (functional._padded_width(f) for f in dimF))   # widths of the panel pipeline
+        assert bool(calls) == (mode and chainable)                   # the chain really ran (or really did not)
+        outs[mode] = [y.detach().clone(), ygnn.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+    for a, b_ in zip(outs[True], outs[False]):
+        assert torch.equal(a, b_)
+
+
+def test_handover_entry_points_refuse_what_they_cannot_do():
+    L = _lib.lib()
+    A = graphgen.er(20000, avg_degree=6.0, seed=0)                   # N > 10239: node-major pipeline
+    gso = SparseGSO.from_any(A)
+    plans = gso.plans(DEV)
+    t = torch.zeros(16, device=DEV)
+    rc = L.gf_lsigf_forward_ex(plans, 1, t.data_ptr(), t.data_ptr(), None, t.data_ptr(), t.data_ptr(), 1, 8, 8, 2, 20000, 4, stream())
+    assert rc == -5 or rc != 0                                       # GF_ERR_UNSUPPORTED: no panel pipeline here
+    assert b"hand-over" in L.gf_last_error()
