@@ -701,3 +701,42 @@ def test_learn_attention_gso_host_logic(path):
     assert relerr(q.detach().numpy(), d["q"]) < 1e-12
     for t, k in ((x, "dx"), (a, "da"), (W, "dW")):
         assert relerr(t.grad.numpy(), d[k]) < 1e-11, k
+
+
+def test_locality_groups_are_cached_per_pattern_on_disk(tmp_path, monkeypatch):
+    """gf_plan_create clusters the rows of large graphs into locality groups (host work, ~1 s at N = 4e4).  With GFHIP_PLAN_CACHE_DIR
+    set the labels are stored once per sparsity pattern (groups_<hash>_<n>_<nnz>.bin: header + one int32 per row) and a damaged file
+    is recomputed, never trusted.  (No GPU here: the call fails at the first device allocation, AFTER the host-side clustering.)"""
+    import ctypes
+    import time
+    from alegnn_amd import _lib, graphgen
+    monkeypatch.setenv("GFHIP_PLAN_CACHE_DIR", str(tmp_path))
+    n = 40000
+    A = graphgen.er(n, avg_degree=4.0, seed=5)
+    rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    col = np.ascontiguousarray(A.indices, dtype=np.int32)
+    val = np.ascontiguousarray(A.data)
+    L = _lib.lib()
+
+    def create():
+        out = ctypes.c_void_p()
+        t0 = time.perf_counter()
+        rc = L.gf_plan_create(n, A.nnz, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, int(val.dtype == np.float64), 0, ctypes.byref(out))
+        dt = time.perf_counter() - t0
+        if rc == 0:
+            L.gf_plan_destroy(out)
+        return rc, dt
+    rc, t_first = create()
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1 and files[0].name.startswith("groups_") and files[0].name.endswith(f"_{n}_{A.nnz}.bin")
+    assert files[0].stat().st_size == 8 + 4 * n
+    labels = np.fromfile(files[0], dtype=np.int32)
+    assert labels[0] == n and labels[1] >= 2 and labels[2:].min() >= 0 and labels[2:].max() < labels[1]
+    assert np.bincount(labels[2:]).max() <= 1.04 * n / labels[1] + 2          # balanced groups
+    files[0].write_bytes(files[0].read_bytes()[: 8 + 4 * (n // 2)])          # truncate: must be recomputed and rewritten
+    other = graphgen.er(n, avg_degree=4.0, seed=6)                            # another pattern -> another file
+    out = ctypes.c_void_p()
+    L.gf_plan_create(n, other.nnz, np.ascontiguousarray(other.indptr, dtype=np.int32).ctypes.data,
+                     np.ascontiguousarray(other.indices, dtype=np.int32).ctypes.data, np.ascontiguousarray(other.data).ctypes.data,
+                     int(other.data.dtype == np.float64), 0, ctypes.byref(out))
+    assert len(list(tmp_path.iterdir())) == 2
