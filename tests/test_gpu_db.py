@@ -233,3 +233,79 @@ def test_grnn_db_against_oracle_flocking_size():
     assert relerr(z.detach().cpu().numpy(), zr.detach().numpy()) < 2 * FWD_RTOL
     for k in arrs:
         assert relerr(got[k].grad.cpu().numpy(), ref[k].grad.numpy()) < GRAD_RTOL, k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# edge cases of the host layer: missing biases, per-node bias, one tap, a single time step, gates of mixed kinds
+# ---------------------------------------------------------------------------------------------------------------
+def test_lsigf_db_per_node_bias_and_single_step():
+    """bias [F,N] (graphML.py:1008-1010: added after the filter, not fused) and T = 1 (every delayed tap is zero)."""
+    rng = np.random.RandomState(11)
+    B, T, E, N, G, F, K = 3, 1, 1, 21, 5, 7, 3
+    S = (rng.rand(B, T, E, N, N) < 0.3) * rng.randn(B, T, E, N, N)
+    h, x, b, dy = rng.randn(F, E, K, G), rng.randn(B, T, G, N), rng.randn(F, N), rng.randn(B, T, F, N)
+    ref = [torch.tensor(v, requires_grad=True) for v in (h, x, b)]
+    yr = dbo.lsigf_db(ref[0], torch.tensor(S), ref[1], ref[2])
+    yr.backward(torch.tensor(dy))
+    got = [cu(v, True) for v in (h, x, b)]
+    y = gml.LSIGF_DB(got[0], cu(S), got[1], got[2])
+    y.backward(cu(dy))
+    assert relerr(y.detach().cpu().numpy(), yr.detach().numpy()) < FWD_RTOL
+    for g, r in zip(got, ref):
+        assert relerr(g.grad.cpu().numpy(), r.grad.numpy()) < GRAD_RTOL
+    # with T = 1 only tap 0 contributes: the taps k >= 1 get exactly zero gradient
+    assert float(got[0].grad[:, :, 1:].abs().max()) == 0.0
+
+
+def test_hidden_state_db_without_bias_and_one_tap():
+    rng = np.random.RandomState(12)
+    B, T, E, N, F, H, K = 2, 4, 1, 18, 3, 8, 1
+    S = (rng.rand(B, T, E, N, N) < 0.3) * rng.rand(B, T, E, N, N)
+    layer = gml.HiddenState_DB(F, H, K, nonlinearity=torch.tanh, E=E, bias=False).to(DEV)
+    layer.addGSO(cu(S))
+    x, z0 = rng.randn(B, T, F, N), rng.randn(B, H, N)
+    xt, z0t = cu(x, True), cu(z0, True)
+    z, zT = layer(xt, z0t)
+    assert tuple(zT.shape) == (B, 1, 1, H, N)
+    z.sum().backward()
+    a, b_ = (p.detach().cpu().double().requires_grad_(True) for p in (layer.aWeights, layer.bWeights))
+    xr, z0r = torch.tensor(x, requires_grad=True), torch.tensor(z0, requires_grad=True)
+    zr = dbo.grnn_db(a, b_, torch.tensor(S), xr, z0r, torch.tanh, None, None)
+    zr.sum().backward()
+    assert relerr(z.detach().cpu().numpy(), zr.detach().numpy()) < 2 * FWD_RTOL
+    assert relerr(xt.grad.cpu().numpy(), xr.grad.numpy()) < GRAD_RTOL
+    assert relerr(z0t.grad.cpu().numpy(), z0r.grad.numpy()) < GRAD_RTOL
+    assert relerr(layer.aWeights.grad.cpu().numpy(), a.grad.numpy()) < GRAD_RTOL
+    assert relerr(layer.bWeights.grad.cpu().numpy(), b_.grad.numpy()) < GRAD_RTOL
+
+
+def test_per_sample_filter_one_tap_gives_zero_gate_gradient():
+    """K = 1: the operator is never applied, so an edge gate gets a zero gradient (and the kernels are not asked for one)."""
+    from alegnn_amd.functional_db import filter_per_sample
+    rng = np.random.RandomState(13)
+    B, T, N, G, F = 2, 3, 10, 8, 8
+    S5 = cu(rng.rand(B, T, 1, N, N), True)
+    h, x = cu(rng.randn(F, 1, 1, G), True), cu(rng.randn(B, T, G, N), True)
+    y = filter_per_sample(h, S5, x, None)
+    y.sum().backward()
+    assert float(S5.grad.abs().max()) == 0.0
+    want = torch.einsum("fg,btgn->btfn", h.detach()[:, 0, 0], x.detach())
+    assert relerr(y.detach().cpu().numpy(), want.cpu().numpy()) < FWD_RTOL
+
+
+def test_mixed_gates_edge_input_gate_with_node_forget_gate():
+    """q_hat an edge gate, q_check a node gate: each branch of GatedGRNN is independent (graphML.py:1385, :1421)."""
+    rng = np.random.RandomState(14)
+    B, T, N, F, H, K = 2, 3, 16, 3, 8, 3
+    S = ((rng.rand(1, N, N) < 0.3) * rng.randn(1, N, N)).astype(np.float64)
+    arrs = dict(a=rng.randn(H, 1, K, F) / 3, b=rng.randn(H, 1, K, H) / 5, x=rng.randn(B, T, F, N), z0=rng.randn(B, H, N), qh=rng.rand(B, T, 1, N, N),
+                qc=rng.rand(B, T, 1, N), xb=rng.randn(H, 1) * 0.1, zb=rng.randn(H, 1) * 0.1)
+    ref = {k: torch.tensor(v, requires_grad=True) for k, v in arrs.items()}
+    zr = dbo.gated_grnn(ref["a"], ref["b"], torch.tensor(S), ref["x"], ref["z0"], torch.tanh, ref["qh"], ref["qc"], ref["xb"], ref["zb"])
+    zr.sum().backward()
+    got = {k: cu(v, True) for k, v in arrs.items()}
+    z = gml.GatedGRNN(got["a"], got["b"], torch.tensor(S), got["x"], got["z0"], torch.tanh, got["qh"], got["qc"], got["xb"], got["zb"])
+    z.sum().backward()
+    assert relerr(z.detach().cpu().numpy(), zr.detach().numpy()) < 2 * FWD_RTOL
+    for k in arrs:
+        assert relerr(got[k].grad.cpu().numpy(), ref[k].grad.numpy()) < GRAD_RTOL, k
