@@ -132,7 +132,10 @@ int main(int argc, char** argv) {
         float *X, *sink;
         CK(hipMalloc(&X, pf * 8 * sizeof(float))); CK(hipMalloc(&sink, 64));
         CK(hipMemset(X, 0, pf * 8 * sizeof(float)));
-        run<0, 8>("plain  8 in flight", X, rows, pf, 4096, sink);
+        const int blocks = argc > 3 ? atoi(argv[3]) : 4096;   // 1024 blocks = 4 per CU = 16 waves per CU (what an LDS-full kernel can hold)
+        run<0, 4>("plain  4 in flight", X, rows, pf, blocks, sink);
+        run<0, 8>("plain  8 in flight", X, rows, pf, blocks, sink);
+        run<0, 16>("plain 16 in flight", X, rows, pf, blocks, sink);
         return 0;
     }
     if (argc > 1) {   // `gather_ceiling narrow`: row-width sweep for the EVGF tap analysis (profiles/r02_c_evgf)

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __re
                                                                   float* __restrict__ Y, int N, int D, int L4, int P, int wgPerXcd,
                                                                   int nTiles, int entriesPerXcd, int B, float uval,
                                                                   unsigned* __restrict__ prog, unsigned base, int lag,
-                                                                  unsigned* __restrict__ stats) {
+                                                                  unsigned* __restrict__ stats, int shift) {
     extern __shared__ __attribute__((aligned(16))) float accs[];   // [(D + 8) * kRow]
     __shared__ unsigned s_prog[kWaves + 1];   // [kWaves] = the XCD's floor as last seen by a polling wave of this workgroup
     auto lds_st = [&](int i, unsigned v) { __hip_atomic_store(&s_prog[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -68,7 +68,11 @@ __global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __re
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     unsigned short* slots = reinterpret_cast<unsigned short*>(prog) + xcd * kSlots;   // 16-bit progress (steps since `base`) per workgroup
     const unsigned* pollp = prog + xcd * (kSlots / 2) + (lane & (wgPerXcd > 64 ? 63 : 31));   // one dword = two slots per lane: 1-2 lines
-    unsigned gi = 0;                         // index (since launch) of the step whose gathers are issued next
+    unsigned* xfloor = prog + 8 * (kSlots / 2) + xcd * 32;   // the XCD's floor, kept by the sync waves: one word, own line
+    // two COHORTS: odd workgroups count their steps from `shift` (half a sweep), i.e. they are let go once the even ones are half a sweep
+    // in, and from then on one cohort stores its tiles while the other gathers (all workgroups storing at the same moment stalls the
+    // TCP's store-data path for 27 % of the kernel: TCP_TCP_TA_DATA_STALL_CYCLES, profiles/r03_a_sweep/v6_tcc_counters.log)
+    unsigned gi = (j & 1) ? (unsigned)shift : 0u;   // index (since launch, in the shifted coordinate) of the step whose gathers are issued next
     unsigned pv = 0;
     unsigned waited = 0, gaveup = 0;
 
@@ -87,8 +91,11 @@ __global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __re
         v = min(v, (unsigned)__shfl_xor((int)v, 4));
         return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     };
-    auto issue_poll = [&]() { pv = ld_sc1(pollp); };
-    auto floor_of = [&]() { return wave_min(min(pv & 0xffffu, pv >> 16)); };
+    // A worker polls ONE word (every lane the same address: one request, no reduction): the minimum over the XCD's counters is taken
+    // by the sync waves.  (Every worker reducing 64-128 counters itself costs 6 dependent ds_bpermute per step: with 14 worker
+    // waves per CU the per-step latency chain, not memory, bounded the prototype -- 62 L2 requests in flight per CU, counters.)
+    auto issue_poll = [&]() { pv = ld_sc1(xfloor); };
+    auto floor_of = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)pv); };
     auto wait_floor = [&]() {   // gate the gathers of step gi: at most `lag` steps ahead of the slowest workgroup of the XCD
         unsigned fl = floor_of();   // the poll issued a step ago (always consumed: keeps the load count uniform)
         issue_poll();
@@ -161,12 +168,19 @@ __global__ __launch_bounds__(kThreads, MINW) void sweep_kernel(const u32x4* __re
                 if (lag >= 0) {
                     unsigned last = 0xffffffffu;
                     const unsigned long long t0 = wall_clock64();
+                    unsigned lastfl = 0xffffffffu;
                     for (int guard = 0; guard < (1 << 22); ++guard) {
                         const unsigned v = wg_min();
                         if (v != last && lane == 0)
                             __hip_atomic_store(slots + j, (unsigned short)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         last = v;
                         ++rounds;
+                        {   // every sync wave refreshes the XCD's floor (a stale lower value overwriting a newer one is conservative, never wrong)
+                            const unsigned q = ld_sc1(pollp);
+                            const unsigned fl = wave_min(min(q & 0xffffu, q >> 16));
+                            if (fl != lastfl && lane == 0) __hip_atomic_store(xfloor, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            lastfl = fl;
+                        }
                         if ((int)(v - target) >= 0) break;
                         __builtin_amdgcn_s_sleep(2);
                     }
@@ -508,7 +522,7 @@ int main(int argc, char** argv) {
         }
     }
     unsigned *prog, *stats;
-    CK(hipMalloc(&prog, 8 * kSlots * 4));
+    CK(hipMalloc(&prog, 8 * kSlots * 4 + 8 * 32 * 4));
     CK(hipMalloc(&stats, 32));
     int cfg = 0;
     for (int wgPerCU : wgs) {
@@ -537,15 +551,16 @@ int main(int argc, char** argv) {
                             auto launch = [&](unsigned epoch) {
                                 std::vector<unsigned short> init(8 * kSlots, 0xffffu);
                                 for (int x = 0; x < 8; ++x)
-                                    for (int jj = 0; jj < S.wgPerXcd; ++jj) init[x * kSlots + jj] = 0;
+                                    for (int jj = 0; jj < S.wgPerXcd; ++jj) init[x * kSlots + jj] = (jj & 1) ? (unsigned short)shift : 0;
                                 CK(hipMemcpyAsync(prog, init.data(), init.size() * 2, hipMemcpyHostToDevice, 0));
+                                CK(hipMemsetAsync(reinterpret_cast<char*>(prog) + 8 * (kSlots / 2) * 4, 0, 8 * 32 * 4, 0));
                                 { const unsigned init8[8] = {0, 0, 0, 0, 0xffffffffu, 0xffffffffu, 0, 0}; CK(hipMemcpyAsync(stats, init8, 32, hipMemcpyHostToDevice, 0)); }
                                 CK(hipStreamSynchronize(0));
                                 return epoch * span;
                             };
                             auto run = [&](unsigned base) {
 #define LAUNCH(AC, MW, DP) hipLaunchKernelGGL((sweep_kernel<AC, MW, DP>), dim3(8 * S.wgPerXcd), dim3(kThreads), lds, 0, (const u32x4*)dst, X, Y, N, S.D, \
-                                          S.L4, S.P, S.wgPerXcd, S.nTiles, entriesPerXcd, B, uval, prog, base, lag, stats)
+                                          S.L4, S.P, S.wgPerXcd, S.nTiles, entriesPerXcd, B, uval, prog, base, lag, stats, shift)
                                 if (wgPerCU >= 3) {
                                     if (ac == 1) LAUNCH(1, 6, 2); else LAUNCH(0, 6, 2);
                                 } else {
