@@ -20,11 +20,14 @@
 //     operand (padding makes (Cin+4)/4 odd -> the 16-lane read groups hit 16 distinct 16-byte slots).
 //     The reduction index c is permuted within each group of 8 so one float4 feeds four consecutive MFMAs:
 //     lane half h, step s  <->  c = 8u + 4h + s.  The next tap's global loads are in flight during the MFMAs.
+#include <mutex>
+
 #include "gf_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
@@ -46,91 +49,167 @@ struct BankView {  // how to read Hm[c = t*Cin + ci][o] out of h[F,E,K,G]
     }
 };
 
-template <int NT, int CIN8>
+// The tap tiles a wave consumes form one STREAM (tile 0 tap 0, tap 1, ..., tile 1 tap 0, ...): D of them are in flight in a register
+// ring at any time, across tile boundaries (slot d holds stream elements d, d + D, ...; a slot is refilled as soon as its tile has been
+// dropped into LDS).  One tap in flight per wave left 48-64 KB per CU on the way and a full round trip exposed at every tile start
+// (contraction at 4.1-5.2 TB/s with the MFMA pipe 47 % busy, profiles/r03_d_final); with D = 4 it is 4x that.
+// The output stores are issued through inline asm: the compiler's wait-count pass then counts loads only (exact vmcnt(k) for the k
+// younger loads instead of vmcnt(0) for "loads and stores pending together"); the hardware counter still includes the stores, which
+// makes the wait conservative, never too short: loads return in order, so "at most k operations pending" implies the load waited for is done.
+// (base = wave-uniform pointer in an SGPR pair, off = the lane's byte offset: no 64-bit address arithmetic per store)
+__device__ __forceinline__ void store_f32_hidden(float* base, unsigned off, float v) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void store_f32x4_hidden(float* base, unsigned off, const float4& v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off), "v"(d), "s"(base) : "memory");
+}
+
+// (batch entry, 32-node tile) cursor of a wave's statically strided tiles, advanced without a division and held in SGPRs (a 64-bit
+// division is a ~130 instruction VALU loop whose result the compiler no longer treats as wave-uniform: every address that depends
+// on it would leave the scalar unit)
+struct TileCursor {
+    int b, tn, sb, sr, tilesPerB;
+    __device__ __forceinline__ void init(int first, int stride, int tpb) {
+        tilesPerB = tpb;
+        b = __builtin_amdgcn_readfirstlane(first / tpb);
+        tn = first - b * tpb;
+        sb = __builtin_amdgcn_readfirstlane(stride / tpb);
+        sr = stride - sb * tpb;
+    }
+    __device__ __forceinline__ void next() {
+        b += sb;
+        tn += sr;
+        if (tn >= tilesPerB) tn -= tilesPerB, ++b;
+    }
+};
+
+template <int NT, int CIN8, int D>
 __global__ __launch_bounds__(kThreads) void contract_mfma_kernel(const float* __restrict__ Z, BankView bank,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
                                                                  int B, int N, int Nout, int Cout, int T, int tilesPerB,
-                                                                 int64_t totalTiles) {
+                                                                 int totalTiles) {
     constexpr int Cin = CIN8 * 8;
     constexpr int Cop = NT * 32;
     constexpr int ZS = Cin + 4;  // padded LDS row stride (floats)
     constexpr int LPR = Cin / 4;  // lanes (float4) per row
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_w = smem;                  // [T*Cin][Cop]
-    float* s_z = smem + T * Cin * Cop;  // [kWaves][32][ZS]
+    constexpr int WS = Cin + 4;         // row stride of the bank: [t][o][Cin + 4] -- a lane reads the four c of four consecutive MFMAs
+    float* s_w = smem;                  //   with ONE 16-byte read ((Cin + 4) / 4 is odd: conflict-free), not four ds_read_b32
+    float* s_b = smem + T * Cop * WS;   // [Cop]: the bias (zeros without one) -- the accumulators start from LDS, not from global loads
+    float* s_z = s_b + Cop;             // [kWaves][32][ZS]                       that would sit in the ring's vmcnt queue at every tile start
 
     const int tid = threadIdx.x;
     for (int idx = tid; idx < T * Cin * Cop; idx += kThreads) {
-        const int o = idx % Cop, c = idx / Cop;
-        s_w[idx] = (o < Cout) ? bank.at(c / Cin, c % Cin, o) : 0.f;
+        const int ci = idx % Cin, o = (idx / Cin) % Cop, t = idx / (Cin * Cop);
+        s_w[(t * Cop + o) * WS + ci] = (o < Cout) ? bank.at(t, ci, o) : 0.f;
     }
+    for (int o = tid; o < Cop; o += kThreads) s_b[o] = (bias != nullptr && o < Cout) ? bias[o] : 0.f;
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    // the wave index as a SCALAR: every tile / tap cursor below then lives in SGPRs and a load is (uniform base) + (a lane offset)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     float* zt = s_z + wave * 32 * ZS;
     const int64_t tapStride = (int64_t)B * N * Cin;
+    const int first = blockIdx.x * kWaves + wave, stride = gridDim.x * kWaves;
+    if (first >= totalTiles) return;   // (after the only workgroup barrier)
+    const int total = __builtin_amdgcn_readfirstlane((totalTiles - 1 - first) / stride + 1) * T;   // stream length of this wave
+    const unsigned ooff = ((unsigned)l31 + 4u * (unsigned)half * (unsigned)Nout) * 4u;   // output: byte offset of (o = 4 half, n = l31)
 
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < totalTiles; tile += (int64_t)gridDim.x * kWaves) {
-        const int b = (int)(tile / tilesPerB);
-        const int n0 = (int)(tile - (int64_t)b * tilesPerB) * 32;
-        const float* zb = Z + ((int64_t)b * N + n0) * Cin;
-
-        f32x16 acc[NT];
+    // ---- producer cursor: the next (tile, tap) to request.  Every load is unconditional (straight-line code: the compiler counts
+    // vmcnt exactly): rows past the last node are clamped to node N - 1 -- a row only ever reaches its own output column, which is
+    // not stored -- and past the end of the stream the last element is requested again.
+    int pv = 0, pt = 0;
+    TileCursor pc, cc;
+    pc.init(first, stride, tilesPerB);
+    cc = pc;
+    const float* pz = Z;
+    unsigned loff[CIN8];
+    auto p_set = [&]() {
+        const int n0 = pc.tn * 32;
+        pz = Z + (int64_t)pc.b * N * Cin;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                acc[nt][r] = (bias != nullptr && o < Cout) ? bias[o] : 0.f;
-            }
-
-        float4 stage[CIN8];
-        auto issue_loads = [&](int t) {
-#pragma unroll
-            for (int i = 0; i < CIN8; ++i) {
-                const int idx = lane + 64 * i;
-                const int row = idx / LPR, c4 = idx % LPR;
-                stage[i] = (n0 + row < Nout) ? *reinterpret_cast<const float4*>(zb + t * tapStride + (int64_t)row * Cin + c4 * 4)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        };
-        issue_loads(0);
-        for (int t = 0; t < T; ++t) {
-#pragma unroll
-            for (int i = 0; i < CIN8; ++i) {
-                const int idx = lane + 64 * i;
-                const int row = idx / LPR, c4 = idx % LPR;
-                *reinterpret_cast<float4*>(zt + row * ZS + c4 * 4) = stage[i];
-            }
-            if (t + 1 < T) issue_loads(t + 1);  // in flight while this tap is multiplied
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const float* wt = s_w + (int64_t)t * Cin * Cop;
-#pragma unroll
-            for (int u = 0; u < CIN8; ++u) {
-                const float4 bv = *reinterpret_cast<const float4*>(zt + l31 * ZS + u * 8 + half * 4);
-                const float bs[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float* wr = wt + (u * 8 + half * 4 + s) * Cop + l31;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[nt * 32], bs[s], acc[nt], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();  // all lanes' reads of zt issued before the next tap overwrites it
+        for (int i = 0; i < CIN8; ++i) {
+            const int idx = lane + 64 * i;
+            const int row = idx / LPR, c4 = idx % LPR;
+            loff[i] = (unsigned)(min(n0 + row, N - 1) * Cin + c4 * 4);
         }
+    };
+    auto issue = [&](f32x4 (&dst)[CIN8]) {
+        const float* src = pz + pt * tapStride;
+#pragma unroll
+        for (int i = 0; i < CIN8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(src + loff[i]);
+        if (pv + 1 < total) {
+            ++pv;
+            if (++pt == T) {
+                pt = 0;
+                pc.next();
+                p_set();
+            }
+        }
+    };
+    f32x4 ring[D][CIN8];   // (a native vector type: an array of HIP float4 structs copied memory-to-memory is not promoted to registers)
+    p_set();
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(ring[d]);
 
-        if (n0 + l31 < Nout) {
-            float* ob = out + (int64_t)b * Cout * Nout + n0 + l31;
+    // ---- consumer (the stream is processed in groups of D; the elements of the last group past the end are multiplied and dropped).
+    // The D steps of a group are written out by hand: a loop over d around a wave barrier is not unrolled, and a ring indexed by a
+    // run-time d lives in scratch memory.
+    int ct = 0;
+    f32x16 acc[NT];
+    auto step = [&](f32x4 (&slot)[CIN8], int ve) {
+        if (ct == 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (o < Cout) ob[(int64_t)o * Nout] = bank.act(acc[nt][r]);
-                }
+                for (int r = 0; r < 16; ++r) acc[nt][r] = s_b[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
         }
+#pragma unroll
+        for (int i = 0; i < CIN8; ++i) {
+            const int idx = lane + 64 * i;
+            const int row = idx / LPR, c4 = idx % LPR;
+            *reinterpret_cast<f32x4*>(zt + row * ZS + c4 * 4) = slot[i];
+        }
+        issue(slot);  // stream element ve + D: in flight during the next D taps
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float* wt = s_w + (ct * Cop + l31) * WS + half * 4;
+#pragma unroll
+        for (int u = 0; u < CIN8; ++u) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(zt + l31 * ZS + u * 8 + half * 4);
+            f32x4 wv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 32 * WS + u * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[nt][s], bv[s], acc[nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();  // all lanes' reads of zt issued before the next tap overwrites it
+        if (++ct == T) {
+            const int b = cc.b, n0 = cc.tn * 32;
+            if (ve < total && n0 + l31 < Nout) {
+                float* ob = out + (int64_t)b * Cout * Nout + n0;   // uniform; the lane adds (l31 + 4 half Nout) floats
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ou = nt * 32 + (r & 3) + 8 * (r >> 2);   // + 4 * half
+                        if (ou + 4 * half < Cout) store_f32_hidden(ob + (int64_t)ou * Nout, ooff, bank.act(acc[nt][r]));
+                    }
+            }
+            ct = 0;
+            cc.next();
+        }
+    };
+    for (int v = 0; v < total; v += D) {
+        step(ring[0], v);
+        if constexpr (D > 1) step(ring[1], v + 1);
+        if constexpr (D > 2) step(ring[2], v + 2);
+        if constexpr (D > 3) step(ring[3], v + 3);
     }
 }
 
@@ -153,20 +232,48 @@ __global__ __launch_bounds__(kThreads) void contract_generic_kernel(const float*
     }
 }
 
+// persistent grids are sized by what is RESIDENT (registers and LDS together; asked of the runtime once per kernel and LDS size): a
+// workgroup beyond that starts when another one has finished its whole share -- with the statically strided tiles that was a second
+// round at a third of the machine (contract_panel_kernel<1, 4>: 131 registers = 3 workgroups per CU under a grid of 4 per CU)
+template <typename Kern>
+int resident_workgroups(Kern kern, size_t lds) {
+    struct Entry { const void* k; size_t lds; int n; };
+    static Entry cache[64];
+    static int used = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (cache[i].k == (const void*)kern && cache[i].lds == lds) return cache[i].n;
+    // the runtime is asked for the REGISTER limit only (dynamic LDS 0): its LDS model stops at 64 KB per CU, the CU has 160 KB
+    // (asked with the real LDS size it answered 1 workgroup per CU for the 38 KB of contract_mfma_kernel<1, 4>: 2x slower)
+    int perCU = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, kThreads, 0) != hipSuccess || perCU < 1) perCU = 1;
+    const int byLds = (int)((160 * 1024) / (lds < 1024 ? 1024 : lds));
+    if (perCU > byLds) perCU = byLds < 1 ? 1 : byLds;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    const int n = perCU * cus;
+    if (used < 64) cache[used++] = Entry{(const void*)kern, lds, n};
+    return n;
+}
+
 template <int NT, int CIN8>
 int launch_mfma(const float* Z, const BankView& bank, const float* bias, float* out, int B, int N, int Nout, int Cout, int T,
                 hipStream_t st) {
     constexpr int Cin = CIN8 * 8;
-    const size_t lds = ((size_t)T * Cin * NT * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
+    constexpr int D = CIN8 <= 4 ? 4 : (CIN8 == 8 ? 2 : 1);   // taps in flight per wave: 16 .. 64 registers of ring
+    const size_t lds = ((size_t)T * (Cin + 4) * NT * 32 + NT * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
     const int tilesPerB = (Nout + 31) / 32;
     const int64_t totalTiles = (int64_t)B * tilesPerB;
-    const int wgPerCU = lds <= 40 * 1024 ? 4 : (lds <= 80 * 1024 ? 2 : 1);
-    int64_t nblk = (totalTiles + kWaves - 1) / kWaves;
-    if (nblk > 256 * wgPerCU) nblk = 256 * wgPerCU;  // persistent: the bank is staged once per workgroup
-    auto kern = contract_mfma_kernel<NT, CIN8>;
+    GF_REQUIRE_SHAPE(totalTiles < INT32_MAX / 8, "gf_contract: B * N = %lld rows exceed the 32-bit tile index", (long long)B * Nout);
+    auto kern = contract_mfma_kernel<NT, CIN8, D>;
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
+    int64_t nblk = (totalTiles + kWaves - 1) / kWaves;
+    const int resident = resident_workgroups(kern, lds);  // persistent: the bank is staged once per workgroup
+    if (nblk > resident) nblk = resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, st, Z, bank, bias, out, B, N, Nout, Cout, T,
-                       tilesPerB, totalTiles);
+                       tilesPerB, (int)totalTiles);
     GF_LAUNCH_CHECK("contract_mfma_kernel");
     return GF_OK;
 }
@@ -187,103 +294,134 @@ int dispatch_cin(int cin8, const float* Z, const BankView& bank, const float* bi
 // ---- column-panel variant: the tap stack is Zp[T][B][Cin/4][N][4] (gf_panel.hip).  Same MFMA schedule as above -- lane half h,
 // step s of group u takes c = 8u + 4h + s -- but the B operand needs no LDS staging: the four values a lane feeds to four
 // consecutive MFMAs are exactly the 16 bytes Zp[t][b][2u + h][n0 + l31][0..3], one coalesced load (512 B per half wave).
-template <int NT, int CIN8>
+template <int NT, int CIN8, int D>
 __global__ __launch_bounds__(kThreads) void contract_panel_kernel(const float* __restrict__ Zp, BankView bank,
                                                                   const float* __restrict__ bias, float* __restrict__ out, int B,
                                                                   int N, int Nout, int Cout, int T, int tilesPerB,
-                                                                  int64_t totalTiles, int out_panels, const float* __restrict__ maskp) {
+                                                                  int totalTiles, int out_panels, const float* __restrict__ maskp) {
     // out_panels = 1 (layer-to-layer hand-over): the result is written as column panels out[b * Cout/4 + o/4][n][o % 4] -- the layout
     // the NEXT layer's K-hop kernels read (its tap 0), or, for the transposed bank, the previous layer's adjoint tap 0 -- instead of the
     // reference layout [B, Cout, Nout].  A lane's accumulators are 4 consecutive outputs of one node per register quad: exactly one
     // 16-byte panel entry, consecutive lanes = consecutive nodes.  maskp (panels of the same shape, nullable): entries whose mask
     // value is <= 0 are written as 0 (the ReLU mask of the layer the gradient is handed to: its activation IS that panel tensor).
+    // The (tile, tap) stream and its register ring of D taps: see contract_mfma_kernel.  A slot is refilled once the MFMAs that read
+    // it have been issued (they read their operands at issue), so D - 1 taps are in flight while one is multiplied.
     constexpr int Cin = CIN8 * 8;
     constexpr int Cop = NT * 32;
     constexpr int Q = Cin / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_w = smem;  // [T*Cin][Cop]
+    constexpr int WS = Cin + 4;         // bank [t][o][Cin + 4], read 16 bytes at a time (see contract_mfma_kernel)
+    float* s_w = smem;
+    float* s_b = smem + T * Cop * WS;   // [Cop] bias (zeros without one)
     const int tid = threadIdx.x;
     for (int idx = tid; idx < T * Cin * Cop; idx += kThreads) {
-        const int o = idx % Cop, c = idx / Cop;
-        s_w[idx] = (o < Cout) ? bank.at(c / Cin, c % Cin, o) : 0.f;
+        const int ci = idx % Cin, o = (idx / Cin) % Cop, t = idx / (Cin * Cop);
+        s_w[(t * Cop + o) * WS + ci] = (o < Cout) ? bank.at(t, ci, o) : 0.f;
     }
+    for (int o = tid; o < Cop; o += kThreads) s_b[o] = (bias != nullptr && o < Cout) ? bias[o] : 0.f;
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar cursors, as in contract_mfma_kernel
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int64_t panelStride = (int64_t)N * 4;
     const int64_t tapStride = (int64_t)B * Q * panelStride;
+    const int first = blockIdx.x * kWaves + wave, stride = gridDim.x * kWaves;
+    if (first >= totalTiles) return;   // (after the only workgroup barrier)
+    const int total = __builtin_amdgcn_readfirstlane((totalTiles - 1 - first) / stride + 1) * T;   // stream length of this wave
+    const unsigned ooff = ((unsigned)l31 + 4u * (unsigned)half * (unsigned)Nout) * 4u;   // bytes, reference layout: (o = 4 half, n = l31)
+    const unsigned poff = ((unsigned)half * (unsigned)N + (unsigned)l31) * 16u;          // bytes, panel output: (panel half, node l31)
 
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < totalTiles; tile += (int64_t)gridDim.x * kWaves) {
-        const int b = (int)(tile / tilesPerB);
-        const int n0 = (int)(tile - (int64_t)b * tilesPerB) * 32;
-        const bool nvalid = n0 + l31 < Nout;
-        const float* zb = Zp + (int64_t)b * Q * panelStride + (int64_t)(n0 + l31) * 4 + (int64_t)half * panelStride;
-
-        f32x16 acc[NT];
+    // ---- producer cursor (unconditional loads: nodes past the end clamp to node N - 1, the stream's end repeats its last element)
+    int pv = 0, pt = 0;
+    TileCursor pc, cc;
+    pc.init(first, stride, tilesPerB);
+    cc = pc;
+    const float* pz = Zp;
+    unsigned loff = 0;
+    auto p_set = [&]() {
+        pz = Zp + (int64_t)pc.b * Q * panelStride;
+        loff = (unsigned)min(pc.tn * 32 + l31, N - 1) * 4u + (unsigned)half * (unsigned)panelStride;   // floats: (panel half, node)
+    };
+    auto issue = [&](float4 (&dst)[CIN8]) {
+        const float* src = pz + pt * tapStride;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                acc[nt][r] = (bias != nullptr && o < Cout) ? bias[o] : 0.f;
-            }
-
-        float4 stage[CIN8], cur[CIN8];
-        auto issue_loads = [&](int t) {
-#pragma unroll
-            for (int u = 0; u < CIN8; ++u)
-                stage[u] = nvalid ? *reinterpret_cast<const float4*>(zb + t * tapStride + (int64_t)(2 * u) * panelStride)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-        };
-        issue_loads(0);
-        for (int t = 0; t < T; ++t) {
-#pragma unroll
-            for (int u = 0; u < CIN8; ++u) cur[u] = stage[u];
-            if (t + 1 < T) issue_loads(t + 1);  // in flight while this tap is multiplied
-            const float* wt = s_w + (int64_t)t * Cin * Cop;
-#pragma unroll
-            for (int u = 0; u < CIN8; ++u) {
-                const float bs[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float* wr = wt + (u * 8 + half * 4 + s) * Cop + l31;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[nt * 32], bs[s], acc[nt], 0, 0, 0);
-                }
+        for (int u = 0; u < CIN8; ++u) dst[u] = *reinterpret_cast<const float4*>(src + (int64_t)(2 * u) * panelStride + loff);
+        if (pv + 1 < total) {
+            ++pv;
+            if (++pt == T) {
+                pt = 0;
+                pc.next();
+                p_set();
             }
         }
+    };
+    float4 ring[D][CIN8];
+    p_set();
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(ring[d]);
 
-        if (nvalid && out_panels) {
-            const int QO = Cout >> 2;
+    // ---- consumer
+    int ct = 0;
+    f32x16 acc[NT];
+    for (int v = 0; v < total; v += D) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+        for (int d = 0; d < D; ++d) {
+            if (ct == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = nt * 8 + 2 * j + half;   // outputs 4q .. 4q + 3
-                    if (q < QO) {
-                        const int64_t at = (((int64_t)b * QO + q) * N + (n0 + l31)) * 4;
-                        float4 v = make_float4(bank.act(acc[nt][4 * j]), bank.act(acc[nt][4 * j + 1]), bank.act(acc[nt][4 * j + 2]),
-                                               bank.act(acc[nt][4 * j + 3]));
-                        if (maskp) {
-                            const float4 m = *reinterpret_cast<const float4*>(maskp + at);
-                            v.x = m.x > 0.f ? v.x : 0.f;
-                            v.y = m.y > 0.f ? v.y : 0.f;
-                            v.z = m.z > 0.f ? v.z : 0.f;
-                            v.w = m.w > 0.f ? v.w : 0.f;
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nt][r] = s_b[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+            }
+            const float* wt = s_w + (ct * Cop + l31) * WS + half * 4;
+#pragma unroll
+            for (int u = 0; u < CIN8; ++u) {
+                const float bs[4] = {ring[d][u].x, ring[d][u].y, ring[d][u].z, ring[d][u].w};
+                f32x4 wv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 32 * WS + u * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[nt][s], bs[s], acc[nt], 0, 0, 0);
+            }
+            issue(ring[d]);  // stream element v + d + D
+            if (++ct == T) {
+                const int b = cc.b, n0 = cc.tn * 32;
+                const bool nvalid = v + d < total && n0 + l31 < Nout;
+                if (nvalid && out_panels) {
+                    const int QO = Cout >> 2;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int q = nt * 8 + 2 * j + half;   // outputs 4q .. 4q + 3
+                            if (q < QO) {
+                                const int64_t at = (((int64_t)b * QO + (nt * 8 + 2 * j)) * N + n0) * 4;   // uniform; + poff bytes per lane
+                                float4 o4 = make_float4(bank.act(acc[nt][4 * j]), bank.act(acc[nt][4 * j + 1]), bank.act(acc[nt][4 * j + 2]),
+                                                        bank.act(acc[nt][4 * j + 3]));
+                                if (maskp) {
+                                    const float4 m = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(maskp + at) + poff);
+                                    o4.x = m.x > 0.f ? o4.x : 0.f;
+                                    o4.y = m.y > 0.f ? o4.y : 0.f;
+                                    o4.z = m.z > 0.f ? o4.z : 0.f;
+                                    o4.w = m.w > 0.f ? o4.w : 0.f;
+                                }
+                                store_f32x4_hidden(out + at, poff, o4);
+                            }
                         }
-                        *reinterpret_cast<float4*>(out + at) = v;
-                    }
-                }
-        } else if (nvalid) {
-            float* ob = out + (int64_t)b * Cout * Nout + n0 + l31;
+                } else if (nvalid) {
+                    float* ob = out + (int64_t)b * Cout * Nout + n0;   // uniform; the lane adds ooff
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (o < Cout) ob[(int64_t)o * Nout] = bank.act(acc[nt][r]);
+                        for (int r = 0; r < 16; ++r) {
+                            const int ou = nt * 32 + (r & 3) + 8 * (r >> 2);   // + 4 * half
+                            if (ou + 4 * half < Cout) store_f32_hidden(ob + (int64_t)ou * Nout, ooff, bank.act(acc[nt][r]));
+                        }
                 }
+                ct = 0;
+                cc.next();
+            }
         }
     }
 }
@@ -292,16 +430,18 @@ template <int NT, int CIN8>
 int launch_panel(const float* Zp, const BankView& bank, const float* bias, float* out, int B, int N, int Nout, int Cout, int T,
                  hipStream_t st, int out_panels, const float* maskp) {
     constexpr int Cin = CIN8 * 8;
-    const size_t lds = (size_t)T * Cin * NT * 32 * sizeof(float);
+    constexpr int D = CIN8 <= 4 ? 4 : (CIN8 == 8 ? 2 : 1);
+    const size_t lds = ((size_t)T * (Cin + 4) * NT * 32 + NT * 32) * sizeof(float);
     const int tilesPerB = (Nout + 31) / 32;
     const int64_t totalTiles = (int64_t)B * tilesPerB;
-    const int wgPerCU = lds <= 40 * 1024 ? 4 : (lds <= 80 * 1024 ? 2 : 1);
-    int64_t nblk = (totalTiles + kWaves - 1) / kWaves;
-    if (nblk > 256 * wgPerCU) nblk = 256 * wgPerCU;
-    auto kern = contract_panel_kernel<NT, CIN8>;
+    GF_REQUIRE_SHAPE(totalTiles < INT32_MAX / 8, "gf_contract_panel: B * N = %lld rows exceed the 32-bit tile index", (long long)B * Nout);
+    auto kern = contract_panel_kernel<NT, CIN8, D>;
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
+    int64_t nblk = (totalTiles + kWaves - 1) / kWaves;
+    const int resident = resident_workgroups(kern, lds);
+    if (nblk > resident) nblk = resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, st, Zp, bank, bias, out, B, N, Nout, Cout, T, tilesPerB,
-                       totalTiles, out_panels, maskp);
+                       (int)totalTiles, out_panels, maskp);
     GF_LAUNCH_CHECK("contract_panel_kernel");
     return GF_OK;
 }
@@ -322,7 +462,7 @@ int dispatch_cin_panel(int cin8, const float* Zp, const BankView& bank, const fl
 
 bool gf_contract_panel_fits(int Cin, int Cout, int T) {
     const int nt = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4);
-    return Cout <= 128 && (size_t)T * Cin * nt * 32 * sizeof(float) <= 160 * 1024;
+    return Cout <= 128 && ((size_t)T * (Cin + 4) * nt * 32 + nt * 32) * sizeof(float) <= 160 * 1024;
 }
 
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G, int F,
@@ -333,7 +473,7 @@ int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias,
     const int cin8 = Cin / 8;
     const bool cin_ok = (Cin % 8 == 0) && (cin8 == 1 || cin8 == 2 || cin8 == 4 || cin8 == 8 || cin8 == 16);
     const int nt = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4);
-    const size_t lds = (size_t)T * Cin * nt * 32 * sizeof(float);
+    const size_t lds = ((size_t)T * (Cin + 4) * nt * 32 + nt * 32) * sizeof(float);
     GF_REQUIRE_SHAPE(cin_ok && Cout <= 128 && lds <= 160 * 1024,
                      "gf_contract_panel: unsupported widths Cin=%d Cout=%d T=%d (Cin in {8,16,32,64,128}, Cout <= 128)", Cin, Cout, T);
     GF_REQUIRE_SHAPE(!out_panels || (Nout == N && Cout % 8 == 0), "gf_contract_panel: panel output needs Nout == N and Cout %% 8 == 0 (Nout=%d N=%d Cout=%d)",
@@ -369,7 +509,7 @@ int gf_contract_launch(const float* Z, const float* h, const float* bias, float*
     const int cin8 = Cin / 8;
     const bool cin_ok = (Cin % 8 == 0) && (cin8 == 1 || cin8 == 2 || cin8 == 4 || cin8 == 8 || cin8 == 16);
     const int nt = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4);
-    const size_t lds = ((size_t)T * Cin * nt * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
+    const size_t lds = ((size_t)T * (Cin + 4) * nt * 32 + nt * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
     if (!env_generic && cin_ok && Cout <= 128 && lds <= 160 * 1024) {
         switch (nt) {
             case 1: return dispatch_cin<1>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st);

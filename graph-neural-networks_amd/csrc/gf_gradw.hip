@@ -14,6 +14,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kMaxWaves = 2048;  // stage-1 partial producers
@@ -376,21 +377,28 @@ void launch_stage1_panel(const Geo& g, const float* Zp, const float* P0p, float*
 // still holds 4 consecutive f (g) of its row -- its four 16-byte loads per tap then come from one 128-byte row instead of four
 // panels, 32 bytes contiguous per pair of lanes; everything after the loads is identical.
 template <int T, int GIN8, int FIN8, int NM>
-__global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* __restrict__ Pp, const float* __restrict__ X0p,
-                                                                   const float* __restrict__ h, float* __restrict__ dx,
-                                                                   float* __restrict__ partial, float* __restrict__ partial_b, int R,
-                                                                   int N, int Nout, int B, int E, int K, int rowsPerWave, int dx_panels,
-                                                                   const float* __restrict__ maskp) {
+__global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const float* __restrict__ Pp, const float* __restrict__ X0p,
+                                                                      const float* __restrict__ h, float* __restrict__ dx,
+                                                                      float* __restrict__ partial, float* __restrict__ partial_b, int R,
+                                                                      int N, int Nout, int B, int E, int K, int rowsPerWave, int dx_panels,
+                                                                      const float* __restrict__ maskp) {
     // dx_panels = 1 (layer-to-layer hand-over, panel stacks only): dx goes out as column panels dx[b * G/4 + g/4][n][g % 4], masked by
     // maskp (nullable; the activation panels of the layer the gradient is handed to: entries <= 0 give 0) -- see contract_panel_kernel
+    //
+    // LDS operands are laid out for 16-BYTE READS: every MFMA of this kernel takes an A (or B) operand out of LDS, and with one
+    // ds_read_b32 per MFMA issued one or two MFMAs ahead the 64-cycle MFMAs of a wave waited for the LDS round trip every second
+    // instruction (58-65 % MFMA busy at two waves per SIMD, profiles/r03_d_final).  The bank is stored [t][g][f] (a lane reads the four
+    // f of four consecutive contraction MFMAs at once), the X0 and P tiles are stored TRANSPOSED [column][row order], rows in the order
+    // the reduction MFMAs consume them (row 2s + half at position 16 half + s): four reads give a lane all 16 operands of a tap.
     constexpr int G = GIN8 * 8, F = FIN8 * 8, QG = G / 4, QF = F / 4;
-    constexpr int TS = 36;  // padded row stride of the wave-private tiles (floats): 16-byte aligned rows, conflict-free column reads
+    constexpr int TS = 36;      // row stride of the transposed tiles (floats): 16-byte aligned, 36/4 odd -> conflict-free 16-byte reads
+    constexpr int FS = F + 4;   // row stride of the bank (same rule: (F + 4) / 4 is odd for F = 8, 16, 32)
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    float* s_w = s_dyn;                                   // Hm[t*F + f][g], g padded to 32: T*F*32 floats
-    float (*s_t)[2][32 * TS] = reinterpret_cast<float (*)[2][32 * TS]>(s_dyn + T * F * 32);   // per wave: X0 tile, P tile
+    float* s_w = s_dyn;                                   // Hm[t][g][f], g padded to 32: T * 32 * FS floats
+    float (*s_t)[2][32 * TS] = reinterpret_cast<float (*)[2][32 * TS]>(s_dyn + T * 32 * FS);   // per wave: X0 tile, P tile (transposed)
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < T * F * 32; idx += kThreads) {
-        const int g = idx & 31, c = idx >> 5, t = c / F, f = c - t * F;
+    for (int idx = tid; idx < T * 32 * F; idx += kThreads) {
+        const int f = idx % F, g = (idx / F) & 31, t = idx / (F * 32);
         float v = 0.f;
         if (g < G) {
             if (t == 0) {
@@ -400,11 +408,12 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
                 v = h[((int64_t)(f * E + e) * K + k) * G + g];
             }
         }
-        s_w[idx] = v;
+        s_w[(t * 32 + g) * FS + f] = v;
     }
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wg = blockIdx.x * kWaves + wave;
     const int r_begin = wg * rowsPerWave, r_end = min(R, r_begin + rowsPerWave);
     const int64_t N4 = (int64_t)N * 4;
@@ -413,6 +422,16 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
     const int64_t xstep = NM ? 8 : 2 * N4;
     float* xs = s_t[wave][0];
     float* ps = s_t[wave][1];
+    // write side of a tile: this lane holds row l31, columns 8u + 4 half + (0..3); read side: column l31, rows 2s + half, s = 0..15
+    const int wpos = (l31 & 1) * 16 + (l31 >> 1) + 4 * half * TS;   // + (8u + j) * TS
+    const int rpos = l31 * TS + 16 * half;                          // 16 consecutive floats
+    auto put_tile = [&](float* tile, const float4& v, int u) {
+        float* q = tile + wpos + 8 * u * TS;
+        q[0] = v.x;
+        q[TS] = v.y;
+        q[2 * TS] = v.z;
+        q[3 * TS] = v.w;
+    };
 
     f32x16 acc_h[T];
 #pragma unroll
@@ -421,6 +440,125 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
         for (int r = 0; r < 16; ++r) acc_h[t][r] = 0.f;
     float bsum = 0.f;
 
+    // ---- the operand stream of a strip: per tile the X0 tile and the T tap tiles, element e of tile i in ring slot (i (T + 1) + e) % 3.
+    // TWO elements are in flight while one is consumed, across tile boundaries (one tap ahead left 32 KB per CU on the way: at the
+    // loaded HBM latency that is 4.3 TB/s, and every tap ended in a wait).  The slot numbers are compile-time when 3 divides T + 1
+    // (T = 5: the K = 5 filters of the configurations; T = 2); the other tap counts keep the one-ahead schedule below.
+    constexpr bool kDeep = (T + 1) % 3 == 0;
+    constexpr int MAXW = GIN8 > FIN8 ? GIN8 : FIN8;
+    if constexpr (kDeep) {
+        f32x4 slot[3][MAXW];
+        int b = 0, n = 0, nb = 0, nn = 0;
+        bool rv = false, nrv = false;
+        const float *pb = Pp, *xb = X0p, *npb = Pp, *nxb = X0p;
+        // every load is UNCONDITIONAL (rows past the strip's end re-read its last row and are zeroed when the tile is consumed): a load
+        // behind a lane-validity branch made the compiler wait with vmcnt(0) instead of counting the younger loads
+#define GF_TILE_ADDR(R0, RV, BB, NN, PB, XB)                                                                                 \
+        do {                                                                                                                 \
+            RV = (R0) + l31 < r_end;                                                                                         \
+            const int r_ = min((R0) + l31, r_end - 1);                                                                       \
+            BB = r_ / N;                                                                                                     \
+            NN = r_ - BB * N;                                                                                                \
+            PB = NM ? Pp + (int64_t)r_ * F + 4 * half : Pp + ((int64_t)BB * QF + half) * N4 + (int64_t)NN * 4;               \
+            XB = NM ? X0p + (int64_t)r_ * G + 4 * half : X0p + ((int64_t)BB * QG + half) * N4 + (int64_t)NN * 4;             \
+        } while (0)
+#define GF_LOAD_X0(S, XB)                                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < GIN8; ++u) slot[S][u] = *reinterpret_cast<const f32x4*>(XB + (int64_t)u * xstep)
+#define GF_LOAD_P(S, PB, TT)                                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < FIN8; ++u)                                                                     \
+            slot[S][u] = *reinterpret_cast<const f32x4*>(PB + (int64_t)(TT) * tapStride + (int64_t)u * pstep)
+        auto put_tile4 = [&](float* tile, const f32x4& v, int u) {
+            float* q = tile + wpos + 8 * u * TS;
+            q[0] = v[0];
+            q[TS] = v[1];
+            q[2 * TS] = v[2];
+            q[3 * TS] = v[3];
+        };
+        if (r_begin < r_end) {
+            GF_TILE_ADDR(r_begin, rv, b, n, pb, xb);
+            GF_LOAD_X0(0, xb);
+            GF_LOAD_P(1, pb, 0);
+        }
+        for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+            f32x16 acc_x;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_x[i] = 0.f;
+#pragma unroll
+            for (int e = 0; e <= T; ++e) {
+                // request element e + 2 (its slot held element e - 1)
+                if (e + 2 <= T) {
+                    GF_LOAD_P((e + 2) % 3, pb, e + 1);
+                } else if (e + 2 == T + 1) {   // X0 of the next tile (past the strip's end: its last row again, never consumed)
+                    GF_TILE_ADDR(r0 + 32, nrv, nb, nn, npb, nxb);
+                    GF_LOAD_X0(0, nxb);
+                } else {
+                    GF_LOAD_P(1, npb, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // the requests stay HERE: the scheduler otherwise sinks them to their first use, two elements later
+                if (e == 0) {
+#pragma unroll
+                    for (int u = 0; u < GIN8; ++u) put_tile4(xs, rv ? slot[0][u] : f32x4{0.f, 0.f, 0.f, 0.f}, u);
+                    continue;
+                }
+                const int t = e - 1;
+                f32x4 cur[FIN8];
+#pragma unroll
+                for (int u = 0; u < FIN8; ++u) cur[u] = rv ? slot[e % 3][u] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < FIN8; ++u) put_tile4(ps, cur[u], u);
+                const float* wt = s_w + (t * 32 + l31) * FS + 4 * half;
+#pragma unroll
+                for (int u = 0; u < FIN8; ++u) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + 8 * u);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc_x = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[s], cur[u][s], acc_x, 0, 0, 0);
+                }
+                if (t == T - 1) {   // dx of this tile is complete: stored ahead of the last 16 tap-gradient MFMAs, through inline asm
+                                    // (see store_f32_hidden: the compiler then keeps exact vmcnt counts for the ring)
+                    if (rv && dx_panels) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int q = 2 * j + half;   // g = 4q .. 4q + 3
+                            if (q < QG) {
+                                const int64_t at = (((int64_t)b * QG + q) * N + n) * 4;
+                                f32x4 v = {acc_x[4 * j], acc_x[4 * j + 1], acc_x[4 * j + 2], acc_x[4 * j + 3]};
+                                if (maskp) {
+                                    const float4 m = *reinterpret_cast<const float4*>(maskp + at);
+                                    v[0] = m.x > 0.f ? v[0] : 0.f;
+                                    v[1] = m.y > 0.f ? v[1] : 0.f;
+                                    v[2] = m.z > 0.f ? v[2] : 0.f;
+                                    v[3] = m.w > 0.f ? v[3] : 0.f;
+                                }
+                                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dx + at), "v"(v) : "memory");
+                            }
+                        }
+                    } else if (rv && n < Nout) {
+                        float* ob = dx + (int64_t)b * G * Nout + n;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
+                            const float v = acc_x[i];
+                            if (g < G) asm volatile("global_store_dword %0, %1, off" ::"v"(ob + (int64_t)g * Nout), "v"(v) : "memory");
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(xs + rpos + 4 * q);
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + rpos + 4 * q);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if (t == 0) bsum += pv[s];
+                        acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], pv[s], acc_h[t], 0, 0, 0);
+                    }
+                }
+            }
+            rv = nrv, b = nb, n = nn, pb = npb, xb = nxb;
+        }
+#undef GF_TILE_ADDR
+#undef GF_LOAD_X0
+#undef GF_LOAD_P
+    } else
     for (int r0 = r_begin; r0 < r_end; r0 += 32) {
         const int r = r0 + l31;
         const bool rv = r < r_end;
@@ -437,7 +575,7 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
         for (int u = 0; u < FIN8; ++u)
             cur[u] = rv ? *reinterpret_cast<const float4*>(pb + (int64_t)u * pstep) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < GIN8; ++u) *reinterpret_cast<float4*>(xs + l31 * TS + 8 * u + 4 * half) = x0[u];
+        for (int u = 0; u < GIN8; ++u) put_tile(xs, x0[u], u);
 
         f32x16 acc_x;
 #pragma unroll
@@ -450,25 +588,28 @@ __global__ __launch_bounds__(kThreads) void bwd_fused_panel_kernel(const float* 
                     nxt[u] = rv ? *reinterpret_cast<const float4*>(pb + (int64_t)(t + 1) * tapStride + (int64_t)u * pstep)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            // P tile -> LDS [row][f] for the reduction (the previous tap's reads are complete: same wave, program order)
+            // P tile -> LDS (transposed) for the reduction (the previous tap's reads are complete: same wave, program order)
 #pragma unroll
-            for (int u = 0; u < FIN8; ++u) *reinterpret_cast<float4*>(ps + l31 * TS + 8 * u + 4 * half) = cur[u];
-            // data path: acc_x[g][row] += Hm[t*F + f][g] * P_t[row][f]
-            const float* wt = s_w + t * F * 32;
+            for (int u = 0; u < FIN8; ++u) put_tile(ps, cur[u], u);
+            // data path: acc_x[g][row] += Hm[t][g][f] * P_t[row][f]
+            const float* wt = s_w + (t * 32 + l31) * FS + 4 * half;
 #pragma unroll
             for (int u = 0; u < FIN8; ++u) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + 8 * u);
                 const float bs[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc_x = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(u * 8 + half * 4 + s) * 32 + l31], bs[s], acc_x, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) acc_x = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[s], bs[s], acc_x, 0, 0, 0);
             }
             // tap gradient: acc_h[t][g][f] += X0[row][g] * P_t[row][f], two rows per MFMA (k = half)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float a = xs[(2 * s + half) * TS + l31];  // (held in registers across the taps instead: measured slower)
-                const float p = ps[(2 * s + half) * TS + l31];
-                if (t == 0) bsum += p;
-                acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p, acc_h[t], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(xs + rpos + 4 * q);
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + rpos + 4 * q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (t == 0) bsum += pv[s];
+                    acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], pv[s], acc_h[t], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int u = 0; u < FIN8; ++u) cur[u] = nxt[u];
@@ -548,7 +689,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
     GF_REQUIRE_ARG(workspace && workspace_bytes >= g.bytes, "gf_lsigf_backward: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
     GF_REQUIRE_SHAPE(g.passes == 1 && g.ctp == g.T, "gf_lsigf_backward: fused backward geometry");
     float* ws = (float*)workspace;
-    const size_t lds = ((size_t)g.T * F * 32 + (size_t)kWaves * 2 * 32 * 36) * sizeof(float);  // bank + wave tiles (TS = 36)
+    const size_t lds = ((size_t)g.T * 32 * (F + 4) + (size_t)kWaves * 2 * 32 * 36) * sizeof(float);  // bank [t][g][F + 4] + wave tiles (TS = 36)
     hipError_t attr = hipSuccess;
 #define GF_BF(TT, GG, FF)                                                                                                      \
     do {                                                                                                                        \
