@@ -49,10 +49,10 @@ struct BankView {  // how to read Hm[c = t*Cin + ci][o] out of h[F,E,K,G]
     }
 };
 
-// The tap tiles a wave consumes form one STREAM (tile 0 tap 0, tap 1, ..., tile 1 tap 0, ...): D of them are in flight in a register
-// ring at any time, across tile boundaries (slot d holds stream elements d, d + D, ...; a slot is refilled as soon as its tile has been
-// dropped into LDS).  One tap in flight per wave left 48-64 KB per CU on the way and a full round trip exposed at every tile start
-// (contraction at 4.1-5.2 TB/s with the MFMA pipe 47 % busy, profiles/r03_d_final); with D = 4 it is 4x that.
+// contract_panel_kernel: the tap tiles a wave consumes form one STREAM (tile 0 tap 0, tap 1, ..., tile 1 tap 0, ...): D of them are in
+// flight in a register ring at any time, across tile boundaries (slot d holds stream elements d, d + D, ...; a slot is refilled as soon
+// as the MFMAs that read it are issued).  One tap in flight per wave left 48 KB per CU on the way and a full round trip exposed at every
+// tile start (4.1 TB/s at config 2, profiles/r03_d_final); with D = 4 it is 4x that: 482 -> 433 us on the same box.
 // The output stores are issued through inline asm: the compiler's wait-count pass then counts loads only (exact vmcnt(k) for the k
 // younger loads instead of vmcnt(0) for "loads and stores pending together"); the hardware counter still includes the stores, which
 // makes the wait conservative, never too short: loads return in order, so "at most k operations pending" implies the load waited for is done.
@@ -63,7 +63,9 @@ __device__ __forceinline__ void store_f32_hidden(float* base, unsigned off, floa
 __device__ __forceinline__ void store_f32x4_hidden(float* base, unsigned off, const float4& v) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off), "v"(d), "s"(base) : "memory");
+    // (s_nop: a store of more than 8 bytes reads its data registers up to two cycles after issue, and the hazard recogniser does not see
+    //  through inline asm -- without it the next VALU write to one of those registers reaches memory instead of the value stored)
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
 }
 
 // (batch entry, 32-node tile) cursor of a wave's statically strided tiles, advanced without a division and held in SGPRs (a 64-bit
@@ -85,131 +87,95 @@ struct TileCursor {
     }
 };
 
-template <int NT, int CIN8, int D>
+// (Round 3 measured the (tile, tap) register ring of contract_panel_kernel below on this kernel too -- 4 taps in flight, scalar cursors,
+// 16-byte bank reads: 1.85 -> 2.00 ms at config 4 on the same box (tools/ab_same_box.sh; the padded bank costs the fourth workgroup per
+// CU) and 1.87 without the padded bank: the node-major contraction runs at 85 % of the read + write ceiling of tools/hbm_ceiling
+// (5.3 of 6.1 TB/s for its 5 : 1 mix) whatever is in flight, so it keeps its one-tap-ahead schedule.)
+template <int NT, int CIN8>
 __global__ __launch_bounds__(kThreads) void contract_mfma_kernel(const float* __restrict__ Z, BankView bank,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
                                                                  int B, int N, int Nout, int Cout, int T, int tilesPerB,
-                                                                 int totalTiles) {
+                                                                 int64_t totalTiles) {
     constexpr int Cin = CIN8 * 8;
     constexpr int Cop = NT * 32;
     constexpr int ZS = Cin + 4;  // padded LDS row stride (floats)
     constexpr int LPR = Cin / 4;  // lanes (float4) per row
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WS = Cin + 4;         // row stride of the bank: [t][o][Cin + 4] -- a lane reads the four c of four consecutive MFMAs
-    float* s_w = smem;                  //   with ONE 16-byte read ((Cin + 4) / 4 is odd: conflict-free), not four ds_read_b32
-    float* s_b = smem + T * Cop * WS;   // [Cop]: the bias (zeros without one) -- the accumulators start from LDS, not from global loads
-    float* s_z = s_b + Cop;             // [kWaves][32][ZS]                       that would sit in the ring's vmcnt queue at every tile start
+    float* s_w = smem;                  // [T*Cin][Cop]
+    float* s_z = smem + T * Cin * Cop;  // [kWaves][32][ZS]
 
     const int tid = threadIdx.x;
     for (int idx = tid; idx < T * Cin * Cop; idx += kThreads) {
-        const int ci = idx % Cin, o = (idx / Cin) % Cop, t = idx / (Cin * Cop);
-        s_w[(t * Cop + o) * WS + ci] = (o < Cout) ? bank.at(t, ci, o) : 0.f;
+        const int o = idx % Cop, c = idx / Cop;
+        s_w[idx] = (o < Cout) ? bank.at(c / Cin, c % Cin, o) : 0.f;
     }
-    for (int o = tid; o < Cop; o += kThreads) s_b[o] = (bias != nullptr && o < Cout) ? bias[o] : 0.f;
     __syncthreads();
 
-    // the wave index as a SCALAR: every tile / tap cursor below then lives in SGPRs and a load is (uniform base) + (a lane offset)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     float* zt = s_z + wave * 32 * ZS;
     const int64_t tapStride = (int64_t)B * N * Cin;
-    const int first = blockIdx.x * kWaves + wave, stride = gridDim.x * kWaves;
-    if (first >= totalTiles) return;   // (after the only workgroup barrier)
-    const int total = __builtin_amdgcn_readfirstlane((totalTiles - 1 - first) / stride + 1) * T;   // stream length of this wave
-    const unsigned ooff = ((unsigned)l31 + 4u * (unsigned)half * (unsigned)Nout) * 4u;   // output: byte offset of (o = 4 half, n = l31)
 
-    // ---- producer cursor: the next (tile, tap) to request.  Every load is unconditional (straight-line code: the compiler counts
-    // vmcnt exactly): rows past the last node are clamped to node N - 1 -- a row only ever reaches its own output column, which is
-    // not stored -- and past the end of the stream the last element is requested again.
-    int pv = 0, pt = 0;
-    TileCursor pc, cc;
-    pc.init(first, stride, tilesPerB);
-    cc = pc;
-    const float* pz = Z;
-    unsigned loff[CIN8];
-    auto p_set = [&]() {
-        const int n0 = pc.tn * 32;
-        pz = Z + (int64_t)pc.b * N * Cin;
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < totalTiles; tile += (int64_t)gridDim.x * kWaves) {
+        const int b = (int)(tile / tilesPerB);
+        const int n0 = (int)(tile - (int64_t)b * tilesPerB) * 32;
+        const float* zb = Z + ((int64_t)b * N + n0) * Cin;
+
+        f32x16 acc[NT];
 #pragma unroll
-        for (int i = 0; i < CIN8; ++i) {
-            const int idx = lane + 64 * i;
-            const int row = idx / LPR, c4 = idx % LPR;
-            loff[i] = (unsigned)(min(n0 + row, N - 1) * Cin + c4 * 4);
-        }
-    };
-    auto issue = [&](f32x4 (&dst)[CIN8]) {
-        const float* src = pz + pt * tapStride;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int i = 0; i < CIN8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(src + loff[i]);
-        if (pv + 1 < total) {
-            ++pv;
-            if (++pt == T) {
-                pt = 0;
-                pc.next();
-                p_set();
+            for (int r = 0; r < 16; ++r) {
+                const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                acc[nt][r] = (bias != nullptr && o < Cout) ? bias[o] : 0.f;
             }
-        }
-    };
-    f32x4 ring[D][CIN8];   // (a native vector type: an array of HIP float4 structs copied memory-to-memory is not promoted to registers)
-    p_set();
-#pragma unroll
-    for (int d = 0; d < D; ++d) issue(ring[d]);
 
-    // ---- consumer (the stream is processed in groups of D; the elements of the last group past the end are multiplied and dropped).
-    // The D steps of a group are written out by hand: a loop over d around a wave barrier is not unrolled, and a ring indexed by a
-    // run-time d lives in scratch memory.
-    int ct = 0;
-    f32x16 acc[NT];
-    auto step = [&](f32x4 (&slot)[CIN8], int ve) {
-        if (ct == 0) {
+        float4 stage[CIN8];
+        auto issue_loads = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < CIN8; ++i) {
+                const int idx = lane + 64 * i;
+                const int row = idx / LPR, c4 = idx % LPR;
+                stage[i] = (n0 + row < Nout) ? *reinterpret_cast<const float4*>(zb + t * tapStride + (int64_t)row * Cin + c4 * 4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        issue_loads(0);
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = 0; i < CIN8; ++i) {
+                const int idx = lane + 64 * i;
+                const int row = idx / LPR, c4 = idx % LPR;
+                *reinterpret_cast<float4*>(zt + row * ZS + c4 * 4) = stage[i];
+            }
+            if (t + 1 < T) issue_loads(t + 1);  // in flight while this tap is multiplied
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float* wt = s_w + (int64_t)t * Cin * Cop;
+#pragma unroll
+            for (int u = 0; u < CIN8; ++u) {
+                const float4 bv = *reinterpret_cast<const float4*>(zt + l31 * ZS + u * 8 + half * 4);
+                const float bs[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float* wr = wt + (u * 8 + half * 4 + s) * Cop + l31;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[nt * 32], bs[s], acc[nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // all lanes' reads of zt issued before the next tap overwrites it
+        }
+
+        if (n0 + l31 < Nout) {
+            float* ob = out + (int64_t)b * Cout * Nout + n0 + l31;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] = s_b[nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                for (int r = 0; r < 16; ++r) {
+                    const int o = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o < Cout) ob[(int64_t)o * Nout] = bank.act(acc[nt][r]);
+                }
         }
-#pragma unroll
-        for (int i = 0; i < CIN8; ++i) {
-            const int idx = lane + 64 * i;
-            const int row = idx / LPR, c4 = idx % LPR;
-            *reinterpret_cast<f32x4*>(zt + row * ZS + c4 * 4) = slot[i];
-        }
-        issue(slot);  // stream element ve + D: in flight during the next D taps
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const float* wt = s_w + (ct * Cop + l31) * WS + half * 4;
-#pragma unroll
-        for (int u = 0; u < CIN8; ++u) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(zt + l31 * ZS + u * 8 + half * 4);
-            f32x4 wv[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 32 * WS + u * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[nt][s], bv[s], acc[nt], 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();  // all lanes' reads of zt issued before the next tap overwrites it
-        if (++ct == T) {
-            const int b = cc.b, n0 = cc.tn * 32;
-            if (ve < total && n0 + l31 < Nout) {
-                float* ob = out + (int64_t)b * Cout * Nout + n0;   // uniform; the lane adds (l31 + 4 half Nout) floats
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ou = nt * 32 + (r & 3) + 8 * (r >> 2);   // + 4 * half
-                        if (ou + 4 * half < Cout) store_f32_hidden(ob + (int64_t)ou * Nout, ooff, bank.act(acc[nt][r]));
-                    }
-            }
-            ct = 0;
-            cc.next();
-        }
-    };
-    for (int v = 0; v < total; v += D) {
-        step(ring[0], v);
-        if constexpr (D > 1) step(ring[1], v + 1);
-        if constexpr (D > 2) step(ring[2], v + 2);
-        if constexpr (D > 3) step(ring[3], v + 3);
     }
 }
 
@@ -245,7 +211,7 @@ int resident_workgroups(Kern kern, size_t lds) {
     for (int i = 0; i < used; ++i)
         if (cache[i].k == (const void*)kern && cache[i].lds == lds) return cache[i].n;
     // the runtime is asked for the REGISTER limit only (dynamic LDS 0): its LDS model stops at 64 KB per CU, the CU has 160 KB
-    // (asked with the real LDS size it answered 1 workgroup per CU for the 38 KB of contract_mfma_kernel<1, 4>: 2x slower)
+    // (asked with the real LDS size it answered 1 workgroup per CU for a 38 KB kernel: 2x slower)
     int perCU = 0, dev = 0, cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, kThreads, 0) != hipSuccess || perCU < 1) perCU = 1;
     const int byLds = (int)((160 * 1024) / (lds < 1024 ? 1024 : lds));
@@ -262,18 +228,16 @@ template <int NT, int CIN8>
 int launch_mfma(const float* Z, const BankView& bank, const float* bias, float* out, int B, int N, int Nout, int Cout, int T,
                 hipStream_t st) {
     constexpr int Cin = CIN8 * 8;
-    constexpr int D = CIN8 <= 4 ? 4 : (CIN8 == 8 ? 2 : 1);   // taps in flight per wave: 16 .. 64 registers of ring
-    const size_t lds = ((size_t)T * (Cin + 4) * NT * 32 + NT * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
+    const size_t lds = ((size_t)T * Cin * NT * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
     const int tilesPerB = (Nout + 31) / 32;
     const int64_t totalTiles = (int64_t)B * tilesPerB;
-    GF_REQUIRE_SHAPE(totalTiles < INT32_MAX / 8, "gf_contract: B * N = %lld rows exceed the 32-bit tile index", (long long)B * Nout);
-    auto kern = contract_mfma_kernel<NT, CIN8, D>;
-    if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
+    const int wgPerCU = lds <= 40 * 1024 ? 4 : (lds <= 80 * 1024 ? 2 : 1);
     int64_t nblk = (totalTiles + kWaves - 1) / kWaves;
-    const int resident = resident_workgroups(kern, lds);  // persistent: the bank is staged once per workgroup
-    if (nblk > resident) nblk = resident;
+    if (nblk > 256 * wgPerCU) nblk = 256 * wgPerCU;  // persistent: the bank is staged once per workgroup
+    auto kern = contract_mfma_kernel<NT, CIN8>;
+    if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, st, Z, bank, bias, out, B, N, Nout, Cout, T,
-                       tilesPerB, (int)totalTiles);
+                       tilesPerB, totalTiles);
     GF_LAUNCH_CHECK("contract_mfma_kernel");
     return GF_OK;
 }
@@ -304,13 +268,13 @@ __global__ __launch_bounds__(kThreads) void contract_panel_kernel(const float* _
     // reference layout [B, Cout, Nout].  A lane's accumulators are 4 consecutive outputs of one node per register quad: exactly one
     // 16-byte panel entry, consecutive lanes = consecutive nodes.  maskp (panels of the same shape, nullable): entries whose mask
     // value is <= 0 are written as 0 (the ReLU mask of the layer the gradient is handed to: its activation IS that panel tensor).
-    // The (tile, tap) stream and its register ring of D taps: see contract_mfma_kernel.  A slot is refilled once the MFMAs that read
+    // The (tile, tap) stream and its register ring of D taps: see above store_f32_hidden.  A slot is refilled once the MFMAs that read
     // it have been issued (they read their operands at issue), so D - 1 taps are in flight while one is multiplied.
     constexpr int Cin = CIN8 * 8;
     constexpr int Cop = NT * 32;
     constexpr int Q = Cin / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WS = Cin + 4;         // bank [t][o][Cin + 4], read 16 bytes at a time (see contract_mfma_kernel)
+    constexpr int WS = Cin + 4;         // bank [t][o][Cin + 4]: a lane reads the four c of four consecutive MFMAs with one 16-byte read ((Cin + 4) / 4 odd: conflict-free)
     float* s_w = smem;
     float* s_b = smem + T * Cop * WS;   // [Cop] bias (zeros without one)
     const int tid = threadIdx.x;
@@ -321,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void contract_panel_kernel(const float* _
     for (int o = tid; o < Cop; o += kThreads) s_b[o] = (bias != nullptr && o < Cout) ? bias[o] : 0.f;
     __syncthreads();
 
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar cursors, as in contract_mfma_kernel
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave index as a SCALAR: every tile / tap cursor below lives in SGPRs
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int64_t panelStride = (int64_t)N * 4;
     const int64_t tapStride = (int64_t)B * Q * panelStride;
@@ -509,7 +473,7 @@ int gf_contract_launch(const float* Z, const float* h, const float* bias, float*
     const int cin8 = Cin / 8;
     const bool cin_ok = (Cin % 8 == 0) && (cin8 == 1 || cin8 == 2 || cin8 == 4 || cin8 == 8 || cin8 == 16);
     const int nt = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4);
-    const size_t lds = ((size_t)T * (Cin + 4) * nt * 32 + nt * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
+    const size_t lds = ((size_t)T * Cin * nt * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
     if (!env_generic && cin_ok && Cout <= 128 && lds <= 160 * 1024) {
         switch (nt) {
             case 1: return dispatch_cin<1>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st);

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
                                                                       const float* __restrict__ h, float* __restrict__ dx,
                                                                       float* __restrict__ partial, float* __restrict__ partial_b, int R,
                                                                       int N, int Nout, int B, int E, int K, int rowsPerWave, int dx_panels,
-                                                                      const float* __restrict__ maskp) {
+                                                                      const float* __restrict__ maskp, int Gtot, int numGI, int passes, int ctp) {
     // dx_panels = 1 (layer-to-layer hand-over, panel stacks only): dx goes out as column panels dx[b * G/4 + g/4][n][g % 4], masked by
     // maskp (nullable; the activation panels of the layer the gradient is handed to: entries <= 0 give 0) -- see contract_panel_kernel
     //
@@ -390,7 +390,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
     // instruction (58-65 % MFMA busy at two waves per SIMD, profiles/r03_d_final).  The bank is stored [t][g][f] (a lane reads the four
     // f of four consecutive contraction MFMAs at once), the X0 and P tiles are stored TRANSPOSED [column][row order], rows in the order
     // the reduction MFMAs consume them (row 2s + half at position 16 half + s): four reads give a lane all 16 operands of a tap.
-    constexpr int G = GIN8 * 8, F = FIN8 * 8, QG = G / 4, QF = F / 4;
+    // Gtot > 32 (64, 128: the widths of config 3's layers): blockIdx.y = one 32-wide block of the input features g -- its own X0 columns,
+    // bank rows, dx columns and tap-gradient tiles; the P tiles are read once per block.
+    constexpr int G = GIN8 * 8, F = FIN8 * 8, QF = F / 4;
+    const int gblk = blockIdx.y, g0 = gblk * 32, QG = Gtot / 4, q0 = gblk * 8;
     constexpr int TS = 36;      // row stride of the transposed tiles (floats): 16-byte aligned, 36/4 odd -> conflict-free 16-byte reads
     constexpr int FS = F + 4;   // row stride of the bank (same rule: (F + 4) / 4 is odd for F = 8, 16, 32)
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -402,10 +405,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
         float v = 0.f;
         if (g < G) {
             if (t == 0) {
-                for (int e = 0; e < E; ++e) v += h[((int64_t)(f * E + e) * K) * G + g];   // tap 0 is shared by the edge features
+                for (int e = 0; e < E; ++e) v += h[((int64_t)(f * E + e) * K) * Gtot + g0 + g];   // tap 0 is shared by the edge features
             } else {
                 const int e = (t - 1) / (K - 1), k = (t - 1) % (K - 1) + 1;
-                v = h[((int64_t)(f * E + e) * K + k) * G + g];
+                v = h[((int64_t)(f * E + e) * K + k) * Gtot + g0 + g];
             }
         }
         s_w[(t * 32 + g) * FS + f] = v;
@@ -444,10 +447,12 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
     // TWO elements are in flight while one is consumed, across tile boundaries (one tap ahead left 32 KB per CU on the way: at the
     // loaded HBM latency that is 4.3 TB/s, and every tap ended in a wait).  The slot numbers are compile-time when 3 divides T + 1
     // (T = 5: the K = 5 filters of the configurations; T = 2); the other tap counts keep the one-ahead schedule below.
-    constexpr bool kDeep = (T + 1) % 3 == 0;
+    // (Node-major stacks only: on column panels the same schedule measured 2 % slower than one-ahead, tools/ab_same_box.sh.)
+    constexpr bool kDeep = (T + 1) % 3 == 0 && NM == 1;
     constexpr int MAXW = GIN8 > FIN8 ? GIN8 : FIN8;
     if constexpr (kDeep) {
         f32x4 slot[3][MAXW];
+        const float one = (float)(R > 0);   // 1.0f the compiler cannot fold
         int b = 0, n = 0, nb = 0, nn = 0;
         bool rv = false, nrv = false;
         const float *pb = Pp, *xb = X0p, *npb = Pp, *nxb = X0p;
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
             BB = r_ / N;                                                                                                     \
             NN = r_ - BB * N;                                                                                                \
             PB = NM ? Pp + (int64_t)r_ * F + 4 * half : Pp + ((int64_t)BB * QF + half) * N4 + (int64_t)NN * 4;               \
-            XB = NM ? X0p + (int64_t)r_ * G + 4 * half : X0p + ((int64_t)BB * QG + half) * N4 + (int64_t)NN * 4;             \
+            XB = NM ? X0p + (int64_t)r_ * Gtot + g0 + 4 * half : X0p + ((int64_t)BB * QG + q0 + half) * N4 + (int64_t)NN * 4; \
         } while (0)
 #define GF_LOAD_X0(S, XB)                                                                                                    \
         _Pragma("unroll") for (int u = 0; u < GIN8; ++u) slot[S][u] = *reinterpret_cast<const f32x4*>(XB + (int64_t)u * xstep)
@@ -514,14 +519,17 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
                     for (int s = 0; s < 4; ++s) acc_x = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[s], cur[u][s], acc_x, 0, 0, 0);
                 }
                 if (t == T - 1) {   // dx of this tile is complete: stored ahead of the last 16 tap-gradient MFMAs, through inline asm
-                                    // (see store_f32_hidden: the compiler then keeps exact vmcnt counts for the ring)
+                                    // (see store_f32_hidden in gf_contract.hip: the compiler then keeps exact vmcnt counts for the ring).
+                                    // Every value passes through a VALU instruction the compiler sees (* one, exact): the wait
+                                    // states between an MFMA and a store reading its result are only inserted for instructions
+                                    // the hazard recogniser knows, not for inline asm.
                     if (rv && dx_panels) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int q = 2 * j + half;   // g = 4q .. 4q + 3
-                            if (q < QG) {
-                                const int64_t at = (((int64_t)b * QG + q) * N + n) * 4;
-                                f32x4 v = {acc_x[4 * j], acc_x[4 * j + 1], acc_x[4 * j + 2], acc_x[4 * j + 3]};
+                            if (q < G / 4) {
+                                const int64_t at = (((int64_t)b * QG + q0 + q) * N + n) * 4;
+                                f32x4 v = {acc_x[4 * j] * one, acc_x[4 * j + 1] * one, acc_x[4 * j + 2] * one, acc_x[4 * j + 3] * one};
                                 if (maskp) {
                                     const float4 m = *reinterpret_cast<const float4*>(maskp + at);
                                     v[0] = m.x > 0.f ? v[0] : 0.f;
@@ -529,15 +537,15 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
                                     v[2] = m.z > 0.f ? v[2] : 0.f;
                                     v[3] = m.w > 0.f ? v[3] : 0.f;
                                 }
-                                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dx + at), "v"(v) : "memory");
+                                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dx + at), "v"(v) : "memory");   // (s_nop: > 8-byte store data hazard, see gf_contract.hip)
                             }
                         }
                     } else if (rv && n < Nout) {
-                        float* ob = dx + (int64_t)b * G * Nout + n;
+                        float* ob = dx + ((int64_t)b * Gtot + g0) * Nout + n;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
-                            const float v = acc_x[i];
+                            const float v = acc_x[i] * one;
                             if (g < G) asm volatile("global_store_dword %0, %1, off" ::"v"(ob + (int64_t)g * Nout), "v"(v) : "memory");
                         }
                     }
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
         const int n = rv ? r - b * N : 0;
         const float* pb = NM ? Pp + (int64_t)r * F + 4 * half                     // + 8u floats, + t taps
                              : Pp + ((int64_t)b * QF + half) * N4 + (int64_t)n * 4;   // + (2u) panels, + t taps
-        const float* xb = NM ? X0p + (int64_t)r * G + 4 * half : X0p + ((int64_t)b * QG + half) * N4 + (int64_t)n * 4;
+        const float* xb = NM ? X0p + (int64_t)r * Gtot + g0 + 4 * half : X0p + ((int64_t)b * QG + q0 + half) * N4 + (int64_t)n * 4;
         float4 x0[GIN8], cur[FIN8], nxt[FIN8];
 #pragma unroll
         for (int u = 0; u < GIN8; ++u)
@@ -618,8 +626,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int q = 2 * j + half;   // g = 4q .. 4q + 3
-                if (q < QG) {
-                    const int64_t at = (((int64_t)b * QG + q) * N + n) * 4;
+                if (q < G / 4) {
+                    const int64_t at = (((int64_t)b * QG + q0 + q) * N + n) * 4;
                     float4 v = make_float4(acc_x[4 * j], acc_x[4 * j + 1], acc_x[4 * j + 2], acc_x[4 * j + 3]);
                     if (maskp) {
                         const float4 m = *reinterpret_cast<const float4*>(maskp + at);
@@ -632,7 +640,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
                 }
             }
         } else if (rv && n < Nout) {
-            float* ob = dx + (int64_t)b * G * Nout + n;
+            float* ob = dx + ((int64_t)b * Gtot + g0) * Nout + n;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
@@ -641,16 +649,19 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
         }
     }
 
-    float* pt = partial + (int64_t)wg * T * 1024;
+    // tap-gradient tile (t, gblk) is tile ct = t * numGI + gblk of the shared partial layout [wave][pass][ctp] (make_geo; one pass when Gtot <= 32)
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < T; ++t) {
+        const int ct = t * numGI + gblk;
+        float* pt = partial + (((int64_t)wg * passes + ct / ctp) * ctp + ct % ctp) * 1024;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
-            pt[t * 1024 + g * 32 + l31] = acc_h[t][i];
+            pt[g * 32 + l31] = acc_h[t][i];
         }
+    }
     const float other = __shfl_xor(bsum, 32, 64);
-    if (half == 0) partial_b[(int64_t)wg * 32 + l31] = bsum + other;  // even rows + odd rows
+    if (half == 0 && gblk == 0) partial_b[(int64_t)wg * 32 + l31] = bsum + other;  // even rows + odd rows
 }
 
 int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, int E, int K, hipStream_t st) {
@@ -677,7 +688,8 @@ int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, 
 bool gf_bwd_fused_supported(int G, int F, int E, int K) {
     const int T = gf_num_taps(E, K);
     auto ok = [](int w) { return w == 8 || w == 16 || w == 32; };
-    return ok(G) && ok(F) && T >= 1 && T <= 6;  // 16 accumulator registers per tap: T = 7, 8 need > 256 VGPRs (one wave per SIMD)
+    // G = 64, 128: one 32-wide block of g per blockIdx.y.  (F > 32 would need the tap gradients of two f blocks in one wave's registers.)
+    return (ok(G) || G == 64 || G == 128) && ok(F) && T >= 1 && T <= 6;  // 16 accumulator registers per tap: T = 7, 8 need > 256 VGPRs
 }
 
 int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,
@@ -687,7 +699,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
     GF_REQUIRE_SHAPE(!dx_panels || (!node_major && Nout == N), "gf_lsigf_backward: panel hand-over of dx needs the panel pipeline and Nin == N");
     GF_REQUIRE_SHAPE(g.R < (int64_t)INT32_MAX - 4096, "gf_lsigf_backward: B*N = %lld too large", (long long)g.R);
     GF_REQUIRE_ARG(workspace && workspace_bytes >= g.bytes, "gf_lsigf_backward: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
-    GF_REQUIRE_SHAPE(g.passes == 1 && g.ctp == g.T, "gf_lsigf_backward: fused backward geometry");
+    GF_REQUIRE_SHAPE(g.numFT == 1 && (G > 32 || (g.passes == 1 && g.ctp == g.T)), "gf_lsigf_backward: fused backward geometry");
     float* ws = (float*)workspace;
     const size_t lds = ((size_t)g.T * 32 * (F + 4) + (size_t)kWaves * 2 * 32 * 36) * sizeof(float);  // bank [t][g][F + 4] + wave tiles (TS = 36)
     hipError_t attr = hipSuccess;
@@ -695,8 +707,8 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
     do {                                                                                                                        \
         auto kern = node_major ? bwd_fused_panel_kernel<TT, GG, FF, 1> : bwd_fused_panel_kernel<TT, GG, FF, 0>;                 \
         if (lds > 64 * 1024) attr = gf_grant_lds((const void*)kern, lds); \
-        hipLaunchKernelGGL(kern, dim3(g.strips), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
-                           Nout, B, E, K, g.rowsPerWave, dx_panels, maskp);                                                     \
+        hipLaunchKernelGGL(kern, dim3(g.strips, g.numGI), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
+                           Nout, B, E, K, g.rowsPerWave, dx_panels, maskp, G, g.numGI, g.passes, g.ctp);                        \
     } while (0)
 #define GF_BF_F(TT, GG)                                                                                                         \
     switch (F / 8) {                                                                                                            \
@@ -705,7 +717,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
         default: GF_BF(TT, GG, 4); break;                                                                                       \
     }
 #define GF_BF_G(TT)                                                                                                             \
-    switch (G / 8) {                                                                                                            \
+    switch (G >= 32 ? 4 : G / 8) {                                                                                              \
         case 1: GF_BF_F(TT, 1); break;                                                                                          \
         case 2: GF_BF_F(TT, 2); break;                                                                                          \
         default: GF_BF_F(TT, 4); break;                                                                                         \

@@ -558,6 +558,12 @@ def test_graph_recurrent_nn_matches_reference():
     dict(N=5000, B=8, G=64, F=32, K=5, directed=False, model="er"),
     dict(N=1682, B=5, G=1, F=64, K=5, directed=False, model="sbm"),      # config-3 first layer shape
     dict(N=2000, B=33, G=32, F=32, K=3, directed=True, model="er", E=2),
+    # one-pass backward over 32-wide blocks of the input features (G = 64, 128): panel pipeline with the two-ahead operand ring (T = 5)
+    # and with the one-ahead schedule (T = 3), several edge features, and the node-major pipeline (N beyond the LDS panel limit)
+    dict(N=700, B=3, G=128, F=16, K=3, directed=True, model="sbm"),
+    dict(N=900, B=4, G=64, F=8, K=3, directed=True, model="er", E=2),
+    dict(N=12000, B=2, G=64, F=32, K=5, directed=False, model="er"),
+    dict(N=11000, B=3, G=128, F=32, K=2, directed=True, model="er"),
 ], ids=lambda c: "_".join(f"{k}{v}" for k, v in c.items()))
 def test_lsigf_random_sparse_vs_oracle(cfg):
     E = cfg.get("E", 1)
@@ -1250,7 +1256,7 @@ def test_training_step_is_hip_graph_capturable():
 # layer-to-layer hand-over in the internal layout (gf_lsigf_forward_ex / gf_lsigf_backward_ex)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dimF,K,N,B", [([1, 64, 32], [5, 5], 234, 5), ([3, 8, 16, 8], [3, 2, 4], 500, 7), ([32, 32, 32], [5, 5], 2000, 16),
-                                        ([2, 16, 8], [3, 3], 97, 3), ([2, 24, 40], [3, 3], 97, 3)])
+                                        ([2, 16, 8], [3, 3], 97, 3), ([2, 24, 40], [3, 3], 97, 3), ([8, 64, 32, 16], [3, 5, 2], 300, 4)])
 def test_layer_handover_is_bitwise_the_separate_layers(dimF, K, N, B, monkeypatch):
     """Runs of [GraphFilter, ReLU, NoPool] blocks keep their signals in the column-panel layout between layers: the same kernels do the
     same arithmetic in the same order, only one reference-layout round trip per inner boundary is gone -- outputs, input gradient and
