@@ -30,6 +30,11 @@ import alegnn.utils.graphTools as gt  # noqa: E402
 import alegnn.modules.architectures as archit  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# --out DIR writes the fixtures somewhere else (tests/test_oracle_golden.py::test_golden_recipe_* regenerates into tmp_path
+# and compares with the committed files)
+OUT = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
+os.makedirs(OUT, exist_ok=True)
+_NO_ATTR = object()
 torch.set_default_dtype(torch.float64)
 
 
@@ -55,7 +60,7 @@ def lsigf_case(name, S, B, G, F, K, bias=True, seed=0):
     out = dict(h=h, x=x, dy=dy, y=y.detach().numpy(), dx=xt.grad.numpy(), dh=ht.grad.numpy(), **coo(S))
     if bias:
         out.update(b=b, db=bt.grad.numpy())
-    np.savez_compressed(os.path.join(HERE, f"lsigf_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"lsigf_{name}.npz"), **out)
     print(f"lsigf_{name}: N={N} E={E} B={B} G={G} F={F} K={K} nnz={int((S != 0).sum())} max|y|={np.abs(out['y']).max():.3g}")
 
 
@@ -71,7 +76,7 @@ def graph_filter_case(name, S, B, G, F, K, Nin, seed=0):
     xt = torch.tensor(x, requires_grad=True)
     y = layer(xt)
     y.backward(torch.tensor(dy))
-    np.savez_compressed(os.path.join(HERE, f"gfilter_{name}.npz"), x=x, dy=dy, y=y.detach().numpy(),
+    np.savez_compressed(os.path.join(OUT, f"gfilter_{name}.npz"), x=x, dy=dy, y=y.detach().numpy(),
                         dx=xt.grad.numpy(), weight=layer.weight.detach().numpy(), bias=layer.bias.detach().numpy(),
                         dweight=layer.weight.grad.numpy(), dbias=layer.bias.grad.numpy(), **coo(S))
     print(f"gfilter_{name}: N={N} Nin={Nin} y{tuple(y.shape)}")
@@ -97,7 +102,7 @@ def selection_gnn_case(name, S2d, dimNodeSignals, nFilterTaps, nSelectedNodes, p
     cfg = dict(dimNodeSignals=dimNodeSignals, nFilterTaps=nFilterTaps, nSelectedNodes=nSelectedNodes, pool=pool,
                poolingSize=poolingSize, dimLayersMLP=dimLayersMLP)
     out["cfg"] = np.array(repr(cfg))
-    np.savez_compressed(os.path.join(HERE, f"selgnn_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"selgnn_{name}.npz"), **out)
     print(f"selgnn_{name}: N={N} y{tuple(y.shape)} ygnn{tuple(ygnn.shape)} keys={[k for k in out if k.startswith('sd:')]}")
 
 
@@ -106,6 +111,7 @@ def selection_gnn_coarsen_case(name, S2d, dimNodeSignals, nFilterTaps, dimLayers
     graphTools.py:1458 still says np.bool (removed in numpy 1.24): aliased here for the duration of the call only."""
     rng = np.random.RandomState(seed)
     L = len(nFilterTaps)
+    saved = getattr(np, "bool", _NO_ATTR)                       # numpy >= 2.0 has its own np.bool again: put it back afterwards
     np.bool = bool
     try:
         np.random.seed(seed)                                     # metis draws the first visiting order (graphTools.py:1393)
@@ -115,7 +121,10 @@ def selection_gnn_coarsen_case(name, S2d, dimNodeSignals, nFilterTaps, dimLayers
         net = archit.SelectionGNN(dimNodeSignals, nFilterTaps, True, torch.nn.ReLU, [0] * L, torch.nn.MaxPool1d, [2] * L,
                                   dimLayersMLP, S2d, coarsening=True)
     finally:
-        del np.bool
+        if saved is _NO_ATTR:
+            del np.bool
+        else:
+            np.bool = saved
     assert [int(v) for v in net.order] == [int(v) for v in perm]
     N = S2d.shape[0]
     x = rng.randn(B, dimNodeSignals[0], N)
@@ -141,7 +150,7 @@ def selection_gnn_coarsen_case(name, S2d, dimNodeSignals, nFilterTaps, dimLayers
         out["grad:" + k] = p.grad.numpy()
     cfg = dict(dimNodeSignals=dimNodeSignals, nFilterTaps=nFilterTaps, dimLayersMLP=dimLayersMLP)
     out["cfg"] = np.array(repr(cfg))
-    np.savez_compressed(os.path.join(HERE, f"selgnn_coarsen_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"selgnn_coarsen_{name}.npz"), **out)
     print(f"selgnn_coarsen_{name}: N={net.N} y{tuple(y.shape)} ygnn{tuple(ygnn.shape)}")
 
 
@@ -168,7 +177,7 @@ def local_gnn_case(name, S2d, dimNodeSignals, nFilterTaps, nSelectedNodes, pool,
     cfg = dict(dimNodeSignals=dimNodeSignals, nFilterTaps=nFilterTaps, nSelectedNodes=nSelectedNodes, pool=pool,
                poolingSize=poolingSize, dimReadout=dimReadout)
     out["cfg"] = np.array(repr(cfg))
-    np.savez_compressed(os.path.join(HERE, f"localgnn_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"localgnn_{name}.npz"), **out)
     print(f"localgnn_{name}: N={N} y{tuple(y.shape)} ysn{tuple(ysn.shape)}")
 
 
@@ -200,7 +209,7 @@ def grnn_case(name, S, B, T, F, H, K, gating, seed=0):
         zz, zT = layer(torch.tensor(x), torch.tensor(z0))
         assert torch.equal(zz, z.detach())
         out["zT_shape"] = np.array(zT.shape)
-    np.savez_compressed(os.path.join(HERE, f"grnn_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"grnn_{name}.npz"), **out)
     print(f"grnn_{name}: z{tuple(z.shape)} gating={gating}")
 
 
@@ -224,7 +233,7 @@ def gated_hidden_state_case(name, kind, S, B, T, F, H, K, seed=0):
         out["sd:" + k] = v.numpy()
     for k, p in layer.named_parameters():
         out["grad:" + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, f"gatedhs_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"gatedhs_{name}.npz"), **out)
     print(f"gatedhs_{name}: z{tuple(z.shape)} keys={list(layer.state_dict())}")
 
 
@@ -247,7 +256,7 @@ def jarma_case(name, S, B, G, F, P, K, tMax, bias=True, seed=0):
         out["d" + k] = v.grad.numpy()
     if bias:
         out["b"], out["db"] = b, bt.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, f"jarma_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"jarma_{name}.npz"), **out)
     print(f"jarma_{name}: y{tuple(y.shape)} tMax={tMax}")
 
 
@@ -267,7 +276,7 @@ def edge_variant_gnn_case(name, S2d, B, seed=0):
         out["sd:" + k] = v.numpy()
     for k, p in net.named_parameters():
         out["grad:" + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, f"evgnn_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"evgnn_{name}.npz"), **out)
     print(f"evgnn_{name}: y{tuple(y.shape)} ygnn{tuple(ygnn.shape)} keys={list(net.state_dict())}")
 
 
@@ -303,7 +312,7 @@ def graph_recurrent_nn_case(name, S2d, B, T, seed=0):
         out["sd:" + k] = v.numpy()
     for k, p in net.named_parameters():
         out["grad:" + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, f"grnnarch_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"grnnarch_{name}.npz"), **out)
     print(f"grnnarch_{name}: y{tuple(y.shape)} keys={list(net.state_dict())}")
 
 
@@ -340,7 +349,7 @@ def nvgf_case(name, S, B, G, F, K, M, Nin=None, bias_nodes=False, seed=0):
         y2.backward(torch.tensor(dy2))
         out.update(f_h=h.detach().numpy(), f_b=bN.detach().numpy(), f_x=x2.detach().numpy(), f_y=y2.detach().numpy(), f_dy=dy2,
                    f_dh=h.grad.numpy(), f_db=bN.grad.numpy(), f_dx=x2.grad.numpy())
-    np.savez_compressed(os.path.join(HERE, f"nvgf_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"nvgf_{name}.npz"), **out)
     print(f"nvgf_{name}: N={N} Nin={Nin} M={M} y{tuple(y.shape)} copyNodes[-5:]={layer.copyNodes.numpy()[-5:]}")
 
 
@@ -360,7 +369,7 @@ def node_variant_gnn_case(name, S2d, B, seed=0):
         out["sd:" + k] = v.numpy()
     for k, p in net.named_parameters():
         out["grad:" + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, f"nvgnn_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"nvgnn_{name}.npz"), **out)
     print(f"nvgnn_{name}: y{tuple(y.shape)} ygnn{tuple(ygnn.shape)} keys={list(net.state_dict())}")
 
 
@@ -410,12 +419,12 @@ def trainer_case(name, G, S2d, archit_fn, nEpochs, batchSize, seed, **trainKw):
     out["costBest"], out["costLast"] = np.array(evalVars["costBest"]), np.array(evalVars["costLast"])
     for k, v in init.items():
         out["init:" + k] = v.numpy()
-    ckpt = os.path.join(HERE, "ckpt")
+    ckpt = os.path.join(OUT, "ckpt")
     os.makedirs(ckpt, exist_ok=True)
     for f in sorted(os.listdir(os.path.join(tmp, "savedModels"))):
         shutil.copy(os.path.join(tmp, "savedModels", f), os.path.join(ckpt, f))
     shutil.rmtree(tmp)
-    np.savez_compressed(os.path.join(HERE, f"trainer_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"trainer_{name}.npz"), **out)
     print(f"trainer_{name}: steps={len(out['lossTrain'])} lossTrain[0,-1]={out['lossTrain'][0]:.4f},{out['lossTrain'][-1]:.4f} "
           f"costValid={out['costValid']} eval={evalVars}")
 
@@ -457,7 +466,7 @@ def evgf_case(name, S, B, G, F, K, M, Nin=None, bias=True, seed=0):
         out.update(weightLSI=layer.weightLSI.detach().numpy(), dweightLSI=layer.weightLSI.grad.numpy())
     if bias:
         out.update(bias=layer.bias.detach().numpy(), dbias=layer.bias.grad.numpy())
-    np.savez_compressed(os.path.join(HERE, f"evgf_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"evgf_{name}.npz"), **out)
     print(f"evgf_{name}: N={N} E={E} M={M} Nin={Nin} B={B} G={G} F={F} K={K} max|y|={np.abs(out['y']).max():.3g}")
 
 
@@ -496,7 +505,7 @@ def lsigf_db_case(name, B, T, E, N, G, F, K, bias=True, seed=0):
     out = dict(S=S, h=h, x=x, dy=dy, y=y.detach().numpy(), dx=xt.grad.numpy(), dh=ht.grad.numpy())
     if bias:
         out.update(b=b, db=bt.grad.numpy())
-    np.savez_compressed(os.path.join(HERE, f"lsigfdb_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"lsigfdb_{name}.npz"), **out)
     print(f"lsigfdb_{name}: S{S.shape} density={np.mean(S != 0):.2f} y{tuple(y.shape)} max|y|={np.abs(out['y']).max():.3g}")
 
 
@@ -517,7 +526,7 @@ def grnn_db_case(name, B, T, E, N, F, H, K, seed=0):
         out["sd:" + k] = v.numpy()
     for k, p in layer.named_parameters():
         out["grad:" + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, f"grnndb_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"grnndb_{name}.npz"), **out)
     print(f"grnndb_{name}: z{tuple(z.shape)} zT{tuple(zT.shape)}")
 
 
@@ -548,7 +557,7 @@ def edge_gated_grnn_case(name, S, B, T, F, H, K, which="both", seed=0):
         out["sd:" + k] = v.numpy()
     for k, p in layer.named_parameters():
         out["grad:" + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, f"edgegrnn_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"edgegrnn_{name}.npz"), **out)
     print(f"edgegrnn_{name}: z{tuple(z.shape)} which={which}")
 
 
@@ -569,7 +578,7 @@ def edge_gated_hidden_state_case(name, S, B, T, F, H, K, seed=0):
         out["sd:" + k] = v.numpy()
     for k, p in layer.named_parameters():
         out["grad:" + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, f"edgehs_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"edgehs_{name}.npz"), **out)
     print(f"edgehs_{name}: z{tuple(z.shape)} keys={list(layer.state_dict())}")
 
 
@@ -582,7 +591,7 @@ def attention_case(name, S, B, G, F, P, seed=0):
     xt, at, Wt = (torch.tensor(v, requires_grad=True) for v in (x, a, W))
     q = gml.learnAttentionGSO(xt, at, Wt, torch.tensor(S))
     (q * torch.tensor(dq)).sum().backward()
-    np.savez_compressed(os.path.join(HERE, f"attention_{name}.npz"), x=x, a=a, W=W, dq=dq, q=q.detach().numpy(), dx=xt.grad.numpy(),
+    np.savez_compressed(os.path.join(OUT, f"attention_{name}.npz"), x=x, a=a, W=W, dq=dq, q=q.detach().numpy(), dx=xt.grad.numpy(),
                         da=at.grad.numpy(), dW=Wt.grad.numpy(), **coo(S))
     print(f"attention_{name}: q{tuple(q.shape)}")
 
@@ -660,7 +669,7 @@ def main():
         gt_out["S_" + name] = Sp
     Sp, order = gt.permDegree(asym)
     gt_out["order_Degree_E2"], gt_out["S_Degree_E2"], gt_out["asym_E2"] = np.array(order), Sp, asym
-    np.savez_compressed(os.path.join(HERE, "graphtools_sbm100.npz"), **gt_out)
+    np.savez_compressed(os.path.join(OUT, "graphtools_sbm100.npz"), **gt_out)
     print("graphtools_sbm100:", sorted(gt_out))
 
     # ---- EVGF / EdgeVariantGF (graphML.py:389-488, 2511-2712) ----------------------------------------------
@@ -693,6 +702,14 @@ def main():
     selection_gnn_case("cfg1_sbm100", sbm, [1, 32, 32], [5, 5], [10, 10], "MaxPoolLocal", [6, 8], [5], B=6)
     # config 3 shapes (examples/movieGNN.py:259-276): F=[1,64,32], K=[5,5], NoPool, MLP [1]; graph = fbego (MovieLens needs network)
     selection_gnn_case("cfg3_fbego", fb[0], [1, 64, 32], [5, 5], [234, 234], "NoPool", [1, 1], [1], B=5)
+    # ---- the callers that reuse LSIGF and the trainer run (row f-4): the same calls as the
+    # --*-only flags above, so that the unflagged recipe regenerates EVERY committed fixture
+    nvgf_cases(sbm, asym, asym37, ring)
+    grnn_cases(sbm, asym, fb)
+    f3_cases(sbm, asym, asym37)
+    trainer_cases(G, sbm)
+    local_gnn_case("fbego_movie", fb[0], [1, 64, 32], [5, 5], [234, 234], "NoPool", [1, 1], [1], B=5)
+    local_gnn_case("sbm100_pool", sbm, [2, 8, 8], [3, 3], [30, 12], "MaxPoolLocal", [2, 3], [6, 3], B=4, seed=2)
 
 
 if __name__ == "__main__":
