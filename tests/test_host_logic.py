@@ -740,3 +740,19 @@ def test_locality_groups_are_cached_per_pattern_on_disk(tmp_path, monkeypatch):
                      np.ascontiguousarray(other.indices, dtype=np.int32).ctypes.data, np.ascontiguousarray(other.data).ctypes.data,
                      int(other.data.dtype == np.float64), 0, ctypes.byref(out))
     assert len(list(tmp_path.iterdir())) == 2
+
+
+def test_stream_image_on_cpu(tmp_path):
+    """The STREAM image of round 4 (csrc/gf_stream_image.h: runs of 32 in-band steps, LAST masks, output-row tables, residual hub slices,
+    prefetch runs) is pure host code: tools/stream_image_check.cpp builds it for random scheduled CSRs, interprets it the way
+    spmm_stream_kernel executes it and compares bit for bit with the row-by-row product (graphML.py:158-161 per batch entry)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    exe = str(tmp_path / "stream_image_check")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "graph-neural-networks_amd", "csrc"),
+                        os.path.join(ROOT, "tools", "stream_image_check.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-3000:]

@@ -1,0 +1,76 @@
+#!/bin/bash
+# Round-4 GPU stages.  Usage (on the GPU box, from the repo root): bash tools/gpu_r4.sh <stage> [outdir]
+cd "$(dirname "$0")/.."; export TMPDIR=/tmp GFHIP_EXPERIMENTS=1
+S=${1:-a}; O=gpurun_out/${2:-r4_$S}; mkdir -p $O
+VARS="v:spmm_algo=3 v:spmm_algo=2+spmm_sd=16+spmm_wps=4 v:spmm_algo=2+spmm_sd=8+spmm_wps=4 v:spmm_algo=2+spmm_wps=6 v:spmm_algo=2+spmm_wps=8"
+case $S in
+a)  # stream kernel: parity, then ER / band timings of every variant on one plan; masked-gather microbenchmark
+  timeout 120 tools/gather_mask > $O/gather_mask.log 2>&1; cat $O/gather_mask.log
+  timeout 900 python -m pytest tests/test_gpu_stream.py -x -q > $O/pytest_stream.log 2>&1; tail -5 $O/pytest_stream.log
+  timeout 300 python tools/hop_probe.py cfg4 10 $VARS > $O/hop_er.log 2>&1; grep "spmm hop" $O/hop_er.log
+  PROBE_GRAPH=band timeout 300 python tools/hop_probe.py cfg4 10 $VARS > $O/hop_band.log 2>&1; grep "spmm hop" $O/hop_band.log
+  ;;
+b)  # ticket hand-out variants (atomic-bound in stage a: one counter per XCD served ~32 tickets/us)
+  timeout 900 python -m pytest tests/test_gpu_stream.py -x -q > $O/pytest_stream.log 2>&1; tail -5 $O/pytest_stream.log
+  V="v:spmm_algo=3"
+  for tk in 0 1 2; do for nc in 16 4; do for sh in spmm_sd=16+spmm_wps=4 spmm_wps=6 spmm_wps=8; do
+    [ $tk = 0 ] && [ $nc = 4 ] && continue
+    V="$V v:spmm_algo=2+spmm_tk=$tk+spmm_nc=$nc+$sh"
+  done; done; done
+  timeout 400 python tools/hop_probe.py cfg4 10 $V > $O/hop_er.log 2>&1; grep "spmm hop" $O/hop_er.log
+  PROBE_GRAPH=band timeout 400 python tools/hop_probe.py cfg4 10 $V > $O/hop_band.log 2>&1; grep "spmm hop" $O/hop_band.log
+  ;;
+c)  # lean stream kernel (buffer loads, LAST mask, scalar-atomic tickets)
+  timeout 300 python -m pytest tests/test_gpu_stream.py -x -q > $O/pytest_stream.log 2>&1; tail -5 $O/pytest_stream.log
+  V="v:spmm_algo=3"
+  for sh in spmm_wps=4 spmm_wps=5 spmm_wps=8; do for tk in "spmm_tk=0" "spmm_tk=2+spmm_nc=16" "spmm_tk=2+spmm_nc=4" "spmm_tk=2+spmm_nc=1"; do
+    V="$V v:spmm_algo=2+$tk+$sh"
+  done; done
+  timeout 120 python tools/hop_probe.py cfg4 10 $V > $O/hop_er.log 2>&1; grep "spmm hop" $O/hop_er.log
+  PROBE_GRAPH=band timeout 120 python tools/hop_probe.py cfg4 10 $V > $O/hop_band.log 2>&1; grep "spmm hop" $O/hop_band.log
+  ;;
+d)  # counters: why is the stream kernel no faster than SELL-8?
+  PROBE_GRAPH=band bash tools/pmc_hop.sh $O > /dev/null 2>&1; cat $O/pmc_hop_band.log
+  bash tools/pmc_hop.sh $O > /dev/null 2>&1; cat $O/pmc_hop_er.log
+  ;;
+e)  # band graph WITHOUT locality groups (window-sorted natural order: true L2 residency) -- both kernels, + hit-rate counters
+  V="v:spmm_algo=3 v:spmm_algo=2+spmm_wps=4+spmm_tk=2+spmm_nc=1 v:spmm_algo=2+spmm_wps=4+spmm_tk=2+spmm_nc=16 v:spmm_algo=2+spmm_wps=5+spmm_tk=2+spmm_nc=1 v:spmm_algo=2+spmm_wps=4+spmm_tk=0"
+  PROBE_GRAPH=band timeout 120 python tools/hop_probe.py cfg4 10 spmm_group=0 $V > $O/hop_band_nogroups.log 2>&1; grep "spmm hop" $O/hop_band_nogroups.log
+  PROBE_GRAPH=band timeout 120 python tools/hop_probe.py cfg4 10 spmm_group=0 spmm_store=3 v:spmm_algo=3 > $O/hop_band_nogroups_nostore.log 2>&1; grep "spmm hop" $O/hop_band_nogroups_nostore.log
+  rm -rf $O/pm; PROBE_GRAPH=band timeout 100 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $O/pm -o pmc -- python tools/hop_probe.py cfg4 3 spmm_group=0 v:spmm_algo=3 v:spmm_algo=2+spmm_wps=4+spmm_tk=2+spmm_nc=1 > $O/pm.log 2>&1
+  python3 - "$O" <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"{O}/pm/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r["Kernel_Name"]
+        tag = "stream" if "spmm_stream" in kn else ("sell" if "spmm_sell" in kn else None)
+        if tag:
+            agg[(tag, r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (tag, k), v in sorted(agg.items()):
+    print(f"band-nogroups {tag:7s} {k:30s} max {max(v):16.0f} n={len(v)}")
+PY
+  rm -rf $O/pm
+  ;;
+f)  # launch order of the K-1 hops (Infinity-Cache residency of the tap just written) + gather rates out of L2 / IC / HBM
+  timeout 200 python tools/chunk_order_probe.py cfg4 8,16,32,64 > $O/chunk_order.log 2>&1; cat $O/chunk_order.log | grep cfg4
+  timeout 200 python tools/chunk_order_probe.py cfg4 8,16 spmm_store=0 > $O/chunk_order_plain_stores.log 2>&1; grep cfg4 $O/chunk_order_plain_stores.log
+  for rows in 32768 131072 524288 2097152; do timeout 60 tools/gather_ceiling one $rows 4096; done > $O/gather_l2_ic_hbm.log 2>&1; cat $O/gather_l2_ic_hbm.log
+  ;;
+g)  # prefetch runs: band graph (with / without locality groups), stream kernel with and without them, against SELL-8; ER unchanged?
+  timeout 200 python -m pytest tests/test_gpu_stream.py -x -q > $O/pytest_stream.log 2>&1; tail -3 $O/pytest_stream.log
+  V="v:spmm_algo=3 v:spmm_algo=2+spmm_wps=4+spmm_tk=2+spmm_nc=1 v:spmm_algo=2+spmm_wps=4+spmm_tk=2+spmm_nc=4 v:spmm_algo=2+spmm_wps=5+spmm_tk=2+spmm_nc=1 v:spmm_algo=2+spmm_wps=4+spmm_tk=0"
+  for spf in 1 0; do for grp in 1 0; do
+    PROBE_GRAPH=band timeout 100 python tools/hop_probe.py cfg4 10 spmm_group=$grp spmm_spf=$spf $V > $O/hop_band_g${grp}_pf$spf.log 2>&1; grep "spmm hop" $O/hop_band_g${grp}_pf$spf.log
+  done; done
+  timeout 100 python tools/hop_probe.py cfg4 10 $V > $O/hop_er.log 2>&1; grep "spmm hop" $O/hop_er.log
+  ;;
+h)  # prefetch lead x front width (waves per SIMD)
+  V="v:spmm_algo=3"; for w in 4 2 1; do for nc in 1 4; do V="$V v:spmm_algo=2+spmm_wps=$w+spmm_tk=2+spmm_nc=$nc"; done; done
+  for spf in 0 2 4; do for grp in 0 1; do
+    PROBE_GRAPH=band timeout 100 python tools/hop_probe.py cfg4 10 spmm_group=$grp spmm_spf=$spf $V > $O/hop_band_g${grp}_pf$spf.log 2>&1; grep "spmm hop" $O/hop_band_g${grp}_pf$spf.log
+  done; done
+  timeout 100 python tools/hop_probe.py cfg4 10 $V > $O/hop_er.log 2>&1; grep "spmm hop" $O/hop_er.log
+  ;;
+esac

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch the dominant kernel of a bench.py workload a few times, nothing else on the stream after set-up: the target of
-`rocprofv3 --pmc ...` / `--kernel-trace --stats` (tools/pmc_collect.sh).  Usage: hop_probe.py <workload> [iters] [key=val ...]"""
+`rocprofv3 --pmc ...` / `--kernel-trace --stats` (tools/pmc_collect.sh).  Usage: hop_probe.py <workload> [iters] [key=val ...]
+An argument `k=v+k=v+...` is a VARIANT: the node-major hop is timed once per variant on the same plan (A/B on one box, one process)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-neural-networks_amd")]
@@ -10,7 +11,10 @@ from alegnn_amd import _lib
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 L = _lib.lib()
+variants = [a for a in sys.argv[3:] if "+" in a or a.startswith("v:")]
 for kv in sys.argv[3:]:
+    if kv in variants:
+        continue
     k, v = kv.split("=")
     assert L.gf_tune(k.encode(), int(v)) == 0, k
 dev = torch.device("cuda:0")
@@ -54,6 +58,17 @@ else:
     else:
         X0 = torch.randn(B, N, W, device=dev); X1 = torch.empty_like(X0)
         ms = ctypes.c_float()
-        _lib.check(L.gf_time_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, W, max(iters, 3), st, ctypes.byref(ms)))
-        print(f"spmm hop {name} graph={os.environ.get('PROBE_GRAPH', 'default')} nnz={w.nnz} {' '.join(sys.argv[3:])}: {ms.value:.4f} ms")
+        ref = None
+        for var in (variants or [""]):
+            for kv in var.replace("v:", "").split("+"):
+                if kv:
+                    k, v = kv.split("=")
+                    assert L.gf_tune(k.encode(), int(v)) == 0, k
+            X1.fill_(float("nan"))
+            _lib.check(L.gf_time_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, W, max(iters, 3), st, ctypes.byref(ms)))
+            torch.cuda.synchronize()
+            same = "" if ref is None else f"  bitwise == first variant: {bool(torch.equal(ref, X1))}"
+            if ref is None:
+                ref = X1.clone()
+            print(f"spmm hop {name} graph={os.environ.get('PROBE_GRAPH', 'default')} nnz={w.nnz} {' '.join(a for a in sys.argv[3:] if a not in variants)} {var}: {ms.value:.4f} ms{same}", flush=True)
 torch.cuda.synchronize()
