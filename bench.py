@@ -19,8 +19,10 @@ per-step HIP-event times is reported next to it (ms_per_step_median).
 
 Extra objects on the JSON line:
   roofline     -- the dominant kernel: achieved = algorithmic bytes per launch / its average launch time, timed here with
-                  HIP events on the launch stream; peak = 8 TB/s HBM3E; traffic = PMC HBM bytes per launch from profiles/*_pmc.json
-                  (rocprofv3 --pmc in passes of their own, tools/pmc_collect.sh) for this workload and kernel, else null.
+                  HIP events on the launch stream; peak = 8 TB/s HBM3E; traffic = PMC bytes per launch on the memory side of the L2s
+                  (fabric / L2-miss traffic: Infinity-Cache hits are counted) from profiles/*_pmc.json (rocprofv3 --pmc in passes of
+                  their own, tools/pmc_collect.sh) for this workload and kernel, only if taken on the running kernel sources, else null.
+  distributed  -- (under torch.distributed.run) per-rank ms_per_step min / max, the all-reduce's HIP-event time per step and its share.
   cpu_baseline -- the reference's CPU path (oracle/: restatement of graphML.py:152-175 / :457-488 in torch / numpy) timed on this box's
                   host cores on a bounded sample of the same workload; rank 0, N = 1 only.
 """
@@ -173,6 +175,9 @@ def main():
     params = [p for p in w.module.parameters() if p.requires_grad]
     bucket = parallel.GradBucket(params) if distributed else None
 
+    ar_events = []                                                 # (start, end) HIP events around the all-reduce, filled only while ar_probe is on
+    ar_probe = [False]
+
     def step():
         if bucket is not None:
             bucket.zero_()
@@ -181,7 +186,14 @@ def main():
                 p.grad = None
         w.step_fwd_bwd()
         if bucket is not None:
-            bucket.allreduce_mean()
+            if ar_probe[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                bucket.allreduce_mean()
+                e1.record()
+                ar_events.append((e0, e1))
+            else:
+                bucket.allreduce_mean()
 
     def sync_all():
         if distributed:
@@ -215,15 +227,35 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    dist_info = None
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # the slowest rank defines the step time
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                               # per-rank wall time of the same K steps: a straggler shows up here
+        per_rank_ms = [1e3 * float(t.item()) / steps for t in every]
+        elapsed = max(float(t.item()) for t in every)              # the slowest rank defines the step time
+        dist_info = dict(backend=dist.get_backend(), rccl_ranks=dist.get_world_size(), ms_per_step_rank_min=min(per_rank_ms),
+                         ms_per_step_rank_max=max(per_rank_ms), ms_per_step_per_rank=[round(v, 4) for v in per_rank_ms])
     ms_per_step = 1e3 * elapsed / steps
     B = wl["B"]
     value = (B * world) * w.units / (elapsed / steps)
     per_step = timed_hip_events(step, max(20, min(steps, 50)))    # median of >= 20, HIP events
     ms_median = float(np.median(per_step))
+    if dist_info is not None and bucket is not None:
+        # the ONE collective of a step, timed with HIP events on the stream it is enqueued on (outside the timed region: 20 more steps):
+        # what it costs on the step's critical path once the backward's last kernel has finished (nothing overlaps it by construction)
+        ar_probe[0] = True
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        ar_probe[0] = False
+        ar_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ar_events)
+        t = torch.tensor([ar_ms[len(ar_ms) // 2], ar_ms[-1]], dtype=torch.float64, device=dev)
+        mx = t.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist_info.update(allreduce_ms_median_max_over_ranks=round(float(mx[0].item()), 4), allreduce_ms_worst=round(float(mx[1].item()), 4),
+                         allreduce_bytes=bucket.nbytes(), allreduce_share_of_step=round(float(mx[0].item()) / ms_per_step, 5),
+                         forced=bool(os.environ.get("GFHIP_FORCE_COLLECTIVES")))
 
     L = _lib.lib()
     roofline = ROOFLINES[wl["kind"]](L, w, wl)                      # every rank runs it: keeps the ranks in step
@@ -245,6 +277,8 @@ def main():
         out = dict(metric="edges*taps/sec (GraphFilter fwd+bwd)", value=value, unit="edges*taps/s", n_gpus=world, steps=steps,
                    warmup=warmup, ms_per_step=ms_per_step, ms_per_step_median=ms_median, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic", config=cfg, roofline=roofline, cpu_baseline=cpu)
+        if dist_info is not None:
+            out["distributed"] = dist_info
         if mfma is not None:
             out["mfma"] = mfma
         if detail:
@@ -288,12 +322,18 @@ def pmc_summary(workload, kernel, suffix="_pmc.json"):
     return pm, src
 
 
+TRAFFIC_KIND = ("fabric bytes per launch = reads + writes that LEAVE the XCDs' L2s (TCC_EA0 requests: FETCH_SIZE x 2 per the guide's gfx950 "
+                "correction + WRITE_SIZE); Infinity-Cache hits are counted, so this is L2-miss traffic, an upper bound on HBM traffic")
+
+
 def pmc_traffic(workload, kernel):
-    """(HBM bytes per launch, provenance): the bytes are reported only when the summary was taken on the kernel sources running now
-    (else null: a stale counter next to a live timing is worse than none)."""
+    """(fabric bytes per launch, provenance): the bytes are reported only when the summary was taken on the kernel sources running now
+    (else null: a stale counter next to a live timing is worse than none).  What the counters see is the memory side of the L2s --
+    Infinity-Cache hits included (MI355X_MICROARCH.md) -- so the number is L2-miss (fabric) traffic, not HBM traffic."""
     pm, src = pmc_summary(workload, kernel)
     if pm is None:
         return None, None
+    src["kind"] = TRAFFIC_KIND
     return (pm.get("hbm_bytes_per_launch") if src["matches_running_sources"] else None), src
 
 
@@ -327,8 +367,9 @@ def filter_hop_roofline(L, plans, name, B, N, W, K, nnz, dev):
         note = "one hop per launch, node-major rows gathered through L2 / Infinity Cache"
     nbytes = hops * hop_bytes(B, N, W, nnz)
     achieved = nbytes / (ms.value * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(name, kern)
     return dict(bound="hbm", kernel=kern, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name, kern)[0], traffic_source=pmc_traffic(name, kern)[1],
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                 algorithmic_bytes=nbytes, launch_ms=round(ms.value, 5), hops_per_launch=hops, pipeline=int(pipe), note=note)
 
 
@@ -390,9 +431,9 @@ def roofline_evgf(L, w, wl):
     tap = F * G * nnzp * 4 + 2 * state
     fwd = (F * G * N * 4 + B * G * N * 4 + state) + (K - 1) * tap + (K * state + B * F * N * 4)   # diag tap + edge taps + sum
     achieved = fwd / (ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(w.name, "ev_hop_lds4_kernel")
     return dict(bound="hbm", kernel="gf_evgf_forward (ev_diag + (K-1) x ev_hop_lds4_kernel + ev_sum)", achieved=round(achieved, 1),
-                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(w.name, "ev_hop_lds4_kernel")[0],
-                traffic_source=pmc_traffic(w.name, "ev_hop_lds4_kernel")[1],
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                 algorithmic_bytes=fwd, algorithmic_bytes_per_tap=tap, launch_ms=round(ms, 4), nnzp=nnzp,
                 note="whole forward timed with HIP events on the launch stream; per-kernel split: profiles/*cfg5*_kernel_stats.csv")
 
@@ -417,6 +458,7 @@ def cpu_filter(w, wl, sample):
     and the scipy CSR restatement (one core)."""
     from oracle import lsigf_oracle as orc
     ncores = os.cpu_count() or 1
+    threads_on_entry = torch.get_num_threads()               # (main() caps the threads per rank: put that back afterwards)
     wt, b = w.module.weight.detach().cpu(), w.module.bias.detach().cpu()
     N, K, B = wl["N"], wl["K"], wl["B"]
     xs = w.x.detach()[:min(B, max(2, sample))].cpu()
@@ -462,7 +504,7 @@ def cpu_filter(w, wl, sample):
     t0 = time.perf_counter()
     fn(xs[:n])
     dt = time.perf_counter() - t0
-    torch.set_num_threads(ncores)
+    torch.set_num_threads(threads_on_entry)
     return dict(value=n * w.nnz * K / dt, unit="edges*taps/s", cores=th, kind="port", variant=name, seconds=round(dt, 3), host_cores=ncores,
                 sample=f"fastest of {len(variants)} CPU variants of graphML.py:152-175 (fwd+bwd, fp32): {name}; {n} of the batch's {B} entries",
                 variants=variants)
@@ -474,6 +516,7 @@ def cpu_selgnn(w, wl, sample):
     small sample and the fastest is the one timed and reported."""
     from oracle import lsigf_oracle as orc
     ncores = os.cpu_count() or 1
+    threads_on_entry = torch.get_num_threads()
     sample = min(sample, wl["B"])
     S = torch.from_numpy(w.A.toarray().astype(np.float32))[None]
     nodes = [wl["N"]] + list(wl["sel"])
@@ -492,7 +535,7 @@ def cpu_selgnn(w, wl, sample):
     probes = {th: run(min(8, sample), th) for th in sorted({min(ncores, t) for t in (16, 64)} | {ncores})}
     th = min(probes, key=probes.get)
     dt = run(sample, th)
-    torch.set_num_threads(ncores)
+    torch.set_num_threads(threads_on_entry)
     return dict(cores=th, host_cores=ncores, kind="port", unit="edges*taps/s", value=sample * w.units / dt, seconds=round(dt, 3),
                 sample=f"the two GraphFilter layers in the literal dense form of graphML.py:152-175 + :2125-2144 (fwd+bwd, fp32), {sample} samples, "
                        f"{th} threads (fastest of {sorted(probes)})")
