@@ -12,6 +12,8 @@ Workloads = BASELINE.json configs (config.workload names the one that ran):
   cfg1            sourceLocGNN SelectionGNN: SBM N=100, F=[1,32,32], K=[5,5], MaxPoolLocal, MLP [5] (configs[0], examples/sourceLocGNN.py)
   cfg3            movieGNN SelectionGNN on a MovieLens-100k-sized graph: N=1682, kNN-10 weights, F=[1,64,32], K=[5,5], NoPool, MLP [1]
   cfg5            EdgeVariantGF (per-edge taps) SBM N=50k nnz~500k, K=3, 32->32, batch 16 (configs[4])
+  db              HiddenState_DB / GRNN_DB (per-sample, per-time-step GSOs with delays) at the flocking shape:
+                  B=20, T=100, N=50, 6 -> 32 features, K=3; a launch-bound recursion (T steps x ~15 launches), replayed as ONE HIP graph
 A step = one pass of the hot path over one batch resident in HBM: forward + backward (dx, dh, db) through the C ABI; for N > 1 plus the
 ONE bucketed RCCL all-reduce of the parameter gradients (batch-axis data parallelism, weak scaling: per-GPU batch fixed).
 value = B_global * sum_layers(nnz * K) / t_step, t_step from the barrier + synchronize bracket the harness prescribes; the median of
@@ -57,12 +59,27 @@ WORKLOADS = {
                  desc="movieGNN SelectionGNN on a MovieLens-100k-sized graph: N=1682 kNN-10 weights, F=[1,64,32], K=[5,5], NoPool, MLP [1], batch 256/GPU (BASELINE configs[2])"),
     "cfg5": dict(kind="evgf", graph="sbm", N=50_000, deg=10.0, B=16, G=32, F=32, K=3, steps=15, warmup=3, cpu_sample=2,
                  desc="EdgeVariantGF per-edge taps: SBM N=50k nnz~500k, K=3, F 32->32, batch 16/GPU (BASELINE configs[4])"),
+    "db": dict(kind="db", graph="flock", N=50, B=20, T=100, G=6, H=32, K=3, steps=30, warmup=5, cpu_sample=20, hip_graph=True,
+               desc="HiddenState_DB / GRNN_DB (graphML.py:1096-1290, 3395-3538) at the flocking example's shape: 50 agents, T=100 steps, a "
+                    "communication-radius GSO per (sample, step), 6 input features, 32 hidden, K=3, batch 20/GPU; fwd+bwd replayed as ONE HIP graph"),
     "tiny": dict(kind="filter", graph="sbm", N=1000, deg=10.0, B=32, G=32, F=32, K=5, steps=50, warmup=5, cpu_sample=8, desc="plumbing check"),
 }
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def flock_gsos(B, T, N, dev, seed=0):
+    """S [B,T,1,N,N]: agents on a random walk in the unit square, an edge where two agents are within the communication radius, each
+    operator divided by its largest degree (what the reference's flocking data set hands the _DB layers, dataTools.py: computeCommunicationGraph
+    with 'normalizeGraph') -- synthetic positions, the same shape and sparsity regime (~10 neighbours per agent)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    pos = torch.rand(B, 1, N, 2, generator=g) + 0.01 * torch.cumsum(torch.randn(B, T, N, 2, generator=g), dim=1)
+    d2 = ((pos[:, :, :, None, :] - pos[:, :, None, :, :]) ** 2).sum(-1)
+    A = ((d2 < 0.26 ** 2) & ~torch.eye(N, dtype=torch.bool)).float()
+    S = A / A.sum(-1).amax(-1).clamp(min=1.0)[..., None, None]
+    return S[:, :, None].contiguous().to(dev), float(A.sum() / (B * T))
 
 
 def make_graph(wl):
@@ -79,11 +96,22 @@ class Workload:
         from alegnn_amd.modules.architectures import SelectionGNN
         from alegnn_amd.utils import graphML as gml
         self.name, self.wl, self.dev = name, wl, dev
-        self.A = make_graph(wl)
-        self.nnz = int(self.A.nnz)
         N, B = wl["N"], wl["B"]
         torch.manual_seed(0)
         gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+        if wl["kind"] == "db":
+            T = wl["T"]
+            self.S, nnz = flock_gsos(B, T, N, dev, seed=rank)
+            self.A, self.nnz = None, int(round(nnz))            # average non-zeros of one (sample, step) operator
+            self.module = gml.HiddenState_DB(wl["G"], wl["H"], wl["K"], torch.tanh, 1, True).to(dev)
+            self.module.addGSO(self.S)
+            self.x = torch.randn(B, T, wl["G"], N, device=dev, generator=gen).requires_grad_(True)
+            self.z0 = torch.zeros(B, wl["H"], N, device=dev)
+            self.dy = torch.randn(B, T, wl["H"], N, device=dev, generator=gen)
+            self.units = 2 * T * self.nnz * wl["K"]            # two filters (A(S)x and B(S)z) per step, T steps per sample
+            return
+        self.A = make_graph(wl)
+        self.nnz = int(self.A.nnz)
         if wl["kind"] == "filter":
             self.module = gml.GraphFilter(wl["G"], wl["F"], wl["K"], 1, True)
             self.module.addGSO(self.A)
@@ -107,7 +135,9 @@ class Workload:
 
     def step_fwd_bwd(self):
         self.x.grad = None
-        if self.dy is not None:
+        if self.wl["kind"] == "db":
+            self.module(self.x, self.z0)[0].backward(self.dy)
+        elif self.dy is not None:
             self.module(self.x).backward(self.dy)
         else:
             self.module(self.x).square().sum().backward()          # the examples' losses need labels; any scalar loss drives the same path
@@ -270,7 +300,7 @@ def main():
 
     if rank == 0:
         cfg = dict(workload=args.workload, description=wl["desc"], graph=wl["graph"], N=wl["N"], nnz=w.nnz, batch_per_gpu=B,
-                   global_batch=B * world, K=wl["K"], E=1, parallelism=f"batch-dp{world}", grad_bucket_bytes=(bucket.nbytes() if bucket is not None else sum(p.numel() * 4 for p in params)),
+                   global_batch=B * world, K=wl["K"], E=1, **({"T": wl["T"], "H": wl["H"]} if "T" in wl else {}), parallelism=f"batch-dp{world}", grad_bucket_bytes=(bucket.nbytes() if bucket is not None else sum(p.numel() * 4 for p in params)),
                    rccl_ranks=(dist.get_world_size() if distributed else 0), hip_graph=use_graph,
                    devices=[torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())][:world])
         cfg.update({k: wl[k] for k in ("G", "F", "dimF", "sel", "pool", "alpha", "mlp") if k in wl})
@@ -438,7 +468,27 @@ def roofline_evgf(L, w, wl):
                 note="whole forward timed with HIP events on the launch stream; per-kernel split: profiles/*cfg5*_kernel_stats.csv")
 
 
-ROOFLINES = {"filter": roofline_filter, "selgnn": roofline_selgnn, "evgf": roofline_evgf}
+def roofline_db(L, w, wl):
+    """The per-(sample, step) hop of the delayed filter A(S)x (db_hop_kernel over all B*T operators in one launch): it reads every dense
+    N x N operator once.  At flocking sizes (N = 50: 10 KB per operator) the launch is ~10 us -- launch-bound, as is the whole
+    recursion (T steps x ~15 launches of a few microseconds); the roofline fraction is reported for completeness."""
+    from alegnn_amd import _lib
+    B, T, N = wl["B"], wl["T"], wl["N"]
+    W = 8                                                         # the 6 input features padded to 8 (16-byte rows)
+    X0 = torch.randn(B * T, N, W, device=w.dev)
+    X1 = torch.empty_like(X0)
+    st = torch.cuda.current_stream().cuda_stream
+    NN = N * N
+    call = lambda: _lib.check(L.gf_db_hop(w.S.data_ptr(), T * NN, NN, X0.data_ptr(), X1.data_ptr(), B, T, N, W, _lib.GF_OP_FWD, 1, st), "gf_db_hop")
+    ms = float(np.median(timed_hip_events(call, 30)[5:]))
+    nbytes = B * T * NN * 4 + 2 * B * T * N * W * 4
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="db_hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=None, traffic_source=None, algorithmic_bytes=nbytes, launch_ms=round(ms, 5),
+                note="one delayed hop of all B*T per-sample operators; launch-bound at this size (see the kernel stats under profiles/)")
+
+
+ROOFLINES = {"filter": roofline_filter, "selgnn": roofline_selgnn, "evgf": roofline_evgf, "db": roofline_db}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -561,7 +611,33 @@ def cpu_evgf(w, wl, sample):
                 sample=f"scipy restatement of graphML.py:457-488 with per-edge taps (forward + analytic backward, fp32), {sample} of the batch's {wl['B']} entries")
 
 
-CPU_BASELINES = {"filter": cpu_filter, "selgnn": cpu_selgnn, "evgf": cpu_evgf}
+def cpu_db(w, wl, sample):
+    """oracle/db_oracle.py's restatement of GRNN_DB (graphML.py:1096-1290) in CPU torch, forward + autograd backward, on `sample` of the
+    batch's samples (all T steps)."""
+    from oracle import db_oracle as dbo
+    ncores = os.cpu_count() or 1
+    threads_on_entry = torch.get_num_threads()
+    n = max(1, min(sample, wl["B"]))
+    m = w.module
+    a, b = m.aWeights.detach().cpu().requires_grad_(True), m.bWeights.detach().cpu().requires_grad_(True)
+    xb, zb = m.xBias.detach().cpu().requires_grad_(True), m.zBias.detach().cpu().requires_grad_(True)
+    S, x, z0, dy = w.S[:n].cpu(), w.x.detach()[:n].cpu().requires_grad_(True), w.z0[:n].cpu(), w.dy[:n].cpu()
+    best = None
+    for th in sorted({min(ncores, t) for t in (1, 8, 32)}):
+        torch.set_num_threads(th)
+        t0 = time.perf_counter()
+        dbo.grnn_db(a, b, S, x, z0, torch.tanh, xb, zb).backward(dy)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (th, dt)
+    torch.set_num_threads(threads_on_entry)
+    th, dt = best
+    return dict(value=n * w.units / dt, unit="edges*taps/s", cores=th, host_cores=ncores, kind="port", seconds=round(dt, 3),
+                sample=f"GRNN_DB restatement (oracle/db_oracle.py, CPU torch, fwd + autograd bwd), {n} of the batch's {wl['B']} samples, all {wl['T']} steps, "
+                       f"{th} threads (fastest of 1 / 8 / 32)")
+
+
+CPU_BASELINES = {"db": cpu_db, "filter": cpu_filter, "selgnn": cpu_selgnn, "evgf": cpu_evgf}
 
 
 def kernel_breakdown(L, w, wl):

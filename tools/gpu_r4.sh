@@ -73,4 +73,10 @@ h)  # prefetch lead x front width (waves per SIMD)
   done; done
   timeout 100 python tools/hop_probe.py cfg4 10 $V > $O/hop_er.log 2>&1; grep "spmm hop" $O/hop_er.log
   ;;
+db)  # the _DB family's bench line: graph replay vs eager launches, kernel stats of the eager step
+  timeout 300 python bench.py --workload db > $O/bench_db.json 2> $O/bench_db.err; tail -3 $O/bench_db.err; cat $O/bench_db.json
+  timeout 300 python bench.py --workload db --no-graph --no-cpu-baseline > $O/bench_db_eager.json 2> $O/bench_db_eager.err; tail -2 $O/bench_db_eager.err; cat $O/bench_db_eager.json | cut -c1-300
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -o db -- python $OLDPWD/bench.py --workload db --no-graph --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1)
+  f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_db_kernel_stats.csv && rm -rf $O/prof; python tools/show_stats.py $O | head -24
+  ;;
 esac
