@@ -16,6 +16,7 @@
 
 #include "gf_common.h"
 #include "gf_stream_image.h"
+#include "gf_sweep_image.h"
 
 // ---------------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -68,6 +69,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_tk")) g_tune.spmm_tk = value;
     else if (!strcmp(key, "spmm_nc")) g_tune.spmm_nc = value;
     else if (!strcmp(key, "spmm_spf")) g_tune.spmm_spf = value;
+    else if (!strcmp(key, "spmm_lag")) g_tune.spmm_lag = value;
     else if (!strcmp(key, "spmm_xcd")) g_tune.spmm_xcd = value;
     else if (!strcmp(key, "spmm_store")) g_tune.spmm_store = value;
     else if (!strcmp(key, "spmm_load")) g_tune.spmm_load = value;
@@ -471,6 +473,23 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
             }
         }
     }
+    // SWEEP image (gf_sweep_image.h): uniform GSOs on graphs whose gather panel does not fit L2, when the row lists balance
+    if (uni && n > kPanelMaxNodes && n <= kSweepMaxNodes) {
+        SweepImage sw = build_sweep_image(n, a.rowptr.data(), a.col.data());
+        const double fill = (double)sw.real_entries / ((double)sw.passes * kSweepWavesPerXcd * 2 * sw.steps);
+        d.sw_fill = fill;
+        if (fill >= 0.8 || (sw.steps <= 4 * kSweepBlock && fill >= 0.5)) {   // (short lists: the rounding to 64 steps is most of the padding)
+            d.sw_passes = sw.passes;
+            d.sw_steps = sw.steps;
+            GF_HIP(hipMalloc((void**)&d.sw_ent, sw.ent.size() * 4));
+            GF_HIP(hipMemcpy(d.sw_ent, sw.ent.data(), sw.ent.size() * 4, hipMemcpyHostToDevice));
+            GF_HIP(hipMalloc((void**)&d.sw_rows, sw.rows.size() * 4));
+            GF_HIP(hipMemcpy(d.sw_rows, sw.rows.data(), sw.rows.size() * 4, hipMemcpyHostToDevice));
+            GF_HIP(hipMalloc((void**)&d.sw_gate, 8 * 34 * 16 * 4));
+            GF_HIP(hipMemset(d.sw_gate, 0, 8 * 34 * 16 * 4));
+            bytes += (int64_t)(sw.ent.size() + sw.rows.size()) * 4;
+        }
+    }
     return upload_panel(n, a, d, bytes);
 }
 
@@ -706,6 +725,9 @@ void free_csr(gf_csr_dev& d) {
     if (d.st_last) (void)hipFree(d.st_last);
     if (d.st_rows) (void)hipFree(d.st_rows);
     if (d.st_ctr) (void)hipFree(d.st_ctr);
+    if (d.sw_ent) (void)hipFree(d.sw_ent);
+    if (d.sw_rows) (void)hipFree(d.sw_rows);
+    if (d.sw_gate) (void)hipFree(d.sw_gate);
     if (d.hub_kptr) (void)hipFree(d.hub_kptr);
     if (d.hub_ent) (void)hipFree(d.hub_ent);
     if (d.hub_col) (void)hipFree(d.hub_col);

@@ -745,6 +745,13 @@ extern "C" int gf_spmm_hop(const gf_plan* plan, int32_t op, const float* Xin, fl
     const bool fits24 = (int64_t)N < (1 << 24) && (int64_t)N * W < (int64_t)INT32_MAX;  // __umul24 offsets
     if (!g_tune.spmm_generic && fits24) {
         if (g_tune.spmm_algo == 2 && stream_applicable(m, N, B, W)) return launch_stream(m, Xin, Xout, N, B, st);
+        if (g_tune.spmm_algo == 4) {   // experiments: the sweep kernel or an error (never a silent fallback)
+            if (!gf_sweep_applicable(m, N, B, W)) {
+                gf_set_error("gf_spmm_hop: spmm_algo = 4 but the sweep kernel does not apply (W = %d, fill = %.3f, N = %d)", W, m.sw_fill, N);
+                return GF_ERR_UNSUPPORTED;
+            }
+            return gf_sweep_launch(m, Xin, Xout, N, B, st);
+        }
         if (g_tune.spmm_algo != 1) {
             switch (W) {
                 case 4: return launch_sell<1, 1>(m, Xin, Xout, N, B, st);

@@ -756,3 +756,29 @@ def test_stream_image_on_cpu(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_sweep_image_on_cpu(tmp_path):
+    """The SWEEP image (csrc/gf_sweep_image.h: per-half-wave entry lists sorted by source, slots = accumulator registers) is pure host
+    code: tools/sweep_image_check.cpp interprets it the way spmm_sweep_kernel executes it and compares bit for bit with the row sums in
+    ascending column order (graphML.py:158-161 per batch entry)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    exe = str(tmp_path / "sweep_image_check")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "graph-neural-networks_amd", "csrc"),
+                        os.path.join(ROOT, "tools", "sweep_image_check.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_sweep_kernel_register_map():
+    """spmm_sweep_kernel names its ring and accumulator registers by hand (v16-v23, v28-v127) inside inline asm: the compiler's own
+    instructions must stay below v16 and nothing may spill (tools/check_sweep_isa.py compiles gf_sweep.hip to ISA and checks)."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_sweep_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

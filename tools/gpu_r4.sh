@@ -79,4 +79,46 @@ db)  # the _DB family's bench line: graph replay vs eager launches, kernel stats
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -o db -- python $OLDPWD/bench.py --workload db --no-graph --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1)
   f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_db_kernel_stats.csv && rm -rf $O/prof; python tools/show_stats.py $O | head -24
   ;;
+swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
+  V="v:spmm_algo=3"; for l in 0 1; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
+  timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
+  for l in 1; do rm -rf $O/pm; timeout 100 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $O/pm -o pmc -- python tools/hop_probe.py cfg4 3 v:spmm_algo=4+spmm_lag=$l > $O/pm.log 2>&1
+  python3 - "$O" $l <<'PY'
+import csv, glob, sys, collections
+O, l = sys.argv[1:3]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"{O}/pm/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "spmm_sweep" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print(f"sweep barriers/entry={l}", {k: max(v) for k, v in sorted(agg.items())})
+PY
+  done; rm -rf $O/pm
+  ;;
+swrobust)  # the sweep kernel's LDS variant: repeated bitwise comparisons at several sizes
+  for a in "100000 5 128 spmm_lag=1" "100000 5 40" "60000 8 64 spmm_lag=1" "30000 9 24"; do timeout 100 python tools/sweep_debug.py $a 2>&1 | grep -a "mismatching"; done
+  for i in 1 2 3; do timeout 200 python -m pytest tests/test_gpu_sweep.py -x -q 2>&1 | tail -1; done
+  V="v:spmm_algo=3 v:spmm_algo=4+spmm_lag=0 v:spmm_algo=4+spmm_lag=1"
+  timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
+  ;;
+sw)  # first contact of the sweep kernel: parity, then ER / band timings against SELL-8, then hit rate
+  timeout 300 python -m pytest tests/test_gpu_sweep.py -x -q > $O/pytest_sweep.log 2>&1; tail -8 $O/pytest_sweep.log
+  V=${SWV:-"v:spmm_algo=3 v:spmm_algo=4+spmm_lag=0+spmm_sd=1 v:spmm_algo=4+spmm_lag=0+spmm_sd=0 v:spmm_algo=4+spmm_lag=4+spmm_sd=0"}
+  timeout 120 python tools/hop_probe.py cfg4 10 $V > $O/hop_er.log 2>&1; grep "spmm hop" $O/hop_er.log || tail -5 $O/hop_er.log
+  rm -rf $O/pm; timeout 100 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $O/pm -o pmc -- python tools/hop_probe.py cfg4 3 v:spmm_algo=3 v:spmm_algo=4+spmm_lag=${PMC_LAG:-16} > $O/pm.log 2>&1
+  python3 - "$O" <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"{O}/pm/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r["Kernel_Name"]
+        tag = "sweep" if "spmm_sweep" in kn else ("sell" if "spmm_sell" in kn else None)
+        if tag:
+            agg[(tag, r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (tag, k), v in sorted(agg.items()):
+    print(f"ER {tag:7s} {k:30s} max {max(v):16.0f} n={len(v)}")
+PY
+  rm -rf $O/pm
+  ;;
 esac
