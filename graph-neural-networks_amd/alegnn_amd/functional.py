@@ -166,24 +166,34 @@ class _LSIGFChainFunction(torch.autograd.Function):
         E = hs[0].shape[1]
         x = x.contiguous()
         dev = x.device
-        stacks = []
+        # The backward needs every layer's tap stack; a forward nobody differentiates (evaluation under no_grad, frozen inputs and
+        # parameters) needs only two at a time: layer l's and the one layer l writes its output into.
+        keep = any(ctx.needs_input_grad)
+        stacks = [None] * nl
+
+        def stack_of(l):
+            if stacks[l] is None:
+                _, _, K, G = hs[l].shape
+                stacks[l] = torch.empty((1 + E * (K - 1), B * G // 4, N, 4), dtype=torch.float32, device=dev)
+            return stacks[l]
+
         with torch.cuda.device(dev):
             plans = gso.plans(dev)
             st = torch.cuda.current_stream().cuda_stream
-            for l in range(nl):
-                F_, _, K, G = hs[l].shape
-                stacks.append(torch.empty((1 + E * (K - 1), B * G // 4, N, 4), dtype=torch.float32, device=dev))
             y = torch.empty((B, hs[-1].shape[0], N), dtype=torch.float32, device=dev)
             for l in range(nl):
                 F_, _, K, G = hs[l].shape
                 last = l == nl - 1
                 flags = (1 if (not last or relu_last) else 0) | (2 if l > 0 else 0) | (0 if last else 4)
-                out = y if last else stacks[l + 1]
-                _lib.check(L.gf_lsigf_forward_ex(plans, E, x.data_ptr() if l == 0 else None, hs[l].data_ptr(), _ptr(bs[l]), stacks[l].data_ptr(),
+                out = y if last else stack_of(l + 1)
+                _lib.check(L.gf_lsigf_forward_ex(plans, E, x.data_ptr() if l == 0 else None, hs[l].data_ptr(), _ptr(bs[l]), stack_of(l).data_ptr(),
                                                  out.data_ptr(), B, G, F_, K, N, flags, st), "gf_lsigf_forward_ex")
+                if not keep:
+                    stacks[l] = None                   # (stream-ordered allocator: the next layer's stack may reuse the block)
         ctx.gso, ctx.nl, ctx.relu_last, ctx.B, ctx.N, ctx.E = gso, nl, bool(relu_last), B, N, E
         ctx.has_bias = [b is not None for b in bs]
-        ctx.save_for_backward(y if relu_last else None, *hs, *stacks)
+        if keep:
+            ctx.save_for_backward(y if relu_last else None, *hs, *stacks)
         return y
 
     @staticmethod

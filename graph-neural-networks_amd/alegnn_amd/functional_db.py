@@ -226,6 +226,11 @@ def GRNN_DB(a, b, S, x, z0, sigma, xBias=None, zBias=None):
     assert z0.shape[0] == B and z0.shape[1] == H and z0.shape[2] == N                       # :1159-1161
     for name, t_ in (("a", a), ("b", b), ("S", S), ("x", x), ("z0", z0)):
         _require_f32_cuda(name, t_)
+    if S.requires_grad:
+        # the hidden-to-hidden recursion's step function does not differentiate with respect to the operator (no reference architecture
+        # trains S here: the flocking GSOs are data; edge gating goes through GatedGRNN): say so instead of returning a partial S.grad
+        raise NotImplementedError("GRNN_DB: S.requires_grad is not supported (the recursion B(S) z_{t-1} has no gradient with respect to S); "
+                                  "detach S, or use GatedGRNN for learnable edge gates")
     Ax = LSIGF_DB(a, S, x, xBias)                                                           # :1164   B x T x H x N
     Hp = _padded_width(H)
     bb, zb, zt = b, (None if zBias is None else zBias.reshape(H, 1)), z0

@@ -245,7 +245,10 @@ class SelectionGNN(nn.Module):
                     break
                 j += 3
             layers = [(f.weight, f.bias, f.fused_activation == "relu") for f in run]
-            if len(run) >= 2 and lsigf_chain_supported(run[0]._gso, x, layers):
+            # (the chain bypasses the inner modules' __call__: a run in which any of them carries a hook goes module by module)
+            inner = mods[i:i + 3 * (len(run) - 1) + 1]
+            hooked = any(q._forward_hooks or q._forward_pre_hooks or q._backward_hooks or getattr(q, "_backward_pre_hooks", None) for q in inner)
+            if len(run) >= 2 and not hooked and lsigf_chain_supported(run[0]._gso, x, layers):
                 x = LSIGF_chain(layers, run[0]._gso, x)
                 i += 3 * (len(run) - 1) + 1      # continue with the modules that follow the run's last filter (its FusedReLU is an identity)
             else:

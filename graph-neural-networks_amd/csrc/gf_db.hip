@@ -192,7 +192,8 @@ extern "C" int gf_db_grad_gso(const float* Xin, const float* dOut, float* dS, in
     int rc = check_db("gf_db_grad_gso", nb, nt, N, W);
     if (rc != GF_OK) return rc;
     const int tiles = (N + 31) / 32;
-    const size_t lds = sizeof(float) * 2 * 32 * (size_t)(W + 1);
+    const size_t lds = sizeof(float) * 2 * 32 * (size_t)(W + 1);   // 65 792 bytes at the widest supported W = 256: past the 64 KiB default
+    GF_HIP(gf_grant_lds((const void*)db_grad_gso_kernel, lds));
     hipLaunchKernelGGL(db_grad_gso_kernel, dim3((unsigned)(nb * nt), (unsigned)(tiles * tiles)), dim3(kT), lds, gf_stream(stream), Xin, dOut, dS,
                        s_stride_b, s_stride_t, nt, N, W, shift, accumulate);
     GF_LAUNCH_CHECK("db_grad_gso_kernel");
@@ -203,7 +204,8 @@ extern "C" int gf_stack_adjoint(const float* P0, const float* h, float* dZ, int6
     GF_REQUIRE_ARG(P0 && h && dZ, "gf_stack_adjoint: NULL argument");
     GF_REQUIRE_SHAPE(BN > 0 && G > 0 && F > 0 && E > 0 && K > 0 && G % 4 == 0, "gf_stack_adjoint: bad shape BN=%lld G=%d F=%d E=%d K=%d (G %% 4 == 0)",
                      (long long)BN, G, F, E, K);
-    GF_REQUIRE_SHAPE((size_t)F * G * 4 <= 64 * 1024, "gf_stack_adjoint: bank slice F*G = %d floats exceeds 64 KiB of LDS", F * G);
+    GF_REQUIRE_SHAPE((size_t)F * G * 4 <= 160 * 1024, "gf_stack_adjoint: bank slice F*G = %d floats exceeds 160 KiB of LDS", F * G);
+    GF_HIP(gf_grant_lds((const void*)stack_adjoint_kernel, sizeof(float) * (size_t)F * G));   // H = 256: 256 KB > LDS is refused above, 128 x 128 and 256 x 128 need the grant
     const int T = gf_num_taps(E, K);
     const int64_t items = BN * (G / 4);
     hipLaunchKernelGGL(stack_adjoint_kernel, dim3((unsigned)((items + kT - 1) / kT), (unsigned)T), dim3(kT), sizeof(float) * (size_t)F * G,

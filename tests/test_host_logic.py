@@ -782,3 +782,14 @@ def test_sweep_kernel_register_map():
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_sweep_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_asm_stores_never_read_mfma_results():
+    """The contraction / one-pass-backward kernels store through inline asm, which the compiler's hazard recogniser does not look into:
+    the XDL-write -> VMEM-read wait states are only guaranteed while every stored value passes through a compiler-visible VALU
+    instruction first.  tools/check_contract_isa.py compiles both files to ISA and checks the last writer of every asm store's data."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_contract_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
