@@ -86,9 +86,9 @@ struct gf_csr_dev {
     // SWEEP image (gf_sweep_image.h, round 4): the source sweep with register-resident partial sums (spmm_sweep_kernel); uniform GSOs,
     // N <= 131071, built when the row lists balance (fill >= 0.8: no hub rows)
     int32_t sw_passes = 0, sw_steps = 0;
-    uint2* sw_ent = nullptr;        // [sw_passes][512 waves][sw_steps + 8]  (entry of half A, entry of half B)
-    uint2* sw_rows = nullptr;       // [sw_passes][512 waves][100 slots]     (output byte offset of half A's row, of half B's row)
-    uint32_t* sw_gate = nullptr;    // [8 XCDs][64] progress gates
+    uint32_t* sw_ent = nullptr;     // [512 waves][sw_passes][sw_steps + 8]  entries (byte offset of the source row << 8 | slot)
+    uint32_t* sw_rows = nullptr;    // [512 waves][sw_passes][100 slots]     output byte offset of the slot's row
+    uint32_t* sw_gate = nullptr;    // [8 XCDs][34 x 16] barrier counters
     double sw_fill = 0.0;
     // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes.  Work unit = OCTET (8 consecutive rows = one 128-byte
     // line of a column panel); octets are sorted by their longest row and a slice = 8 octets = one wavefront (lane l handles
@@ -168,7 +168,7 @@ struct gf_tuning {
     int spmm_wps = 0;           // stream kernel: waves per SIMD, 0 = default, 4 | 6 | 8
     int spmm_tk = -1;           // stream kernel: run hand-out, -1 = default, 0 = static stride, 1 = vector atomic, 2 = scalar atomic
     int spmm_nc = 0;            // stream kernel: ticket counters per XCD, 0 = default, 1 .. 16
-    int spmm_lag = 0;           // sweep kernel: progress gates, 0 = none
+    int spmm_lag = 1;           // sweep kernel: XCD barriers per pass of an entry pair (>= 1)
     int spmm_spf = 0;           // stream image: prefetch runs for units whose new source rows are few, this many units ahead; 0 = none (set BEFORE gf_plan_create)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
     int spmm_ucap = 0;          // 0/16 = up to 16 gathers in flight per lane, 8 = up to 8 (fewer registers, more waves)

@@ -476,7 +476,7 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
     // SWEEP image (gf_sweep_image.h): uniform GSOs on graphs whose gather panel does not fit L2, when the row lists balance
     if (uni && n > kPanelMaxNodes && n <= kSweepMaxNodes) {
         SweepImage sw = build_sweep_image(n, a.rowptr.data(), a.col.data());
-        const double fill = (double)sw.real_entries / ((double)sw.passes * kSweepWavesPerXcd * 2 * sw.steps);
+        const double fill = (double)sw.real_entries / ((double)sw.passes * kSweepWavesPerXcd * sw.steps);
         d.sw_fill = fill;
         if (fill >= 0.8 || (sw.steps <= 4 * kSweepBlock && fill >= 0.5)) {   // (short lists: the rounding to 64 steps is most of the padding)
             d.sw_passes = sw.passes;

@@ -80,9 +80,9 @@ db)  # the _DB family's bench line: graph replay vs eager launches, kernel stats
   f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_db_kernel_stats.csv && rm -rf $O/prof; python tools/show_stats.py $O | head -24
   ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
-  V="v:spmm_algo=3"; for l in 0 1; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
+  V="v:spmm_algo=3"; for l in ${LAGS:-0 1 2 4}; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
   timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
-  for l in 1; do rm -rf $O/pm; timeout 100 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $O/pm -o pmc -- python tools/hop_probe.py cfg4 3 v:spmm_algo=4+spmm_lag=$l > $O/pm.log 2>&1
+  for l in ${PMLAGS:-1 4}; do rm -rf $O/pm; timeout 100 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $O/pm -o pmc -- python tools/hop_probe.py cfg4 3 v:spmm_algo=4+spmm_lag=$l > $O/pm.log 2>&1
   python3 - "$O" $l <<'PY'
 import csv, glob, sys, collections
 O, l = sys.argv[1:3]
@@ -96,8 +96,8 @@ PY
   done; rm -rf $O/pm
   ;;
 swrobust)  # the sweep kernel's LDS variant: repeated bitwise comparisons at several sizes
-  for a in "100000 5 128 spmm_lag=1" "100000 5 40" "60000 8 64 spmm_lag=1" "30000 9 24"; do timeout 100 python tools/sweep_debug.py $a 2>&1 | grep -a "mismatching"; done
-  for i in 1 2 3; do timeout 200 python -m pytest tests/test_gpu_sweep.py -x -q 2>&1 | tail -1; done
+  for a in "100000 5 128 spmm_lag=1" "100000 5 41 spmm_lag=0" "60000 8 64 spmm_lag=1" "30000 9 24"; do timeout 100 python tools/sweep_debug.py $a 2>&1 | grep -a "mismatching"; done
+  timeout 300 python -m pytest tests/test_gpu_sweep.py -x -q 2>&1 | tail -1
   V="v:spmm_algo=3 v:spmm_algo=4+spmm_lag=0 v:spmm_algo=4+spmm_lag=1"
   timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
   ;;

@@ -54,3 +54,11 @@ if len(rows):
                 print(f"   explained: neighbour {cc} was replaced by row {hit.tolist()}")
             # shifted-lane hypothesis: lane l got element 2l, or element l of another row
         print("   got/uval [0:8]", np.round((got[b, i] / 0.0625).cpu().numpy()[:8], 5).tolist())
+import ctypes
+ms = ctypes.c_float()
+out = torch.empty_like(X)
+for tag, kws in (("SELL-8", dict(spmm_algo=3)), ("sweep", dict(spmm_algo=4))):
+    for k, v in kws.items():
+        assert L.gf_tune(k.encode(), int(v)) == 0
+    _lib.check(L.gf_time_spmm_hop(plans[0], 0, X.data_ptr(), out.data_ptr(), B, 32, 10, st, ctypes.byref(ms)))
+    print(f"timing n={n} nnz={A.nnz} B={B}: {tag}: {ms.value:.4f} ms per hop")

@@ -37,7 +37,7 @@ static int check(int32_t n, double avg_deg, int hubs, uint32_t seed, int W) {
             a *= 0.37f;
             if (memcmp(&a, &Y[(size_t)i * W + w], 4) != 0) ++bad;
         }
-    const double fill = (double)im.real_entries / ((double)im.passes * kSweepWavesPerXcd * 2 * im.steps);
+    const double fill = (double)im.real_entries / ((double)im.passes * kSweepWavesPerXcd * im.steps);
     printf("n=%d deg=%.1f hubs=%d: passes=%d steps=%d fill=%.4f image=%.1f MB  %s\n", n, avg_deg, hubs, im.passes, im.steps, fill,
            (im.ent.size() + im.rows.size()) * 4 / 1e6, bad ? "MISMATCH" : "ok");
     return bad;
@@ -48,8 +48,8 @@ int main() {
     bad += check(1, 0.0, 0, 1, 2);
     bad += check(203, 6.0, 0, 2, 2);
     bad += check(4099, 10.0, 3, 3, 2);
-    bad += check(100000, 10.0, 0, 4, 1);      // config 4's shape: one pass, ~1000 steps
-    bad += check(131071, 6.0, 2, 5, 1);       // two passes
+    bad += check(100000, 10.0, 0, 4, 1);      // config 4's shape: two passes of ~1000 steps
+    bad += check(131071, 6.0, 2, 5, 1);       // three passes
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad != 0;
 }
