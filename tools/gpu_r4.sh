@@ -79,6 +79,28 @@ db)  # the _DB family's bench line: graph replay vs eager launches, kernel stats
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -o db -- python $OLDPWD/bench.py --workload db --no-graph --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1)
   f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_db_kernel_stats.csv && rm -rf $O/prof; python tools/show_stats.py $O | head -24
   ;;
+suite)   # the whole GPU suite as the driver runs it + smoke
+  unset GFHIP_EXPERIMENTS
+  timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+  ;;
+final)   # the round's numbers on the final sources: bench lines, kernel stats, PMC traffic of the dominant kernels
+  unset GFHIP_EXPERIMENTS
+  timeout 400 python bench.py > $O/bench_cfg4.json 2> $O/bench_cfg4.err; tail -2 $O/bench_cfg4.err; cut -c1-400 $O/bench_cfg4.json
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -o cfg4 -- python $OLDPWD/bench.py --no-cpu-baseline --steps 20 --warmup 3 > /dev/null 2>&1)
+  f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_cfg4_kernel_stats.csv; rm -rf $O/prof
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_collect.sh cfg4 spmm_sell_kernel r04 > $O/pmc_cfg4.log 2>&1; tail -1 $O/pmc_cfg4.log | cut -c1-500; cp gpurun_out/pmc_cfg4/r04_cfg4_pmc.json $O/ 2>/dev/null
+  for wl in cfg2 cfg3 cfg5 cfg1 db; do
+    timeout 300 python bench.py --workload $wl --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err; python -c "import json,sys; d=json.load(open('$O/bench_$wl.json')); print('$wl', round(d['ms_per_step'],4), 'ms/step', d['roofline']['kernel'][:40], d['roofline']['frac'])"
+  done
+  python tools/show_stats.py $O | head -12
+  ;;
+final2)  # PMC of the other workloads' dominant kernels + MFMA utilisation (source-hash tied)
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_collect.sh cfg2 spmm_chain_kernel r04 > $O/pmc_cfg2.log 2>&1; tail -1 $O/pmc_cfg2.log | cut -c1-300; cp gpurun_out/pmc_cfg2/r04_cfg2_pmc.json $O/ 2>/dev/null
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_mfma.sh cfg4 contract_mfma_kernel r04 > $O/mfma_cfg4.log 2>&1; tail -1 $O/mfma_cfg4.log | cut -c1-300
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_mfma.sh cfg4 bwd_fused_panel_kernel r04 > $O/mfma_cfg4b.log 2>&1; tail -1 $O/mfma_cfg4b.log | cut -c1-300
+  cp gpurun_out/pmc_mfma_*/r04_*_mfma_pmc.json $O/ 2>/dev/null; ls $O
+  ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
   V="v:spmm_algo=3"; for l in ${LAGS:-0 1 2 4}; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
   timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
