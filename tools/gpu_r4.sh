@@ -97,8 +97,7 @@ final)   # the round's numbers on the final sources: bench lines, kernel stats, 
   ;;
 final2)  # PMC of the other workloads' dominant kernels + MFMA utilisation (source-hash tied)
   GFHIP_EXPERIMENTS=1 bash tools/pmc_collect.sh cfg2 spmm_chain_kernel r04 > $O/pmc_cfg2.log 2>&1; tail -1 $O/pmc_cfg2.log | cut -c1-300; cp gpurun_out/pmc_cfg2/r04_cfg2_pmc.json $O/ 2>/dev/null
-  GFHIP_EXPERIMENTS=1 bash tools/pmc_mfma.sh cfg4 contract_mfma_kernel r04 > $O/mfma_cfg4.log 2>&1; tail -1 $O/mfma_cfg4.log | cut -c1-300
-  GFHIP_EXPERIMENTS=1 bash tools/pmc_mfma.sh cfg4 bwd_fused_panel_kernel r04 > $O/mfma_cfg4b.log 2>&1; tail -1 $O/mfma_cfg4b.log | cut -c1-300
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_mfma.sh cfg4 r04 > $O/mfma_cfg4.log 2>&1; tail -1 $O/mfma_cfg4.log | cut -c1-300
   cp gpurun_out/pmc_mfma_*/r04_*_mfma_pmc.json $O/ 2>/dev/null; ls $O
   ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
