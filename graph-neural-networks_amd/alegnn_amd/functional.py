@@ -149,8 +149,8 @@ _HANDOVER = os.environ.get("GFHIP_LAYER_HANDOVER", "1") != "0"
 
 
 class _LSIGFChainFunction(torch.autograd.Function):
-    """Consecutive ReLU graph-filter layers on ONE graph with the signals handed over in the internal column-panel layout
-    (gf_lsigf_forward_ex / gf_lsigf_backward_ex): layer l's contraction writes relu(y_l) straight into tap 0 of layer l+1's stack and,
+    """Consecutive ReLU graph-filter layers on ONE graph with the signals handed over in the internal layout -- column panels, or
+    node-major rows on graphs beyond the LDS panel limit -- (gf_lsigf_forward_ex / gf_lsigf_backward_ex): layer l's contraction writes relu(y_l) straight into tap 0 of layer l+1's stack and,
     in the backward, layer l+1 writes its dx -- masked by relu'(y_l) -- straight into tap 0 of layer l's adjoint stack.  Per inner
     boundary one reference-layout tensor, one pack pass forward and one backward disappear (the reference permutes at every layer,
     graphML.py:170-171; SelectionGNN strings the blocks together, architectures.py:286-294).  Arithmetic and summation orders are
@@ -236,21 +236,26 @@ class _LSIGFChainFunction(torch.autograd.Function):
 
 
 def lsigf_chain_supported(gso, x, layers):
-    """True when `layers` = [(h, b, relu), ...] (consecutive GraphFilter layers on `gso`) can hand their signals over in the panel
-    layout: every layer on the column-panel pipeline with per-feature bias, ReLU after every layer but possibly the last, Nin == N."""
+    """True when `layers` = [(h, b, relu), ...] (consecutive GraphFilter layers on `gso`) can hand their signals over in the internal
+    layout: every layer on the SAME pipeline (column panels, or node-major rows with widths that are multiples of 4) with per-feature
+    bias, ReLU after every layer but possibly the last, Nin == N."""
     if not _HANDOVER or len(layers) < 2 or x.dim() != 3 or x.device.type != "cuda" or x.shape[2] != gso.N:
         return False
     L = _lib.lib()
     plans = gso.plans(x.device)
+    pipes = set()
     for l, (h, b, relu) in enumerate(layers):
         F_, E, K, G = h.shape
         if E != gso.E or (b is not None and (b.dim() != 2 or b.shape[1] != 1)) or (l < len(layers) - 1 and not relu):
             return False
         if l > 0 and layers[l - 1][0].shape[0] != G:
             return False
-        if L.gf_lsigf_pipeline(plans, E, _padded_width(G), _padded_width(F_), K) != 2:
+        Gp, Fp = _padded_width(G), _padded_width(F_)
+        pipe = L.gf_lsigf_pipeline(plans, E, Gp, Fp, K)
+        if pipe not in (1, 2) or (pipe == 1 and (Gp % 4 or Fp % 4)):
             return False
-    return True
+        pipes.add(pipe)
+    return len(pipes) == 1
 
 
 def LSIGF_chain(layers, S, x):

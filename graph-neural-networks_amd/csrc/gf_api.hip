@@ -118,8 +118,9 @@ extern "C" int gf_time_khop_panel(const gf_plan* const* plans, int32_t E, int32_
     return rc;
 }
 
-// lx: layer-to-layer hand-over inside the panel pipeline (gf_lsigf_forward_ex / gf_lsigf_backward_ex): bit 1 = tap 0 of the stack already
-// holds the input as column panels (the previous call wrote it there: no pack pass), bit 2 = the result goes out as column panels.
+// lx: layer-to-layer hand-over in the internal layout (gf_lsigf_forward_ex / gf_lsigf_backward_ex): bit 1 = tap 0 of the stack already
+// holds the input in the pipeline's layout -- column panels, or node-major rows [B][N][G] on the node-major pipeline -- (the previous
+// call wrote it there: no pack / transpose pass), bit 2 = the result goes out in that layout.
 static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z,
                               float* y, int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, void* stream, int relu, int lx = 0) {
     GF_REQUIRE_ARG(plans && (x || (lx & 2)) && h && Z && y, "gf_lsigf_forward: NULL argument");
@@ -134,8 +135,12 @@ static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const floa
     }
     const int pipe = pick_pipeline(plans, E, G, F, K);
     if (pipe < 0) return pipe;
-    if ((lx & 6) && (pipe != 2 || Nin != N)) {
-        gf_set_error("gf_lsigf_forward_ex: the panel hand-over needs the column-panel pipeline and Nin == N (pipeline %d, Nin %d, N %d)", pipe, Nin, N);
+    if ((lx & 6) && Nin != N) {
+        gf_set_error("gf_lsigf_forward_ex: the hand-over in the internal layout needs Nin == N (Nin %d, N %d)", Nin, N);
+        return GF_ERR_UNSUPPORTED;
+    }
+    if ((lx & 6) && pipe != 2 && (G % 4 != 0 || F % 4 != 0)) {
+        gf_set_error("gf_lsigf_forward_ex: the hand-over of node-major rows needs widths that are multiples of 4 (G %d, F %d)", G, F);
         return GF_ERR_UNSUPPORTED;
     }
     if (pipe == 2) {
@@ -146,11 +151,12 @@ static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const floa
         return gf_contract_panel_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream),
                                         (lx & 4) ? 1 : 0, nullptr);
     }
-    int rc = gf_layout_bgn_to_bng(x, Z, B, G, Nin, N, stream);
+    int rc = (lx & 2) ? GF_OK : gf_layout_bgn_to_bng(x, Z, B, G, Nin, N, stream);
     if (rc != GF_OK) return rc;
     rc = gf_khop(plans, E, GF_OP_FWD, Z, B, G, K, stream);
     if (rc != GF_OK) return rc;
-    return gf_contract_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream));
+    return gf_contract_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream),
+                              (lx & 4) ? 1 : 0, nullptr);
 }
 
 static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const float* dy, const float* Z, const float* h, float* P,
@@ -168,8 +174,12 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
     }
     const int pipe = pick_pipeline(plans, E, G, F, K);
     if (pipe < 0) return pipe;
-    if ((lx & 6) && (pipe != 2 || Nin != N)) {
-        gf_set_error("gf_lsigf_backward_ex: the panel hand-over needs the column-panel pipeline and Nin == N (pipeline %d, Nin %d, N %d)", pipe, Nin, N);
+    if ((lx & 6) && Nin != N) {
+        gf_set_error("gf_lsigf_backward_ex: the hand-over in the internal layout needs Nin == N (Nin %d, N %d)", Nin, N);
+        return GF_ERR_UNSUPPORTED;
+    }
+    if ((lx & 6) && pipe != 2 && (G % 4 != 0 || F % 4 != 0)) {
+        gf_set_error("gf_lsigf_backward_ex: the hand-over of node-major rows needs widths that are multiples of 4 (G %d, F %d)", G, F);
         return GF_ERR_UNSUPPORTED;
     }
     if (pipe == 2) {
@@ -197,9 +207,12 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
         }
         return rc;
     }
-    int rc = y_relu ? gf_layout_masked_launch(dy, y_relu, P, B, F, Nin, N, gf_stream(stream))
-                    : gf_layout_bgn_to_bng(dy, P, B, F, Nin, N, stream);  // P[0] = dy, node-major, rows >= Nin zero
+    // P[0] = dy, node-major, rows >= Nin zero -- unless the next layer's backward already wrote it there (lx bit 1)
+    int rc = (lx & 2) ? GF_OK
+             : y_relu ? gf_layout_masked_launch(dy, y_relu, P, B, F, Nin, N, gf_stream(stream))
+                      : gf_layout_bgn_to_bng(dy, P, B, F, Nin, N, stream);
     if (rc != GF_OK) return rc;
+    const int dxr = (lx & 4) ? 1 : 0;
     if (dx && dh && g_tune.bwd_fuse && gf_bwd_fused_supported(G, F, E, K)) {
         // one pass over the adjoint stack for dx and dh (dh_t = X0^T P_t), as in the panel pipeline: the separate tap-gradient kernel
         // re-reads the whole forward stack (8.2 GB at config 4)
@@ -207,7 +220,7 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
         rc = gf_khop(plans, E, GF_OP_BWD, P, B, F, K, stream);
         if (rc != GF_OK) return rc;
         return gf_bwd_fused_panel_launch(P, Z, h, dx, dh, dbias, workspace, workspace_bytes, B, N, Nin, G, F, E, K, gf_stream(stream),
-                                         /*node_major=*/1);
+                                         /*node_major=*/1, dxr, dx_mask);
     }
     if (dh || dbias) {
         GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
@@ -217,7 +230,7 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
     if (dx) {
         rc = gf_khop(plans, E, GF_OP_BWD, P, B, F, K, stream);
         if (rc != GF_OK) return rc;
-        rc = gf_contract_launch(P, h, nullptr, dx, B, N, Nin, G, F, E, K, /*transpose_bank=*/1, gf_stream(stream));
+        rc = gf_contract_launch(P, h, nullptr, dx, B, N, Nin, G, F, E, K, /*transpose_bank=*/1, gf_stream(stream), dxr, dx_mask);
     }
     return rc;
 }
@@ -249,8 +262,8 @@ extern "C" int gf_lsigf_backward_relu(const gf_plan* const* plans, int32_t E, co
 }
 
 // Consecutive filter layers on the same graph (SelectionGNN with NoPool, architectures.py:286-294: GFL = [filter, sigma, rho, filter, ...])
-// hand their signals over in the internal column-panel layout: layer l's contraction writes sigma(y_l) straight into tap 0 of layer
-// l+1's stack (no reference-layout round trip: one unpack-transpose in the epilogue and one pack pass less per boundary), and in
+// hand their signals over in the internal layout (column panels, or node-major rows for graphs beyond the LDS panel limit): layer l's
+// contraction writes sigma(y_l) straight into tap 0 of layer l+1's stack (no reference-layout round trip: one unpack-transpose in the epilogue and one pack pass less per boundary), and in
 // the backward layer l+1 writes dx, masked by sigma'(y_l) = [tap 0 of its own stack > 0], straight into tap 0 of layer l's adjoint stack.
 extern "C" int gf_lsigf_forward_ex(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z, float* y,
                                    int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, int32_t flags, void* stream) {
@@ -263,6 +276,6 @@ extern "C" int gf_lsigf_backward_ex(const gf_plan* const* plans, int32_t E, cons
                                     int32_t F, int32_t K, int32_t Nin, int32_t flags, const float* dx_mask, void* stream) {
     GF_REQUIRE_ARG((flags & ~6) == 0, "gf_lsigf_backward_ex: flags = %d", flags);
     GF_REQUIRE_ARG(!(flags & 2) || y_relu == nullptr, "gf_lsigf_backward_ex: a handed-over gradient is already masked (y_relu must be NULL)");
-    GF_REQUIRE_ARG(dx_mask == nullptr || (flags & 4), "gf_lsigf_backward_ex: dx_mask is only defined for a panel dx");
+    GF_REQUIRE_ARG(dx_mask == nullptr || (flags & 4), "gf_lsigf_backward_ex: dx_mask is only defined for a dx in the internal layout");
     return lsigf_backward_impl(plans, E, dy, Z, h, P, dx, dh, dbias, workspace, workspace_bytes, B, G, F, K, Nin, stream, y_relu, flags & 6, dx_mask);
 }

@@ -200,7 +200,7 @@ extern gf_tuning g_tune;
 bool gf_sweep_applicable(const gf_csr_dev& m, int N, int B, int W);
 int gf_sweep_launch(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st);
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
-                       int F, int E, int K, int transpose_bank, hipStream_t st);
+                       int F, int E, int K, int transpose_bank, hipStream_t st, int out_rows = 0, const float* mask = nullptr);
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)
 bool gf_bwd_fused_supported(int G, int F, int E, int K);
 int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h, float* dx, float* dh, float* dbias, void* workspace,

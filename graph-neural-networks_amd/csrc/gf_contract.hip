@@ -95,7 +95,12 @@ template <int NT, int CIN8>
 __global__ __launch_bounds__(kThreads) void contract_mfma_kernel(const float* __restrict__ Z, BankView bank,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
                                                                  int B, int N, int Nout, int Cout, int T, int tilesPerB,
-                                                                 int64_t totalTiles) {
+                                                                 int64_t totalTiles, int out_rows, const float* __restrict__ mask) {
+    // out_rows = 1 (layer-to-layer hand-over on the node-major pipeline): the result is written as node-major rows out[b][n][0..Cout) --
+    // the layout of the NEXT layer's tap 0 (forward), or of the previous layer's adjoint tap 0 (transposed bank) -- instead of the
+    // reference layout [B, Cout, Nout].  A lane's register quad r = 4q .. 4q+3 is 4 consecutive outputs of its node: one 16-byte piece
+    // of the row; the two halves of the wave fill alternate pieces.  mask (rows of the same shape, nullable): entries whose mask value
+    // is <= 0 are written as 0 (the ReLU mask of the layer the gradient is handed to: its activation IS that tensor).
     constexpr int Cin = CIN8 * 8;
     constexpr int Cop = NT * 32;
     constexpr int ZS = Cin + 4;  // padded LDS row stride (floats)
@@ -166,7 +171,29 @@ __global__ __launch_bounds__(kThreads) void contract_mfma_kernel(const float* __
             __builtin_amdgcn_wave_barrier();  // all lanes' reads of zt issued before the next tap overwrites it
         }
 
-        if (n0 + l31 < Nout) {
+        if (out_rows) {
+            if (n0 + l31 < Nout) {
+                const int64_t row = ((int64_t)b * N + n0 + l31) * Cout;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int o = nt * 32 + 8 * q + 4 * half;   // outputs o .. o + 3
+                        if (o < Cout) {
+                            float4 v = make_float4(bank.act(acc[nt][4 * q]), bank.act(acc[nt][4 * q + 1]), bank.act(acc[nt][4 * q + 2]),
+                                                   bank.act(acc[nt][4 * q + 3]));
+                            if (mask != nullptr) {
+                                const float4 m = *reinterpret_cast<const float4*>(mask + row + o);
+                                v.x = m.x > 0.f ? v.x : 0.f;
+                                v.y = m.y > 0.f ? v.y : 0.f;
+                                v.z = m.z > 0.f ? v.z : 0.f;
+                                v.w = m.w > 0.f ? v.w : 0.f;
+                            }
+                            *reinterpret_cast<float4*>(out + row + o) = v;
+                        }
+                    }
+            }
+        } else if (n0 + l31 < Nout) {
             float* ob = out + (int64_t)b * Cout * Nout + n0 + l31;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -183,7 +210,8 @@ __global__ __launch_bounds__(kThreads) void contract_mfma_kernel(const float* __
 // does not tile (Cin not in {8,16,32,64,128}, Cout > 128, filter bank larger than LDS).
 __global__ __launch_bounds__(kThreads) void contract_generic_kernel(const float* __restrict__ Z, BankView bank,
                                                                     const float* __restrict__ bias, float* __restrict__ out,
-                                                                    int B, int N, int Nout, int Cin, int Cout, int T) {
+                                                                    int B, int N, int Nout, int Cin, int Cout, int T, int out_rows,
+                                                                    const float* __restrict__ mask) {
     const int64_t total = (int64_t)B * Cout * Nout;
     const int64_t tapStride = (int64_t)B * N * Cin;
     for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
@@ -194,7 +222,12 @@ __global__ __launch_bounds__(kThreads) void contract_generic_kernel(const float*
         float acc = bias ? bias[o] : 0.f;
         for (int t = 0; t < T; ++t)
             for (int ci = 0; ci < Cin; ++ci) acc = fmaf(zr[t * tapStride + ci], bank.at(t, ci, o), acc);
-        out[idx] = bank.act(acc);
+        if (out_rows) {   // node-major rows (see contract_mfma_kernel); Nout == N
+            const int64_t at = (b * N + n) * Cout + o;
+            out[at] = (mask != nullptr && !(mask[at] > 0.f)) ? 0.f : bank.act(acc);
+        } else {
+            out[idx] = bank.act(acc);
+        }
     }
 }
 
@@ -226,7 +259,7 @@ int resident_workgroups(Kern kern, size_t lds) {
 
 template <int NT, int CIN8>
 int launch_mfma(const float* Z, const BankView& bank, const float* bias, float* out, int B, int N, int Nout, int Cout, int T,
-                hipStream_t st) {
+                hipStream_t st, int out_rows, const float* mask) {
     constexpr int Cin = CIN8 * 8;
     const size_t lds = ((size_t)T * Cin * NT * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
     const int tilesPerB = (Nout + 31) / 32;
@@ -237,20 +270,20 @@ int launch_mfma(const float* Z, const BankView& bank, const float* bias, float* 
     auto kern = contract_mfma_kernel<NT, CIN8>;
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, st, Z, bank, bias, out, B, N, Nout, Cout, T,
-                       tilesPerB, totalTiles);
+                       tilesPerB, totalTiles, out_rows, mask);
     GF_LAUNCH_CHECK("contract_mfma_kernel");
     return GF_OK;
 }
 
 template <int NT>
 int dispatch_cin(int cin8, const float* Z, const BankView& bank, const float* bias, float* out, int B, int N, int Nout,
-                 int Cout, int T, hipStream_t st) {
+                 int Cout, int T, hipStream_t st, int out_rows, const float* mask) {
     switch (cin8) {
-        case 1: return launch_mfma<NT, 1>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
-        case 2: return launch_mfma<NT, 2>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
-        case 4: return launch_mfma<NT, 4>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
-        case 8: return launch_mfma<NT, 8>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
-        default: return launch_mfma<NT, 16>(Z, bank, bias, out, B, N, Nout, Cout, T, st);
+        case 1: return launch_mfma<NT, 1>(Z, bank, bias, out, B, N, Nout, Cout, T, st, out_rows, mask);
+        case 2: return launch_mfma<NT, 2>(Z, bank, bias, out, B, N, Nout, Cout, T, st, out_rows, mask);
+        case 4: return launch_mfma<NT, 4>(Z, bank, bias, out, B, N, Nout, Cout, T, st, out_rows, mask);
+        case 8: return launch_mfma<NT, 8>(Z, bank, bias, out, B, N, Nout, Cout, T, st, out_rows, mask);
+        default: return launch_mfma<NT, 16>(Z, bank, bias, out, B, N, Nout, Cout, T, st, out_rows, mask);
     }
 }
 
@@ -464,8 +497,11 @@ int unused_anchor_() { return 0; }
 }  // namespace
 
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G, int F,
-                       int E, int K, int transpose_bank, hipStream_t st) {
+                       int E, int K, int transpose_bank, hipStream_t st, int out_rows, const float* mask) {
     const int T = gf_num_taps(E, K);
+    GF_REQUIRE_SHAPE(!out_rows || (Nout == N && ((transpose_bank & 1) ? G : F) % 4 == 0),
+                     "gf_contract: node-major output rows need Nout == N and a width that is a multiple of 4 (Nout=%d N=%d)", Nout, N);
+    GF_REQUIRE_ARG(mask == nullptr || out_rows, "gf_contract: a mask is only defined for node-major output rows");
     const int Cin = (transpose_bank & 1) ? F : G, Cout = (transpose_bank & 1) ? G : F;
     BankView bank{h, E, K, G, F, (transpose_bank & 1) ? 1 : 0, (transpose_bank >> 1) & 1};  // bit 0: transposed bank, bit 1: ReLU epilogue
     static const int env_generic = getenv("GFHIP_CONTRACT_GENERIC") ? atoi(getenv("GFHIP_CONTRACT_GENERIC")) : 0;
@@ -476,15 +512,15 @@ int gf_contract_launch(const float* Z, const float* h, const float* bias, float*
     const size_t lds = ((size_t)T * Cin * nt * 32 + (size_t)kWaves * 32 * (Cin + 4)) * sizeof(float);
     if (!env_generic && cin_ok && Cout <= 128 && lds <= 160 * 1024) {
         switch (nt) {
-            case 1: return dispatch_cin<1>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st);
-            case 2: return dispatch_cin<2>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st);
-            default: return dispatch_cin<4>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st);
+            case 1: return dispatch_cin<1>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st, out_rows, mask);
+            case 2: return dispatch_cin<2>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st, out_rows, mask);
+            default: return dispatch_cin<4>(cin8, Z, bank, bias, out, B, N, Nout, Cout, T, st, out_rows, mask);
         }
     }
     const int64_t total = (int64_t)B * Cout * Nout;
     const int64_t want = (total + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(contract_generic_kernel, dim3((unsigned)(want < 65536 * 8 ? want : 65536 * 8)), dim3(kThreads), 0, st,
-                       Z, bank, bias, out, B, N, Nout, Cin, Cout, T);
+                       Z, bank, bias, out, B, N, Nout, Cin, Cout, T, out_rows, mask);
     GF_LAUNCH_CHECK("contract_generic_kernel");
     return GF_OK;
 }
@@ -496,5 +532,5 @@ extern "C" int gf_contract(const float* Z, const float* h, const float* bias, fl
                      "gf_contract: bad shape B=%d N=%d Nout=%d G=%d F=%d E=%d K=%d", B, N, Nout, G, F, E, K);
     GF_REQUIRE_ARG(transpose_bank == 0 || transpose_bank == 1, "gf_contract: transpose_bank = %d", transpose_bank);
     GF_REQUIRE_ARG(!(transpose_bank && bias), "gf_contract: bias is only defined for the forward bank");
-    return gf_contract_launch(Z, h, bias, out, B, N, Nout, G, F, E, K, transpose_bank, gf_stream(stream));
+    return gf_contract_launch(Z, h, bias, out, B, N, Nout, G, F, E, K, transpose_bank, gf_stream(stream), 0, nullptr);
 }

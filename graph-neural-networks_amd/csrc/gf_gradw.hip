@@ -382,8 +382,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
                                                                       float* __restrict__ partial, float* __restrict__ partial_b, int R,
                                                                       int N, int Nout, int B, int E, int K, int rowsPerWave, int dx_panels,
                                                                       const float* __restrict__ maskp, int Gtot, int numGI, int passes, int ctp) {
-    // dx_panels = 1 (layer-to-layer hand-over, panel stacks only): dx goes out as column panels dx[b * G/4 + g/4][n][g % 4], masked by
-    // maskp (nullable; the activation panels of the layer the gradient is handed to: entries <= 0 give 0) -- see contract_panel_kernel
+    // dx_panels = 1 (layer-to-layer hand-over): dx goes out in the layout of the stacks -- column panels dx[b * G/4 + g/4][n][g % 4], or
+    // (NM) node-major rows dx[b][n][g] -- masked by maskp (nullable; the activation of the layer the gradient is handed to, same layout:
+    // entries <= 0 give 0) -- see contract_panel_kernel / contract_mfma_kernel
     //
     // LDS operands are laid out for 16-BYTE READS: every MFMA of this kernel takes an A (or B) operand out of LDS, and with one
     // ds_read_b32 per MFMA issued one or two MFMAs ahead the 64-cycle MFMAs of a wave waited for the LDS round trip every second
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
                         for (int j = 0; j < 4; ++j) {
                             const int q = 2 * j + half;   // g = 4q .. 4q + 3
                             if (q < G / 4) {
-                                const int64_t at = (((int64_t)b * QG + q0 + q) * N + n) * 4;
+                                const int64_t at = NM ? ((int64_t)b * N + n) * Gtot + g0 + 4 * q : (((int64_t)b * QG + q0 + q) * N + n) * 4;
                                 f32x4 v = {acc_x[4 * j] * one, acc_x[4 * j + 1] * one, acc_x[4 * j + 2] * one, acc_x[4 * j + 3] * one};
                                 if (maskp) {
                                     const float4 m = *reinterpret_cast<const float4*>(maskp + at);
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
             for (int j = 0; j < 4; ++j) {
                 const int q = 2 * j + half;   // g = 4q .. 4q + 3
                 if (q < G / 4) {
-                    const int64_t at = (((int64_t)b * QG + q0 + q) * N + n) * 4;
+                    const int64_t at = NM ? ((int64_t)b * N + n) * Gtot + g0 + 4 * q : (((int64_t)b * QG + q0 + q) * N + n) * 4;
                     float4 v = make_float4(acc_x[4 * j], acc_x[4 * j + 1], acc_x[4 * j + 2], acc_x[4 * j + 3]);
                     if (maskp) {
                         const float4 m = *reinterpret_cast<const float4*>(maskp + at);
@@ -696,7 +697,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
                               size_t workspace_bytes, int B, int N, int Nout, int G, int F, int E, int K, hipStream_t st, int node_major,
                               int dx_panels, const float* maskp) {
     const Geo g = make_geo(B, N, G, F, E, K);
-    GF_REQUIRE_SHAPE(!dx_panels || (!node_major && Nout == N), "gf_lsigf_backward: panel hand-over of dx needs the panel pipeline and Nin == N");
+    GF_REQUIRE_SHAPE(!dx_panels || Nout == N, "gf_lsigf_backward: the hand-over of dx in the internal layout needs Nin == N");
     GF_REQUIRE_SHAPE(g.R < (int64_t)INT32_MAX - 4096, "gf_lsigf_backward: B*N = %lld too large", (long long)g.R);
     GF_REQUIRE_ARG(workspace && workspace_bytes >= g.bytes, "gf_lsigf_backward: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
     GF_REQUIRE_SHAPE(g.numFT == 1 && (G > 32 || (g.passes == 1 && g.ctp == g.T)), "gf_lsigf_backward: fused backward geometry");

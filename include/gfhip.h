@@ -228,13 +228,14 @@ int gf_lsigf_db_backward(const float* S, const float* dy, const float* Z, const 
                          int32_t F, int32_t E, int32_t K, int32_t N, int32_t shift, void* stream);
 
 /* ---- layer-to-layer hand-over in the internal layout (no reference counterpart: the reference permutes at every layer,
- * graphML.py:170-171; SelectionGNN strings [filter, sigma, rho] blocks together, architectures.py:286-294).  Column-panel pipeline
- * only (gf_lsigf_pipeline() == 2) and Nin == N, else GF_ERR_UNSUPPORTED.
+ * graphML.py:170-171; SelectionGNN strings [filter, sigma, rho] blocks together, architectures.py:286-294).  "Internal layout" = the
+ * layout of the pipeline gf_lsigf_pipeline() names for the layer: column panels [B*C/4][N][4] (2), or node-major rows [B][N][C] (1,
+ * widths that are multiples of 4); neighbouring layers must run the same pipeline.  Nin == N, else GF_ERR_UNSUPPORTED.
  *   flags bit 0 (forward): fused ReLU epilogue, as gf_lsigf_forward_relu
- *   flags bit 1: tap 0 of the stack (Z for forward, P for backward) ALREADY holds the input as column panels -- x / dy are ignored
- *                (NULL allowed): the neighbouring layer's call wrote it there
- *   flags bit 2: the result (y, resp. dx) is written as column panels [B*C/4][N][4] -- pass the neighbouring layer's tap 0;
- *                backward: masked by dx_mask (panels of the same shape, nullable; entries <= 0 give 0 = the ReLU of the layer below,
+ *   flags bit 1: tap 0 of the stack (Z for forward, P for backward) ALREADY holds the input in the internal layout -- x / dy are
+ *                ignored (NULL allowed): the neighbouring layer's call wrote it there
+ *   flags bit 2: the result (y, resp. dx) is written in the internal layout -- pass the neighbouring layer's tap 0;
+ *                backward: masked by dx_mask (same shape and layout, nullable; entries <= 0 give 0 = the ReLU of the layer below,
  *                whose activation is tap 0 of THIS layer's forward stack). */
 int gf_lsigf_forward_ex(const gf_plan* const* plans, int32_t E, const float* x, const float* h, const float* bias, float* Z, float* y,
                         int32_t B, int32_t G, int32_t F, int32_t K, int32_t Nin, int32_t flags, void* stream);

@@ -1256,10 +1256,14 @@ def test_training_step_is_hip_graph_capturable():
 # layer-to-layer hand-over in the internal layout (gf_lsigf_forward_ex / gf_lsigf_backward_ex)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dimF,K,N,B", [([1, 64, 32], [5, 5], 234, 5), ([3, 8, 16, 8], [3, 2, 4], 500, 7), ([32, 32, 32], [5, 5], 2000, 16),
-                                        ([2, 16, 8], [3, 3], 97, 3), ([2, 24, 40], [3, 3], 97, 3), ([8, 64, 32, 16], [3, 5, 2], 300, 4)])
+                                        ([2, 16, 8], [3, 3], 97, 3), ([2, 24, 40], [3, 3], 97, 3), ([8, 64, 32, 16], [3, 5, 2], 300, 4),
+                                        ([2, 16, 24], [3, 3], 97, 3),                       # panel layer + node-major layer: no hand-over
+                                        ([32, 32, 32], [5, 5], 12000, 3), ([3, 16, 64, 8], [3, 2, 4], 10500, 2),   # N > 10239: node-major rows
+                                        ([5, 40, 24, 132], [2, 3, 2], 301, 2)])            # widths without a panel / MFMA tiling
 def test_layer_handover_is_bitwise_the_separate_layers(dimF, K, N, B, monkeypatch):
-    """Runs of [GraphFilter, ReLU, NoPool] blocks keep their signals in the column-panel layout between layers: the same kernels do the
-    same arithmetic in the same order, only one reference-layout round trip per inner boundary is gone -- outputs, input gradient and
+    """Runs of [GraphFilter, ReLU, NoPool] blocks keep their signals in the internal layout between layers (column panels; node-major
+    rows when the layers run the node-major pipeline: N > 10239 or widths the panels do not tile): the same kernels do the same
+    arithmetic in the same order, only one reference-layout round trip per inner boundary is gone -- outputs, input gradient and
     every parameter gradient must be BITWISE those of the separate layers (which the golden tests pin to the reference)."""
     from alegnn_amd import functional
     A = graphgen.sbm(N, avg_degree=8.0, seed=3)
@@ -1278,8 +1282,10 @@ def test_layer_handover_is_bitwise_the_separate_layers(dimF, K, N, B, monkeypatc
         y, ygnn = net.splitForward(xr)
         (y * w).sum().backward()
         monkeypatch.setattr(functional._LSIGFChainFunction, "apply", orig)
-        chainable = all(w in (8, 16, 32, 64, 128) for w in (functional._padded_width(f) for f in dimF))   # widths of the panel pipeline
-        assert bool(calls) == (mode and chainable)                   # the chain really ran (or really did not)
+        pw = [functional._padded_width(f) for f in dimF]
+        panel = [N <= 10239 and g in (8, 16, 32, 64, 128) and f in (8, 16, 32, 64, 128) for g, f in zip(pw[:-1], pw[1:])]   # per layer
+        chainable = all(panel) or (not any(panel) and all(w % 4 == 0 for w in pw))   # one pipeline for the whole run
+        assert bool(calls) == (mode and chainable), (panel, pw)      # the chain really ran (or really did not)
         outs[mode] = [y.detach().clone(), ygnn.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in net.parameters()]
     for a, b_ in zip(outs[True], outs[False]):
         assert torch.equal(a, b_)
@@ -1291,6 +1297,8 @@ def test_handover_entry_points_refuse_what_they_cannot_do():
     gso = SparseGSO.from_any(A)
     plans = gso.plans(DEV)
     t = torch.zeros(16, device=DEV)
-    rc = L.gf_lsigf_forward_ex(plans, 1, t.data_ptr(), t.data_ptr(), None, t.data_ptr(), t.data_ptr(), 1, 8, 8, 2, 20000, 4, stream())
-    assert rc == -5 or rc != 0                                       # GF_ERR_UNSUPPORTED: no panel pipeline here
+    rc = L.gf_lsigf_forward_ex(plans, 1, t.data_ptr(), t.data_ptr(), None, t.data_ptr(), t.data_ptr(), 1, 8, 8, 2, 19999, 4, stream())
+    assert rc != 0                                                   # GF_ERR_UNSUPPORTED: a handed-over signal covers every node
     assert b"hand-over" in L.gf_last_error()
+    rc = L.gf_lsigf_forward_ex(plans, 1, t.data_ptr(), t.data_ptr(), None, t.data_ptr(), t.data_ptr(), 1, 6, 8, 2, 20000, 4, stream())
+    assert rc != 0 and b"multiples of 4" in L.gf_last_error()        # node-major rows are written 16 bytes at a time

@@ -100,6 +100,34 @@ final2)  # PMC of the other workloads' dominant kernels + MFMA utilisation (sour
   GFHIP_EXPERIMENTS=1 bash tools/pmc_mfma.sh cfg4 r04 > $O/mfma_cfg4.log 2>&1; tail -1 $O/mfma_cfg4.log | cut -c1-300
   cp gpurun_out/pmc_mfma_*/r04_*_mfma_pmc.json $O/ 2>/dev/null; ls $O
   ;;
+pw)      # config-3-class weighted panel hop: decomposition + LDS counters
+  timeout 200 python tools/panel_w_probe.py 1682 64 256 v:panel_np=1 v:panel_np=4 v:panel_rotate=0 v:panel_grid=512 v:panel_grid=256 > $O/probe.log 2>&1; cat $O/probe.log
+  timeout 100 python tools/panel_w_probe.py 1682 32 256 > $O/probe_w32.log 2>&1; grep -A1 "^weighted\|^equal" $O/probe_w32.log
+  for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+             "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VALU SQ_INSTS_SALU" \
+             "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+    rm -rf $O/pm; (export TMPDIR=/tmp PROBE_ONLY=1; timeout 100 rocprofv3 --pmc $grp --output-format csv -d $O/pm -o pmc -- python tools/panel_w_probe.py 1682 64 256 > $O/pm.log 2>&1 || echo "group failed: $grp")
+    python3 - "$O" <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"{O}/pm/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "spmm_panel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in sorted(agg.items()):
+    print(f"{k:42s} {sum(v)/len(v):18.0f}  ({len(v)} launches)")
+PY
+  done 2>&1 | tee $O/panel_counters.log
+  rm -rf $O/pm
+  ;;
+ho)      # node-major layer hand-over: bitwise tests + the step it saves at the config-4 class
+  timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "handover" > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+  timeout 300 python tools/handover_bench.py 100000 128 2 > $O/bench2.log 2>&1; tail -1 $O/bench2.log
+  timeout 300 python tools/handover_bench.py 100000 64 3 > $O/bench3.log 2>&1; tail -1 $O/bench3.log
+  ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
   V="v:spmm_algo=3"; for l in ${LAGS:-0 1 2 4}; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
   timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
