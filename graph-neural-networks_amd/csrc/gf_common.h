@@ -185,10 +185,16 @@ struct gf_tuning {
                                 // 2 = always, 0 = never (one launch per hop, gf_panel.hip)
     int panel_rotate = 1;       // 1 = each workgroup walks the slice list from its own starting offset
     int panel_grid = 0;         // experiments: cap on the panel kernel's grid (0 = one workgroup per LDS-full)
+    int bwd_fuse64 = 1;         // ... also for F = 64 (G <= 32): 0 = tap-gradient kernel + contraction, as in round 3
     int bwd_fuse = 1;           // panel pipeline backward: 1 = dx and dh from the adjoint stack in one kernel (G, F <= 32), 0 = separate
     int panel_split = 0;        // workgroups per pass when there are fewer passes than CUs: 0 = as many as fit (<= 8), 1 = off
     int panel_unit = 8;         // rows per work unit of the panel image: 8 | 4 | 2 (set BEFORE gf_plan_create)
     int panel_np = 0;           // panels per workgroup pass: 0 = heuristic (2 while two workgroups still fit a CU's LDS), 1, 2
+    int spmm_lanes = 0;         // experiments: batch tiles in flight in the SELL kernels (0 = one per XCD)
+    int panel_db = 1;           // the double-buffered per-hop kernel (spmm_panel_db_kernel): 1 = where one workgroup fills a CU's LDS
+                                // with its four panels (1280 <= N <= 2559), 2 = wherever four panels fit, 0 = never
+    int panel_thr = 0;          // experiments: threads of its workgroup (0 = 1024 when one workgroup fills a CU, else 512)
+    int panel_loaders = 0;      // experiments: its loader waves (0 = 2 of 16 waves, 1 of 8)
     int panel_even = 0;         // 1 = pad every slice to an even number of group-rows (set BEFORE gf_plan_create)
     int panel_sort = 1;         // 1 = octets sorted by their longest row (set BEFORE gf_plan_create)
     int evgf_idx16 = 1;         // EVGF: 16-bit node indices when N <= 65535 (half the index streams that share L2 with the gather panel)

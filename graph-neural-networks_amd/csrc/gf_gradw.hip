@@ -376,8 +376,11 @@ void launch_stage1_panel(const Geo& g, const float* Zp, const float* P0p, float*
 // NM = 1: the same pass over NODE-MAJOR stacks P[T][B][N][F], X0[B][N][G] (the pipeline of graphs beyond the LDS panel limit): a lane
 // still holds 4 consecutive f (g) of its row -- its four 16-byte loads per tap then come from one 128-byte row instead of four
 // panels, 32 bytes contiguous per pair of lanes; everything after the loads is identical.
+// F = 64 (FIN8 = 8; round 4: the 8 -> 64 first layers of config 3's class): the P tile is 64 columns wide, the contraction walks all 8
+// column groups and the tap gradients are kept for BOTH 32-wide f blocks (T x 2 accumulator tiles: 160 registers at T = 5 -- one
+// workgroup per CU, accumulators in AGPRs); G <= 32 only (a second g block would re-read the 64-wide P tiles).
 template <int T, int GIN8, int FIN8, int NM>
-__global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const float* __restrict__ Pp, const float* __restrict__ X0p,
+__global__ __launch_bounds__(kThreads, (FIN8 > 4 ? 1 : 2)) void bwd_fused_panel_kernel(const float* __restrict__ Pp, const float* __restrict__ X0p,
                                                                       const float* __restrict__ h, float* __restrict__ dx,
                                                                       float* __restrict__ partial, float* __restrict__ partial_b, int R,
                                                                       int N, int Nout, int B, int E, int K, int rowsPerWave, int dx_panels,
@@ -394,12 +397,14 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
     // Gtot > 32 (64, 128: the widths of config 3's layers): blockIdx.y = one 32-wide block of the input features g -- its own X0 columns,
     // bank rows, dx columns and tap-gradient tiles; the P tiles are read once per block.
     constexpr int G = GIN8 * 8, F = FIN8 * 8, QF = F / 4;
+    constexpr int FB = FIN8 > 4 ? FIN8 / 4 : 1;   // 32-wide f blocks of the tap gradients
     const int gblk = blockIdx.y, g0 = gblk * 32, QG = Gtot / 4, q0 = gblk * 8;
     constexpr int TS = 36;      // row stride of the transposed tiles (floats): 16-byte aligned, 36/4 odd -> conflict-free 16-byte reads
     constexpr int FS = F + 4;   // row stride of the bank (same rule: (F + 4) / 4 is odd for F = 8, 16, 32)
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     float* s_w = s_dyn;                                   // Hm[t][g][f], g padded to 32: T * 32 * FS floats
-    float (*s_t)[2][32 * TS] = reinterpret_cast<float (*)[2][32 * TS]>(s_dyn + T * 32 * FS);   // per wave: X0 tile, P tile (transposed)
+    constexpr int WT = (1 + FB) * 32 * TS;               // per wave: X0 tile [32 columns][TS], P tile [32 FB columns][TS] (transposed)
+    float* s_tiles = s_dyn + T * 32 * FS;
     const int tid = threadIdx.x;
     for (int idx = tid; idx < T * 32 * F; idx += kThreads) {
         const int f = idx % F, g = (idx / F) & 31, t = idx / (F * 32);
@@ -424,8 +429,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
     const int64_t tapStride = (int64_t)B * QF * N4;     // floats per tap (either layout: B * N * F)
     const int64_t pstep = NM ? 8 : 2 * N4;              // from one 8-column group of a row to the next: +8 floats | +2 panels
     const int64_t xstep = NM ? 8 : 2 * N4;
-    float* xs = s_t[wave][0];
-    float* ps = s_t[wave][1];
+    float* xs = s_tiles + wave * WT;
+    float* ps = xs + 32 * TS;
     // write side of a tile: this lane holds row l31, columns 8u + 4 half + (0..3); read side: column l31, rows 2s + half, s = 0..15
     const int wpos = (l31 & 1) * 16 + (l31 >> 1) + 4 * half * TS;   // + (8u + j) * TS
     const int rpos = l31 * TS + 16 * half;                          // 16 consecutive floats
@@ -437,19 +442,21 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
         q[3 * TS] = v.w;
     };
 
-    f32x16 acc_h[T];
+    f32x16 acc_h[T * FB];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < T * FB; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_h[t][r] = 0.f;
-    float bsum = 0.f;
+    float bsum[FB];
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) bsum[fb] = 0.f;
 
     // ---- the operand stream of a strip: per tile the X0 tile and the T tap tiles, element e of tile i in ring slot (i (T + 1) + e) % 3.
     // TWO elements are in flight while one is consumed, across tile boundaries (one tap ahead left 32 KB per CU on the way: at the
     // loaded HBM latency that is 4.3 TB/s, and every tap ended in a wait).  The slot numbers are compile-time when 3 divides T + 1
     // (T = 5: the K = 5 filters of the configurations; T = 2); the other tap counts keep the one-ahead schedule below.
     // (Node-major stacks only: on column panels the same schedule measured 2 % slower than one-ahead, tools/ab_same_box.sh.)
-    constexpr bool kDeep = (T + 1) % 3 == 0 && NM == 1;
+    constexpr bool kDeep = (T + 1) % 3 == 0 && NM == 1 && FB == 1;
     constexpr int MAXW = GIN8 > FIN8 ? GIN8 : FIN8;
     if constexpr (kDeep) {
         f32x4 slot[3][MAXW];
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
                     const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + rpos + 4 * q);
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        if (t == 0) bsum += pv[s];
+                        if (t == 0) bsum[0] += pv[s];
                         acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], pv[s], acc_h[t], 0, 0, 0);
                     }
                 }
@@ -613,11 +620,14 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(xs + rpos + 4 * q);
-                const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + rpos + 4 * q);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if (t == 0) bsum += pv[s];
-                    acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], pv[s], acc_h[t], 0, 0, 0);
+                for (int fb = 0; fb < FB; ++fb) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + fb * 32 * TS + rpos + 4 * q);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if (t == 0) bsum[fb] += pv[s];
+                        acc_h[t * FB + fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], pv[s], acc_h[t * FB + fb], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -651,18 +661,25 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_fused_panel_kernel(const floa
     }
 
     // tap-gradient tile (t, gblk) is tile ct = t * numGI + gblk of the shared partial layout [wave][pass][ctp] (make_geo; one pass when Gtot <= 32)
+    // (pass = c-pass * numFT + f block, as grad_taps_kernel numbers them; FB = 2 runs with numGI = 1: one c-pass)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int ct = t * numGI + gblk;
-        float* pt = partial + (((int64_t)wg * passes + ct / ctp) * ctp + ct % ctp) * 1024;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
-            pt[g * 32 + l31] = acc_h[t][i];
+        for (int fb = 0; fb < FB; ++fb) {
+            float* pt = partial + (((int64_t)wg * passes + (ct / ctp) * FB + fb) * ctp + ct % ctp) * 1024;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
+                pt[g * 32 + l31] = acc_h[t * FB + fb][i];
+            }
         }
     }
-    const float other = __shfl_xor(bsum, 32, 64);
-    if (half == 0 && gblk == 0) partial_b[(int64_t)wg * 32 + l31] = bsum + other;  // even rows + odd rows
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) {
+        const float other = __shfl_xor(bsum[fb], 32, 64);
+        if (half == 0 && gblk == 0) partial_b[((int64_t)wg * FB + fb) * 32 + l31] = bsum[fb] + other;  // even rows + odd rows
+    }
 }
 
 int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, int E, int K, hipStream_t st) {
@@ -689,7 +706,8 @@ int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, 
 bool gf_bwd_fused_supported(int G, int F, int E, int K) {
     const int T = gf_num_taps(E, K);
     auto ok = [](int w) { return w == 8 || w == 16 || w == 32; };
-    // G = 64, 128: one 32-wide block of g per blockIdx.y.  (F > 32 would need the tap gradients of two f blocks in one wave's registers.)
+    // G = 64, 128: one 32-wide block of g per blockIdx.y.  F = 64: the tap gradients of two f blocks in one wave's registers (G <= 32).
+    if (F == 64) return ok(G) && T >= 1 && T <= 6 && g_tune.bwd_fuse64 != 0;
     return (ok(G) || G == 64 || G == 128) && ok(F) && T >= 1 && T <= 6;  // 16 accumulator registers per tap: T = 7, 8 need > 256 VGPRs
 }
 
@@ -700,9 +718,10 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
     GF_REQUIRE_SHAPE(!dx_panels || Nout == N, "gf_lsigf_backward: the hand-over of dx in the internal layout needs Nin == N");
     GF_REQUIRE_SHAPE(g.R < (int64_t)INT32_MAX - 4096, "gf_lsigf_backward: B*N = %lld too large", (long long)g.R);
     GF_REQUIRE_ARG(workspace && workspace_bytes >= g.bytes, "gf_lsigf_backward: workspace %zu bytes < required %zu", workspace_bytes, g.bytes);
-    GF_REQUIRE_SHAPE(g.numFT == 1 && (G > 32 || (g.passes == 1 && g.ctp == g.T)), "gf_lsigf_backward: fused backward geometry");
+    GF_REQUIRE_SHAPE((g.numFT == 1 && (G > 32 || (g.passes == 1 && g.ctp == g.T))) || (F == 64 && G <= 32 && g.passes == 2 && g.ctp == g.T),
+                     "gf_lsigf_backward: fused backward geometry");
     float* ws = (float*)workspace;
-    const size_t lds = ((size_t)g.T * 32 * (F + 4) + (size_t)kWaves * 2 * 32 * 36) * sizeof(float);  // bank [t][g][F + 4] + wave tiles (TS = 36)
+    const size_t lds = ((size_t)g.T * 32 * (F + 4) + (size_t)kWaves * (1 + (F > 32 ? F / 32 : 1)) * 32 * 36) * sizeof(float);  // bank [t][g][F + 4] + wave tiles (TS = 36)
     hipError_t attr = hipSuccess;
 #define GF_BF(TT, GG, FF)                                                                                                      \
     do {                                                                                                                        \
@@ -711,10 +730,17 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
         hipLaunchKernelGGL(kern, dim3(g.strips, g.numGI), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
                            Nout, B, E, K, g.rowsPerWave, dx_panels, maskp, G, g.numGI, g.passes, g.ctp);                        \
     } while (0)
+#define GF_BF64(TT, GG)                                                                                                         \
+    do {                                                                                                                        \
+        if constexpr ((TT) <= 6) {                                                                                              \
+            GF_BF((TT) <= 6 ? (TT) : 1, GG, 8);                                                                                 \
+        }                                                                                                                       \
+    } while (0)
 #define GF_BF_F(TT, GG)                                                                                                         \
     switch (F / 8) {                                                                                                            \
         case 1: GF_BF(TT, GG, 1); break;                                                                                        \
         case 2: GF_BF(TT, GG, 2); break;                                                                                        \
+        case 8: GF_BF64(TT, GG); break;                                                                                         \
         default: GF_BF(TT, GG, 4); break;                                                                                       \
     }
 #define GF_BF_G(TT)                                                                                                             \
@@ -736,6 +762,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
     GF_HIP(attr);
 #undef GF_BF_G
 #undef GF_BF_F
+#undef GF_BF64
 #undef GF_BF
     GF_LAUNCH_CHECK("bwd_fused_panel_kernel");
     return finish_taps(g, ws, dh, dbias, G, F, E, K, st);

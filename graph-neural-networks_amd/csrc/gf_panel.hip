@@ -34,7 +34,13 @@
 
 namespace {
 
-constexpr int kGC = 2;   // entry groups (of 4 neighbours) per lane gathered per round
+#ifndef GF_PANEL_KGC
+#define GF_PANEL_KGC 2
+#endif
+#ifndef GF_PANEL_BATCH
+#define GF_PANEL_BATCH 0
+#endif
+constexpr int kGC = GF_PANEL_KGC;   // entry groups (of 4 neighbours) per lane gathered per round
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -214,6 +220,202 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     }
 }
 
+// ---- double-buffered variant (round 4): the load of the NEXT pass's panels runs under the gathers of the current one ----------------
+// spmm_panel_kernel alternates a load phase (HBM-bound) and a gather phase (LDS-bound) per workgroup and relies on the two or three
+// workgroups of a CU being in different phases.  Measured at N = 1682 (config 3: weighted kNN, width 64, tools/panel_w_probe.py): load +
+// store skeleton alone 35 us per hop, LDS busy 30 us per hop (SQ_LDS_IDX_ACTIVE; a third of it bank conflicts, which is what random
+// columns cost with 16 lanes per service group), the hop 65 us: the phases add up instead of overlapping.  Here ONE workgroup owns two
+// buffers of NP panels: loader waves fetch pass i + 1 with LDS-DMA (no registers, and their vmcnt queue holds nothing else) while the
+// gather waves work on pass i and store its results from registers; one LDS-only barrier per pass (stores stay in flight across it).
+// Slices are CLAIMED from an LDS counter in the plan's order (longest first): waves that finish early take the next slice instead of
+// waiting at the barrier for the wave that drew the long ones.  Columns come from the 16-bit stream for weighted and equal-weight
+// GSOs alike (the buffer base is folded into the shift: v_lshl_add_u32), so the equal-weight stream is half the per-hop kernel's.
+// Arithmetic per row is the per-hop kernel's: same ELL image, same two accumulators, same order -- bitwise the same results.
+template <int UNIFORM, int NP>
+__global__ __launch_bounds__(1024) void spmm_panel_db_kernel(const int2* __restrict__ slice, const int32_t* __restrict__ octs,
+                                                             const uint2* __restrict__ cols, const float4* __restrict__ vals, float uval,
+                                                             const float* __restrict__ Xin, float* __restrict__ Xout, int N, int nSlices,
+                                                             int nPanels, int sentinel, int store_mode, int ush, int nLoaders) {
+    extern __shared__ __attribute__((aligned(16))) float4 panel[];  // [2 buffers][NP regions][N + 1] float4, then two claim counters
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nW = (int)(blockDim.x >> 6), Wg = nW - nLoaders;
+    const bool gatherer = wave < Wg;
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // the panels start at LDS address 0 (absolute ds_read addresses)
+    f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
+    const int region4 = N + 1;
+    const unsigned regionB = (unsigned)region4 * 16u, bufB = NP * regionB;
+    unsigned* ctr = reinterpret_cast<unsigned*>(lds4 + 2 * NP * region4);
+    const int64_t pstride = (int64_t)N * 4;
+    const int nGroups = (nPanels + NP - 1) / NP;
+    const int nChunks = (N + 63) >> 6;
+    int p = (int)blockIdx.x;
+    if (p >= nGroups) return;
+    if (tid < 2 * NP) lds4[tid * region4 + N] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (tid == 0) ctr[0] = ctr[1] = 0u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    // the panels of pass `pass` into buffer `buf`, 64-row chunks w, w + nw, ... (LDS-DMA: 1 KiB per instruction at a wave-uniform base)
+    auto dma_pass = [&](int pass, int buf, int w, int nw) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (pass * NP + k >= nPanels) break;
+            const f32x4* src = reinterpret_cast<const f32x4*>(Xin + ((int64_t)pass * NP + k) * pstride);
+            const unsigned base = (unsigned)buf * bufB + k * regionB;
+            for (int c = w; c < nChunks; c += nw) {
+                const int row0 = c * 64;
+                if (row0 + lane < N) __builtin_amdgcn_global_load_lds(src + row0 + lane, (lds_void*)(uintptr_t)(base + (unsigned)row0 * 16u), 16, 0, 0);
+            }
+        }
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // (the waits on the DMA go through the builtin: the compiler's wait-count pass tracks LDS-DMA as "may write any LDS address" and,
+    //  not seeing a wait it understands, would put vmcnt(0) in front of every ds_read of the gather loop -- i.e. behind the entry
+    //  loads it has just issued for the NEXT chunk)
+    constexpr int kWaitVm0 = 0x0F70;   // s_waitcnt vmcnt(0), gfx9 encoding (expcnt / lgkmcnt fields at their maxima)
+    dma_pass(p, 0, wave, nW);
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);
+    __syncthreads();
+
+    const uint2* col2 = cols + lane;
+    const f32x4* val4 = reinterpret_cast<const f32x4*>(vals) + lane;
+    auto load_chunk = [&](uint2 (&cc)[kGC], f32x4 (&vv)[kGC], int g0) {
+#pragma unroll
+        for (int g = 0; g < kGC; ++g) {
+            cc[g] = col2[(int64_t)(g0 + g) * 64];
+            if (!UNIFORM) vv[g] = val4[(int64_t)(g0 + g) * 64];
+        }
+    };
+    int cur = 0;
+    for (;;) {
+        const int pn = p + (int)gridDim.x;
+        if (!gatherer) {
+            if (pn < nGroups) dma_pass(pn, cur ^ 1, wave - Wg, nLoaders);
+            if (wave == Wg && lane == 0) ctr[cur ^ 1] = 0u;   // last used in the previous pass, which ended at the barrier
+            __builtin_amdgcn_s_waitcnt(kWaitVm0);   // the next pass's panels have landed before the barrier lets anyone read them
+        } else {
+            // a ticket = the counter before lane 0's increment.  Through inline asm: the compiler brackets a workgroup-scope atomic with
+            // vmcnt(0) -- a full round trip of the entry loads and of the result stores in flight, at every slice boundary.  (One lane
+            // only: 64 lanes adding to one word are 64 serialised LDS atomics, 5 us per pass.)
+            const unsigned ctr_addr = (unsigned)(2 * NP * region4) * 16u + (unsigned)cur * 4u;
+            auto claim = [&]() -> int {
+                unsigned v = 0;
+                if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ctr_addr), "v"(1u) : "memory");
+                return __builtin_amdgcn_readfirstlane((int)v);
+            };
+            int s = claim();
+            if (s < nSlices) {
+                float* outp = Xout + (int64_t)p * NP * pstride;
+                const int nvalid = min(NP, nPanels - p * NP);
+                const unsigned bbase = (unsigned)cur * bufB;
+                int2 si = slice[s];
+                int oc = octs[(s << (6 - ush)) + (lane >> ush)];
+                int sn = claim();
+                int2 sin = make_int2(sentinel, 0);
+                int ocn = -1;
+                if (sn < nSlices) {
+                    sin = slice[sn];
+                    ocn = octs[(sn << (6 - ush)) + (lane >> ush)];
+                }
+                int j0 = 0;
+                f32x4 acc0[NP], acc1[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) acc0[k] = acc1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                uint2 cA[kGC], cB[kGC];
+                f32x4 vA[kGC], vB[kGC];
+                load_chunk(cA, vA, si.y > 0 ? si.x : sentinel);
+                auto process = [&](uint2 (&cc)[kGC], f32x4 (&vv)[kGC], uint2 (&cn)[kGC], f32x4 (&vn)[kGC]) -> bool {
+                    const bool same = (j0 + kGC) < si.y;
+                    const int gnext = same ? si.x + j0 + kGC : (sin.y > 0 ? sin.x : sentinel);
+                    load_chunk(cn, vn, gnext);
+#pragma unroll
+                    for (int g = 0; g < kGC; ++g) {
+                        if (g > 0 && j0 + g >= si.y) break;
+                        typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+#if GF_PANEL_BATCH
+                        f32x4 xx[NP][4];
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) {
+                            const unsigned rb = bbase + k * regionB;
+                            xx[k][0] = *reinterpret_cast<lds_f32x4*>(((cc[g].x & 0xffffu) << 4) + rb);
+                            xx[k][1] = *reinterpret_cast<lds_f32x4*>(((cc[g].x >> 16) << 4) + rb);
+                            xx[k][2] = *reinterpret_cast<lds_f32x4*>(((cc[g].y & 0xffffu) << 4) + rb);
+                            xx[k][3] = *reinterpret_cast<lds_f32x4*>(((cc[g].y >> 16) << 4) + rb);
+                        }
+                        asm volatile("" ::: "memory");   // all reads of the group are issued before the first FMA waits for one
+#endif
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) {
+#if GF_PANEL_BATCH
+                            const f32x4 x0 = xx[k][0], x1 = xx[k][1], x2 = xx[k][2], x3 = xx[k][3];
+#else
+                            const unsigned rb = bbase + k * regionB;
+                            const unsigned o0 = ((cc[g].x & 0xffffu) << 4) + rb, o1 = ((cc[g].x >> 16) << 4) + rb;
+                            const unsigned o2 = ((cc[g].y & 0xffffu) << 4) + rb, o3 = ((cc[g].y >> 16) << 4) + rb;
+                            const f32x4 x0 = *reinterpret_cast<lds_f32x4*>(o0);
+                            const f32x4 x1 = *reinterpret_cast<lds_f32x4*>(o1);
+                            const f32x4 x2 = *reinterpret_cast<lds_f32x4*>(o2);
+                            const f32x4 x3 = *reinterpret_cast<lds_f32x4*>(o3);
+#endif
+                            if (UNIFORM) {
+                                acc0[k] += x0;
+                                acc1[k] += x1;
+                                acc0[k] += x2;
+                                acc1[k] += x3;
+                            } else {
+                                acc0[k] += vv[g].x * x0;
+                                acc1[k] += vv[g].y * x1;
+                                acc0[k] += vv[g].z * x2;
+                                acc1[k] += vv[g].w * x3;
+                            }
+                        }
+                    }
+                    if (same) {
+                        j0 += kGC;
+                        return false;
+                    }
+                    const int row = (oc << ush) + (lane & ((1 << ush) - 1));
+                    if (oc >= 0 && row < N) {
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) {
+                            if (k >= nvalid) break;
+                            f32x4 acc = acc0[k] + acc1[k];
+                            if (UNIFORM) acc *= uval;
+                            f32x4* dst = reinterpret_cast<f32x4*>(outp + (int64_t)k * pstride + (int64_t)row * 4);
+                            if (store_mode == 2)
+                                __builtin_nontemporal_store(acc, dst);
+                            else
+                                *dst = acc;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) acc0[k] = acc1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    s = sn;
+                    if (s >= nSlices) return true;
+                    si = sin;
+                    oc = ocn;
+                    j0 = 0;
+                    sn = claim();
+                    sin = make_int2(sentinel, 0);
+                    ocn = -1;
+                    if (sn < nSlices) {
+                        sin = slice[sn];
+                        ocn = octs[(sn << (6 - ush)) + (lane >> ush)];
+                    }
+                    return false;
+                };
+                for (;;) {
+                    if (process(cA, vA, cB, vB)) break;
+                    if (process(cB, vB, cA, vA)) break;
+                }
+            }
+        }
+        lds_barrier();   // every gatherer is done with buffer cur, the loaders' DMA into the other one has landed
+        p = pn;
+        cur ^= 1;
+        if (p >= nGroups) break;
+    }
+}
+
 // x[B, C, Nin] (reference layout, node index contiguous) -> Xp[B*C/4][N][4]; rows n >= Nin are zero
 // (== GraphFilter.forward's zero padding, graphML.py:2131-2135).  C % 4 == 0.
 __global__ __launch_bounds__(256) void pack_panels_kernel(const float* __restrict__ x, float* __restrict__ Xp, int Nin, int N,
@@ -330,6 +532,28 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
         grid = (int64_t)nGroups * split;
     }
     if (g_tune.panel_grid > 0 && grid > g_tune.panel_grid) grid = g_tune.panel_grid / split * split;  // experiments: fewer workgroups than CUs
+    // double-buffered variant (spmm_panel_db_kernel): two buffers of two panels in one workgroup
+    const size_t lds_db = 4 * (size_t)(N + 1) * 16 + 16;
+    // measured (tools/panel_w_probe.py, profiles/r04_f_panel_db): N = 1682 weighted 64.2 -> 60.2 us per hop at width 64 (equal weights
+    // 59.8 -> 58.6), N = 2500 47.6 -> 43.0 (44.5 -> 41.7) at width 32; N = 1000 (two workgroups per CU either way) 20.6 vs 20.8: the
+    // default takes it where one workgroup fills the CU (1280 <= N <= 2559); knob panel_db: 0 = never, 2 = wherever four panels fit
+    const bool one = lds_db > 80 * 1024;   // one workgroup per CU: all 16 waves
+    if (g_tune.panel_db != 0 && (one || g_tune.panel_db == 2) && lds_db <= 160 * 1024 && nPanels >= 2 * num_cus() && m.pn_slices >= 2 &&
+        g_tune.panel_np == 0) {
+        const int thr_db = g_tune.panel_thr > 0 ? g_tune.panel_thr : (one ? 1024 : 512);
+        // (loader waves of 16: on a tap stack -- every hop reads what the last one wrote, nothing comes from the Infinity Cache -- 2: 75.4,
+        //  3: 74.1, 4: 71.0 us per hop at N = 1682, width 64, weighted; the per-hop kernel 79.4; tools/panel_w_probe.py with PROBE_KHOP=1)
+        const int loaders = g_tune.panel_loaders > 0 ? g_tune.panel_loaders : (thr_db >= 1024 ? 4 : (thr_db >= 512 ? 2 : 1));
+        const int nG = (nPanels + 1) / 2;
+        int64_t gdb = (int64_t)num_cus() * (one ? 1 : 2);
+        if (gdb > nG) gdb = nG;
+        auto kdb = uniform ? spmm_panel_db_kernel<1, 2> : spmm_panel_db_kernel<0, 2>;
+        if (lds_db > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kdb, lds_db));
+        hipLaunchKernelGGL(kdb, dim3((unsigned)gdb), dim3(thr_db), lds_db, st, m.pn_slice, m.pn_oct, (const uint2*)m.pn_col2, m.pn_val4, m.pn_uval,
+                           Xin, Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, m.pn_ushift, loaders);
+        GF_LAUNCH_CHECK("spmm_panel_db_kernel");
+        return GF_OK;
+    }
     typedef void (*kern_t)(const int2*, const int32_t*, const void*, const float4*, float, const float*, float*, int, int, int, int, int,
                            int, int, int);
     kern_t kern = np == 4 ? (uniform ? (kern_t)spmm_panel_kernel<1, 4> : (kern_t)spmm_panel_kernel<0, 4>)

@@ -84,9 +84,14 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "panel_sort")) g_tune.panel_sort = value;
     else if (!strcmp(key, "panel_even")) g_tune.panel_even = value;
     else if (!strcmp(key, "panel_np")) g_tune.panel_np = value;
+    else if (!strcmp(key, "spmm_lanes")) g_tune.spmm_lanes = value;
+    else if (!strcmp(key, "panel_db")) g_tune.panel_db = value;
+    else if (!strcmp(key, "panel_thr")) g_tune.panel_thr = value;
+    else if (!strcmp(key, "panel_loaders")) g_tune.panel_loaders = value;
     else if (!strcmp(key, "panel_unit")) g_tune.panel_unit = value;
     else if (!strcmp(key, "panel_split")) g_tune.panel_split = value;
     else if (!strcmp(key, "bwd_fuse")) g_tune.bwd_fuse = value;
+    else if (!strcmp(key, "bwd_fuse64")) g_tune.bwd_fuse64 = value;
     else if (!strcmp(key, "panel_grid")) g_tune.panel_grid = value;
     else if (!strcmp(key, "panel_rotate")) g_tune.panel_rotate = value;
     else if (!strcmp(key, "panel_chain")) g_tune.panel_chain = value;

@@ -611,7 +611,10 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     }
     // XCD roles: `lanes` batch-tile lanes x `parts` slice partitions (lanes * parts <= 8); spmm_xcd = 0 ignores the XCD
     // structure (every XCD works on the same tile).
-    const int lanes = !g_tune.spmm_xcd ? 1 : (nBTiles >= 8 ? 8 : nBTiles);
+    // (knob spmm_lanes = 1 | 2 | 4: fewer batch tiles in flight, 8 / lanes XCDs share a tile's slices -- a smaller active source set
+    //  in the Infinity Cache against a lower L2 hit rate per XCD)
+    int lanes = !g_tune.spmm_xcd ? 1 : (nBTiles >= 8 ? 8 : nBTiles);
+    if (g_tune.spmm_lanes == 1 || g_tune.spmm_lanes == 2 || g_tune.spmm_lanes == 4) lanes = std::min(lanes, g_tune.spmm_lanes);
     const int parts = 8 / lanes;
     const int64_t tileBytes = (int64_t)N * W * 4 * BL * bt;
     const bool l2_resident = tileBytes * 2 <= (6 << 20);  // this tile's panel + the prefetched next one

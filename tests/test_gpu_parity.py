@@ -564,6 +564,13 @@ def test_graph_recurrent_nn_matches_reference():
     dict(N=900, B=4, G=64, F=8, K=3, directed=True, model="er", E=2),
     dict(N=12000, B=2, G=64, F=32, K=5, directed=False, model="er"),
     dict(N=11000, B=3, G=128, F=32, K=2, directed=True, model="er"),
+    # one-pass backward with 64 output features (round 4: two f blocks of tap gradients per wave; G <= 32): panels and node-major,
+    # T = 5 with two edge features, T = 6, T = 2
+    dict(N=900, B=4, G=16, F=64, K=3, directed=True, model="er", E=2),
+    dict(N=700, B=3, G=8, F=64, K=6, directed=False, model="sbm"),
+    dict(N=12000, B=2, G=32, F=64, K=5, directed=False, model="er"),
+    dict(N=10500, B=3, G=5, F=64, K=2, directed=True, model="er"),
+    dict(N=300, B=7, G=32, F=60, K=4, directed=True, model="sbm"),       # F = 60 is padded to 64
 ], ids=lambda c: "_".join(f"{k}{v}" for k, v in c.items()))
 def test_lsigf_random_sparse_vs_oracle(cfg):
     E = cfg.get("E", 1)
@@ -856,7 +863,8 @@ def tune(**kw):
 @pytest.fixture
 def pipeline_knob():
     yield tune
-    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_chain=1, panel_np=0, evgf_generic=0)
+    tune(pipeline=0, panel_uniform=1, panel_order=1, panel_sort=1, panel_chain=1, panel_np=0, evgf_generic=0, panel_db=1, panel_thr=0,
+         panel_loaders=0)
 
 
 def to_panels(x, N):
@@ -924,6 +932,44 @@ def test_spmm_hop_panel_against_scipy(N, P, kind, pipeline_knob):
             _lib.check(L.gf_spmm_hop_panel(plans[0], op, Xt.data_ptr(), out2.data_ptr(), P, stream()))
             pipeline_knob(panel_np=0)
             assert torch.equal(out, out2)                    # bitwise deterministic, whatever the pass width
+
+
+@pytest.mark.parametrize("N,P,kind,knobs", [
+    (1682, 1024, "weighted", {}), (1682, 1024, "uniform", {}), (1280, 513, "weighted", {}), (2559, 515, "uniform", {}), (2000, 2050, "weighted", {}),
+    (1000, 601, "weighted", dict(panel_db=2)), (300, 1029, "uniform", dict(panel_db=2)), (129, 512, "weighted", dict(panel_db=2)),
+    (1682, 700, "weighted", dict(panel_loaders=1)), (1682, 700, "uniform", dict(panel_loaders=4, panel_thr=768)),
+], ids=lambda v: str(v))
+def test_double_buffered_panel_hop_is_bitwise_the_per_hop_kernel(N, P, kind, knobs, pipeline_knob):
+    """spmm_panel_db_kernel (loader waves fetch the next pass with LDS-DMA under the gathers, slices claimed from an LDS counter) walks the
+    same ELL image with the same accumulators as spmm_panel_kernel: the same bits, whatever the claim order; against scipy as well.
+    Launched 6 times in a row (the claim order differs from launch to launch)."""
+    L = _lib.lib()
+    rng = np.random.RandomState(N + P)
+    A = sp.random(N, N, density=min(0.5, 12.0 / N), format="lil", random_state=rng, data_rvs=rng.randn)
+    A[N // 2, :] = 0
+    A[:, N // 3] = 0
+    hub = rng.choice(N, size=min(N, 200), replace=False)
+    A[1, hub] = rng.randn(len(hub))
+    A[hub, 2] = rng.randn(len(hub))
+    A = sp.csr_matrix(A)
+    if kind == "uniform":
+        A.data[:] = -0.41
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    X = rng.randn(P, N, 4).astype(np.float32)
+    Xt = cu(X)
+    for op, M in ((0, A.T.tocsr()), (1, A)):
+        pipeline_knob(panel_db=0)
+        ref = torch.full((P, N, 4), float("nan"), device=DEV)
+        _lib.check(L.gf_spmm_hop_panel(plans[0], op, Xt.data_ptr(), ref.data_ptr(), P, stream()))
+        want = np.stack([M.astype(np.float64) @ X[p].astype(np.float64) for p in range(P)])
+        assert relerr(ref.cpu().numpy(), want) < 2e-6
+        pipeline_knob(**dict(dict(panel_db=1), **knobs))
+        for it in range(6):
+            out = torch.full((P, N, 4), float("nan"), device=DEV)
+            _lib.check(L.gf_spmm_hop_panel(plans[0], op, Xt.data_ptr(), out.data_ptr(), P, stream()))
+            assert torch.equal(out, ref), (op, it)
+        pipeline_knob(panel_db=1, panel_thr=0, panel_loaders=0)
 
 
 @pytest.mark.parametrize("N,B,W,K,kind", [

@@ -128,6 +128,54 @@ ho)      # node-major layer hand-over: bitwise tests + the step it saves at the 
   timeout 300 python tools/handover_bench.py 100000 128 2 > $O/bench2.log 2>&1; tail -1 $O/bench2.log
   timeout 300 python tools/handover_bench.py 100000 64 3 > $O/bench3.log 2>&1; tail -1 $O/bench3.log
   ;;
+pdb)     # double-buffered panel kernel against the per-hop kernel
+  timeout 200 python tools/panel_w_probe.py 1682 64 256 v:panel_db=1 v:panel_db=1+panel_loaders=1 v:panel_db=1+panel_loaders=3 v:panel_db=1+panel_thr=768 > $O/probe.log 2>&1; grep -v "amdgpu.ids" $O/probe.log
+  timeout 100 python tools/panel_w_probe.py 1682 32 256 v:panel_db=1 > $O/probe_w32.log 2>&1; grep -A2 "^weighted\|^equal" $O/probe_w32.log
+  timeout 100 python tools/panel_w_probe.py 1000 32 256 v:panel_db=1 v:panel_db=1+panel_thr=1024 > $O/probe_n1000.log 2>&1; grep -A3 "^weighted\|^equal" $O/probe_n1000.log
+  timeout 100 python tools/panel_w_probe.py 2500 32 256 v:panel_db=1 > $O/probe_n2500.log 2>&1; grep -A2 "^weighted\|^equal" $O/probe_n2500.log
+  ;;
+pvar)    # A/B builds of gf_panel.hip (tools/panel_variant.sh): entry-chunk size and LDS read batching
+  for v in "" kgc4 batch kgc4b; do
+    echo "== variant ${v:-shipped}"
+    (export GFHIP_EXPERIMENTS=1; [ -n "$v" ] && export GFHIP_LIB=$PWD/graph-neural-networks_amd/alegnn_amd/libgfhip_$v.so; timeout 100 python tools/panel_w_probe.py 1682 64 256 v:panel_db=1 2>&1 | grep -A2 "^weighted\|^equal")
+  done > $O/variants.log 2>&1; cat $O/variants.log
+  ;;
+pdbt)    # tests of the double-buffered panel kernel + the panel-pipeline tests it now takes part in + cfg3 bench
+  timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "panel or khop or handover or pipelines or selection or golden" > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+  timeout 300 python bench.py --workload cfg3 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err; python -c "import json; d=json.load(open('$O/bench_cfg3.json')); print(d['ms_per_step'], d['roofline'])"
+  GFHIP_EXPERIMENTS=1 timeout 300 python - <<'PY' > $O/bench_cfg3_off.log 2>&1
+import sys; sys.path[:0]=['.','graph-neural-networks_amd']
+from alegnn_amd import _lib
+_lib.check(_lib.lib().gf_tune(b"panel_db", 0))
+sys.argv=['bench.py','--workload','cfg3','--no-cpu-baseline']
+exec(open('bench.py').read())
+PY
+  tail -1 $O/bench_cfg3_off.log | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('panel_db=0:', d['ms_per_step'], d['roofline']['launch_ms'])"
+  ;;
+pkh)     # the same probe on a tap stack (4 hops back to back, as bench.py times them), variants alternated; then cfg3 with and without
+  export PROBE_KHOP=1
+  timeout 200 python tools/panel_w_probe.py 1682 64 256 v:panel_db=0 v:panel_db=1 v:panel_db=0 v:panel_db=1 v:panel_db=1+panel_loaders=6 v:panel_db=1+panel_loaders=2 > $O/probe.log 2>&1; grep -v "amdgpu.ids" $O/probe.log | grep -A7 "^weighted\|^equal"
+  timeout 100 python tools/panel_w_probe.py 1682 32 256 v:panel_db=0 v:panel_db=1 v:panel_db=0 v:panel_db=1 > $O/probe_w32.log 2>&1; grep -A5 "^weighted\|^equal" $O/probe_w32.log
+  unset PROBE_KHOP
+  for rep in 1 2; do for db in 0 1; do
+  GFHIP_EXPERIMENTS=1 DB=$db timeout 300 python - <<'PY' 2>/dev/null | tail -1 | python -c "import json,sys,os; d=json.loads(sys.stdin.readline()); print('cfg3 panel_db=%s:' % os.environ.get('DB'), round(d['ms_per_step'],4), 'ms/step, hop', d['roofline']['launch_ms'])"
+import sys, os; sys.path[:0]=['.','graph-neural-networks_amd']
+from alegnn_amd import _lib
+_lib.check(_lib.lib().gf_tune(b"panel_db", int(os.environ["DB"])))
+sys.argv=['bench.py','--workload','cfg3','--no-cpu-baseline']
+exec(open('bench.py').read())
+PY
+  done; done
+  ;;
+f64)     # one-pass backward with F = 64: oracle parity, goldens, cfg3 with and without
+  timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "oracle or golden or selection or handover or trainer" > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+  for f in 1 0; do
+    GFHIP_EXPERIMENTS=1 timeout 300 python bench.py --workload cfg3 --no-cpu-baseline --tune bwd_fuse64=$f 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('cfg3 bwd_fuse64=$f:', round(d['ms_per_step'],4), 'ms/step')"
+  done
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -o cfg3 -- python $OLDPWD/bench.py --workload cfg3 --no-cpu-baseline --steps 50 --warmup 3 > /dev/null 2>&1)
+  f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_cfg3_kernel_stats.csv; rm -rf $O/prof
+  python tools/show_stats.py $O | head -12
+  ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
   V="v:spmm_algo=3"; for l in ${LAGS:-0 1 2 4}; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
   timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"

@@ -23,11 +23,13 @@ ms = ctypes.c_float()
 A = graphgen.knn_weighted(N, k=10, seed=0)
 Au = A.copy(); Au.data[:] = 0.37
 graphs = [("weighted", A)] if os.environ.get("PROBE_ONLY") else [("weighted", A), ("equal-w", Au), ("empty", sp.csr_matrix((N, N), dtype=np.float32))]
+KH = os.environ.get("PROBE_KHOP") == "1"
 X = torch.randn(P, N, 4, device=dev)
+Z = torch.randn(5, P, N, 4, device=dev) if KH else None
 Y = torch.empty_like(X)
 alg = 2 * P * N * 16
 print(f"N={N} W={W} B={B} panels={P} nnz={A.nnz} algorithmic bytes/hop={alg}")
-DEFAULTS = dict(panel_np=0, panel_chain=1, panel_rotate=1, panel_split=0, panel_grid=0)
+DEFAULTS = dict(panel_np=0, panel_chain=1, panel_rotate=1, panel_split=0, panel_grid=0, panel_db=0, panel_thr=0, panel_loaders=0)
 for name, M in graphs:
     gso = SparseGSO([M]); plans = gso.plans(dev)
     ns, uni, cyc, fill = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
@@ -40,7 +42,18 @@ for name, M in graphs:
         for k, x in kv.items():
             _lib.check(L.gf_tune(k.encode(), x), k)
         it = 1 if os.environ.get("PROBE_ONLY") else 20
-        _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X.data_ptr(), Y.data_ptr(), P, it, st, ctypes.byref(ms)))
-        print(f"   {v or 'default':28s} {ms.value * 1e3:7.1f} us/hop   {alg / ms.value / 1e6:7.0f} GB/s = {alg / ms.value / 8e9 * 100:5.1f} %", flush=True)
+        if KH:      # the bench's measure: the K - 1 = 4 per-hop launches of a tap stack back to back (every hop reads what the last one wrote)
+            _lib.check(L.gf_tune(b"panel_chain", 0))
+            _lib.check(L.gf_time_khop_panel(plans, 1, 0, Z.data_ptr(), B, W, 5, it, st, ctypes.byref(ms)))
+            ms.value /= 4
+            Y.copy_(Z[4])
+        else:
+            _lib.check(L.gf_time_spmm_hop_panel(plans[0], 0, X.data_ptr(), Y.data_ptr(), P, it, st, ctypes.byref(ms)))
+        torch.cuda.synchronize()
+        if not v:
+            Yref = Y.clone()
+        same = "bitwise = default" if torch.equal(Y, Yref) else f"DIFFERS from default (max abs {float((Y - Yref).abs().max()):.3g})"
+        print(f"   {v or 'default':28s} {ms.value * 1e3:7.1f} us/hop   {alg / ms.value / 1e6:7.0f} GB/s = {alg / ms.value / 8e9 * 100:5.1f} %   {same}", flush=True)
+        Y.fill_(float("nan"))
     for k, x in DEFAULTS.items():
         _lib.check(L.gf_tune(k.encode(), x), k)
