@@ -661,29 +661,47 @@ __global__ __launch_bounds__(kThreads, (FIN8 > 4 ? 1 : 2)) void bwd_fused_panel_
     }
 
     // tap-gradient tile (t, gblk) is tile ct = t * numGI + gblk of the shared partial layout [wave][pass][ctp] (make_geo; one pass when Gtot <= 32)
+    // The four waves of the workgroup add their tiles up through LDS, in wave order (fixed: deterministic), and the workgroup writes ONE
+    // set of partial tiles: row blockIdx.x of the partial matrix (round 3 wrote one per wave: at config 3 the 2048 x 40 KB of partials
+    // were 84 MB written here and read back by reduce_rows_kernel, 29 us per call, four calls per step).  Tile by tile: every wave
+    // drops its tile into its slot, one barrier, the 256 threads add the four slots for four elements each and store them coalesced;
+    // two sets of slots alternate, so the next tile is dropped while stragglers still read.  The wave tiles are dead by now: their LDS
+    // (4 x (1 + FB) x 32 x 36 >= 9216 floats) holds the 2 x 4 slots of 1024 and the bias sums.
     // (pass = c-pass * numFT + f block, as grad_taps_kernel numbers them; FB = 2 runs with numGI = 1: one c-pass)
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int ct = t * numGI + gblk;
-#pragma unroll
-        for (int fb = 0; fb < FB; ++fb) {
-            float* pt = partial + (((int64_t)wg * passes + (ct / ctp) * FB + fb) * ctp + ct % ctp) * 1024;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
-                pt[g * 32 + l31] = acc_h[t * FB + fb][i];
-            }
-        }
-    }
+    static_assert(kWaves * WT >= 2 * kWaves * 1024 + kWaves * FB * 32, "the wave tiles hold the slots of the workgroup reduction");
+    float* slots = s_tiles;
+    float* bslot = s_tiles + 2 * kWaves * 1024;
+    __syncthreads();   // every wave is done with its tiles
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) {
-        const float other = __shfl_xor(bsum[fb], 32, 64);
-        if (half == 0 && gblk == 0) partial_b[((int64_t)wg * FB + fb) * 32 + l31] = bsum[fb] + other;  // even rows + odd rows
+        const float both = bsum[fb] + __shfl_xor(bsum[fb], 32, 64);   // even rows + odd rows
+        if (half == 0) bslot[(wave * FB + fb) * 32 + l31] = both;
     }
+#pragma unroll
+    for (int k = 0; k < T * FB; ++k) {
+        float* set = slots + (k & 1) * kWaves * 1024;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int g = (i & 3) + 8 * (i >> 2) + 4 * half;
+            set[wave * 1024 + g * 32 + l31] = acc_h[k][i];
+        }
+        __syncthreads();
+        const int t = k / FB, fb = k - t * FB;
+        const int ct = t * numGI + gblk;
+        float* pt = partial + (((int64_t)blockIdx.x * passes + (ct / ctp) * FB + fb) * ctp + ct % ctp) * 1024;
+#pragma unroll
+        for (int j = 0; j < 1024 / kThreads; ++j) {
+            const int e = tid + j * kThreads;
+            pt[e] = ((set[e] + set[1024 + e]) + set[2048 + e]) + set[3072 + e];
+        }
+    }
+    if (gblk == 0 && tid < FB * 32)   // (the bias slots were complete at the first barrier of the loop)
+        partial_b[(int64_t)blockIdx.x * FB * 32 + tid] = ((bslot[tid] + bslot[FB * 32 + tid]) + bslot[2 * FB * 32 + tid]) + bslot[3 * FB * 32 + tid];
 }
 
-int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, int E, int K, hipStream_t st) {
-    const int wavesPadded = g.strips * kWaves;
+// per_wg: the stage-1 kernel wrote one row of partials per WORKGROUP (bwd_fused_panel_kernel) instead of one per wave
+int finish_taps(const Geo& g, float* ws, float* dh, float* dbias, int G, int F, int E, int K, hipStream_t st, bool per_wg = false) {
+    const int wavesPadded = per_wg ? g.strips : g.strips * kWaves;
     const int slices = wavesPadded < kSlices ? wavesPadded : kSlices;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((g.tileOutputs + kThreads - 1) / kThreads), slices), dim3(kThreads), 0,
                        st, ws, ws + g.off_mid, wavesPadded, g.tileOutputs, slices);
@@ -765,7 +783,7 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
 #undef GF_BF64
 #undef GF_BF
     GF_LAUNCH_CHECK("bwd_fused_panel_kernel");
-    return finish_taps(g, ws, dh, dbias, G, F, E, K, st);
+    return finish_taps(g, ws, dh, dbias, G, F, E, K, st, /*per_wg=*/true);
 }
 
 extern "C" int gf_grad_taps_panel(const float* Zp, const float* P0p, float* dh, float* dbias, void* workspace, size_t workspace_bytes,

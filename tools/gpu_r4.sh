@@ -176,6 +176,15 @@ f64)     # one-pass backward with F = 64: oracle parity, goldens, cfg3 with and 
   f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_cfg3_kernel_stats.csv; rm -rf $O/prof
   python tools/show_stats.py $O | head -12
   ;;
+wgred)   # workgroup-level reduction of the tap-gradient partials: parity, then the benches it touches
+  timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+  for wl in cfg3 cfg2 cfg4; do
+    timeout 300 python bench.py --workload $wl --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('$wl', round(d['ms_per_step'],4), 'ms/step')"
+  done
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -o cfg3 -- python $OLDPWD/bench.py --workload cfg3 --no-cpu-baseline --steps 50 --warmup 3 > /dev/null 2>&1)
+  f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_cfg3_kernel_stats.csv; rm -rf $O/prof
+  python tools/show_stats.py $O | head -12
+  ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
   V="v:spmm_algo=3"; for l in ${LAGS:-0 1 2 4}; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
   timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
