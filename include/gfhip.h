@@ -262,7 +262,11 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * "panel_order" (0/1 bank-aware neighbour order; read by gf_plan_create), "panel_sort" (0/1 octets sorted by longest row; read by gf_plan_create),
  * "panel_rotate" (0/1 per-workgroup rotated slice walk), "panel_np" (0 = heuristic | 1 | 2 panels per pass), "panel_split" (workgroups per pass
  * for small batches: 0 = as many as fit, 1 = off), "panel_chain" (0/1 the K-1 hops of a panel inside LDS, gf_chain.hip), "gradw_lds" (0/1),
+ * "panel_db" (double-buffered per-hop panel kernel: 1 = where one workgroup fills a CU's LDS with four panels, 1280 <= N <= 2559 | 2 = wherever
+ * four panels fit | 0 = never), "panel_thr" / "panel_loaders" (its workgroup size and loader waves, 0 = default), "spmm_lanes" (SELL kernels:
+ * batch tiles in flight, 0 = one per XCD | 1 | 2 | 4),
  * "bwd_fuse" (0/1 dx and dh in one pass over the adjoint stack, either pipeline, when F <= 32 and G <= 32 or G = 64 / 128),
+ * "bwd_fuse64" (0/1 the same for F = 64, G <= 32),
  * "evgf_generic" (0 = best EVGF tap kernel | 1 = one thread per output | 2 = LDS-staged 4-byte gathers), "evgf_idx16" (0/1 16-bit node
  * indices in the EVGF kernels when N <= 65535).
  * EXPERIMENTS ONLY: the knobs are process-global and not thread-safe, so gf_tune is refused (GF_ERR_UNSUPPORTED) unless the
