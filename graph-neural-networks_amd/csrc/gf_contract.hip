@@ -427,7 +427,10 @@ template <int NT, int CIN8>
 int launch_panel(const float* Zp, const BankView& bank, const float* bias, float* out, int B, int N, int Nout, int Cout, int T,
                  hipStream_t st, int out_panels, const float* maskp) {
     constexpr int Cin = CIN8 * 8;
-    constexpr int D = CIN8 <= 4 ? 4 : (CIN8 == 8 ? 2 : 1);
+#ifndef GF_CONTRACT_D8
+#define GF_CONTRACT_D8 4   // Cin = 64: 159 registers, still the three workgroups per CU the 43.5 KB bank allows (D = 2: 95; config 3 step 1.613 -> 1.601 ms)
+#endif
+    constexpr int D = CIN8 <= 4 ? 4 : (CIN8 == 8 ? GF_CONTRACT_D8 : 1);
     const size_t lds = ((size_t)T * (Cin + 4) * NT * 32 + NT * 32) * sizeof(float);
     const int tilesPerB = (Nout + 31) / 32;
     const int64_t totalTiles = (int64_t)B * tilesPerB;

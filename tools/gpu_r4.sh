@@ -185,6 +185,14 @@ wgred)   # workgroup-level reduction of the tap-gradient partials: parity, then 
   f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_cfg3_kernel_stats.csv; rm -rf $O/prof
   python tools/show_stats.py $O | head -12
   ;;
+cd8)     # ring depth of contract_panel_kernel<., 8, D> (Cin = 64): kernel averages under rocprofv3, cfg3
+  for v in "" d8_3 d8_4; do
+    (export GFHIP_EXPERIMENTS=1; [ -n "$v" ] && export GFHIP_LIB=$PWD/graph-neural-networks_amd/alegnn_amd/libgfhip_$v.so
+     cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_$v -o cfg3 -- python $OLDPWD/bench.py --workload cfg3 --no-cpu-baseline --steps 50 --warmup 3 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('variant ${v:-shipped}:', round(d['ms_per_step'],4), 'ms/step (under rocprof)')")
+    f=$(find $O/prof_$v -name "*kernel_stats.csv" | head -1); grep "contract_panel_kernel" $f | cut -d, -f1-4 | cut -c1-120
+    rm -rf $O/prof_$v
+  done 2>&1 | tee $O/d8.log
+  ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
   V="v:spmm_algo=3"; for l in ${LAGS:-0 1 2 4}; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
   timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
