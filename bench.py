@@ -381,12 +381,13 @@ def filter_hop_roofline(L, plans, name, B, N, W, K, nnz, dev):
     if pipe == 2:                                                 # column panels: the K-1 hops of a panel are ONE launch (gf_chain.hip)
         Z = torch.randn(K, B * W // 4, N, 4, device=dev)
         _lib.check(L.gf_time_khop_panel(plans, 1, 0, Z.data_ptr(), B, W, K, 20, st, ctypes.byref(ms)))
-        if L.gf_khop_panel_uses_chain(plans[0], 0, B * W // 4) == 1:
+        which = L.gf_khop_panel_uses_chain(plans[0], 0, B * W // 4)
+        if which == 1:
             kern, hops = "spmm_chain_kernel", K - 1
             note = ("K-1 hops of every panel in one launch, panel resident in LDS: HBM sees 1 read + (K-1) writes of the signal per launch, "
                     "the algorithmic count (a read and a write per hop) is what `achieved` divides by")
         else:                                                     # few panels / small weighted GSO: one launch per hop
-            kern, hops = "spmm_panel_kernel", 1
+            kern, hops = ("spmm_panel_db_kernel" if which == 2 else "spmm_panel_kernel"), 1
             ms.value /= (K - 1)
             note = "one hop per launch (the K-1 launches of a chain timed together, launch_ms = their mean), gathers from an LDS-resident panel"
     else:                                                         # node-major, gathers through L2

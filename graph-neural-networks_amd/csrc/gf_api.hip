@@ -86,7 +86,7 @@ extern "C" int gf_lsigf_pipeline(const gf_plan* const* plans, int32_t E, int32_t
 
 extern "C" int gf_khop_panel_uses_chain(const gf_plan* plan, int32_t op, int32_t n_panels) {
     GF_REQUIRE_ARG(plan != nullptr && (op == GF_OP_FWD || op == GF_OP_BWD) && n_panels > 0, "gf_khop_panel_uses_chain: bad argument");
-    return use_chain(plan, op, n_panels) ? 1 : 0;
+    return use_chain(plan, op, n_panels) ? 1 : (gf_panel_db_applies(plan, op, n_panels) ? 2 : 0);
 }
 
 extern "C" int gf_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, void* stream) {

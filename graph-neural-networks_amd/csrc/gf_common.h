@@ -222,5 +222,6 @@ hipError_t gf_grant_lds(const void* kernel, size_t lds_bytes);
 int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st, const float* mask);
 int gf_layout_masked_launch(const float* dy, const float* y, float* X, int B, int G, int Nin, int N, hipStream_t st);
 int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st);
+bool gf_panel_db_applies(const gf_plan* plan, int op, int nPanels);
 int gf_contract_panel_launch(const float* Zp, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
                              int F, int E, int K, int transpose_bank, hipStream_t st, int out_panels = 0, const float* maskp = nullptr);

@@ -497,6 +497,15 @@ int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int 
     return GF_OK;
 }
 
+// does a per-hop launch for nPanels panels run the double-buffered kernel?  (the launcher and gf_khop_panel_uses_chain share the rule)
+bool gf_panel_db_applies(const gf_plan* plan, int op, int nPanels) {
+    const gf_csr_dev& m = plan->mat[op];
+    const size_t lds_db = 4 * (size_t)(plan->n + 1) * 16 + 16;
+    const bool one = lds_db > 80 * 1024;
+    return g_tune.panel_db != 0 && (one || g_tune.panel_db == 2) && lds_db <= 160 * 1024 && nPanels >= 2 * num_cus() && m.pn_slices >= 2 &&
+           g_tune.panel_np == 0;
+}
+
 int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st) {
     const gf_csr_dev& m = plan->mat[op];
     const int N = plan->n;
@@ -538,8 +547,7 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
     // 59.8 -> 58.6), N = 2500 47.6 -> 43.0 (44.5 -> 41.7) at width 32; N = 1000 (two workgroups per CU either way) 20.6 vs 20.8: the
     // default takes it where one workgroup fills the CU (1280 <= N <= 2559); knob panel_db: 0 = never, 2 = wherever four panels fit
     const bool one = lds_db > 80 * 1024;   // one workgroup per CU: all 16 waves
-    if (g_tune.panel_db != 0 && (one || g_tune.panel_db == 2) && lds_db <= 160 * 1024 && nPanels >= 2 * num_cus() && m.pn_slices >= 2 &&
-        g_tune.panel_np == 0) {
+    if (gf_panel_db_applies(plan, op, nPanels)) {
         const int thr_db = g_tune.panel_thr > 0 ? g_tune.panel_thr : (one ? 1024 : 512);
         // (loader waves of 16: on a tap stack -- every hop reads what the last one wrote, nothing comes from the Infinity Cache -- 2: 75.4,
         //  3: 74.1, 4: 71.0 us per hop at N = 1682, width 64, weighted; the per-hop kernel 79.4; tools/panel_w_probe.py with PROBE_KHOP=1)

@@ -128,7 +128,8 @@ int gf_time_spmm_hop_panel(const gf_plan* plan, int32_t op, const float* Xin, fl
  * events on `stream`, average milliseconds per call (per K-1 hops of every edge feature). */
 int gf_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, void* stream);
 /* 1 when gf_khop_panel runs the chain kernel (spmm_chain_kernel, one launch per edge feature) for n_panels panels on this plan, 0 when it
- * runs one spmm_panel_kernel launch per hop (few panels; small weighted GSOs): which kernel a profile of the call shows */
+ * runs one spmm_panel_kernel launch per hop (few panels; small weighted GSOs), 2 when those per-hop launches are the double-buffered
+ * spmm_panel_db_kernel (1280 <= N <= 2559): which kernel a profile of the call shows */
 int gf_khop_panel_uses_chain(const gf_plan* plan, int32_t op, int32_t n_panels);
 int gf_time_khop_panel(const gf_plan* const* plans, int32_t E, int32_t op, float* Zp, int32_t B, int32_t W, int32_t K, int32_t iters,
                        void* stream, float* avg_ms);
