@@ -193,6 +193,15 @@ cd8)     # ring depth of contract_panel_kernel<., 8, D> (Cin = 64): kernel avera
     rm -rf $O/prof_$v
   done 2>&1 | tee $O/d8.log
   ;;
+final3)  # kernel stats of the other workloads, config-5 PMC, the torchrun / RCCL N = 1 rehearsal -- all on the final sources
+  for wl in cfg2 cfg3 cfg5 db; do
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -o $wl -- python $OLDPWD/bench.py --workload $wl --no-cpu-baseline --steps 20 --warmup 3 > /dev/null 2>&1)
+    f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_${wl}_kernel_stats.csv; rm -rf $O/prof
+  done
+  python tools/show_stats.py $O | head -40
+  GFHIP_EXPERIMENTS=1 bash tools/pmc_collect.sh cfg5 ev_hop_lds4_kernel r04 > $O/pmc_cfg5.log 2>&1; tail -1 $O/pmc_cfg5.log | cut -c1-300; cp gpurun_out/pmc_cfg5/r04_cfg5_pmc.json $O/ 2>/dev/null
+  timeout 600 bash tools/scale.sh cfg4 1 > $O/scale.log 2>&1; tail -6 $O/scale.log; mkdir -p $O/scale; cp gpurun_out/scale/cfg4_*.json $O/scale/ 2>/dev/null
+  ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
   V="v:spmm_algo=3"; for l in ${LAGS:-0 1 2 4}; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
   timeout 120 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "spmm hop"
