@@ -188,6 +188,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # RCCL prints a version banner on STDOUT when it creates its first communicator; rank 0's stdout carries exactly one JSON line, so
+        # the process's stdout (fd 1) points at stderr from here until that line is written.
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from alegnn_amd import _lib, parallel
@@ -313,7 +318,12 @@ def main():
             out["mfma"] = mfma
         if detail:
             out["breakdown_ms"] = detail
+        if distributed:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        if distributed:
+            os.dup2(2, 1)   # (whatever the teardown prints stays off stdout as well)
     if distributed:
         dist.destroy_process_group()
 
