@@ -108,7 +108,7 @@ pw)      # config-3-class weighted panel hop: decomposition + LDS counters
              "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VALU SQ_INSTS_SALU" \
              "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
              "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
-    rm -rf $O/pm; (export TMPDIR=/tmp PROBE_ONLY=1; timeout 100 rocprofv3 --pmc $grp --output-format csv -d $O/pm -o pmc -- python tools/panel_w_probe.py 1682 64 256 > $O/pm.log 2>&1 || echo "group failed: $grp")
+    rm -rf $O/pm; (export TMPDIR=/tmp PROBE_ONLY=1; timeout 100 rocprofv3 --pmc $grp --output-format csv -d $O/pm -o pmc -- python tools/panel_w_probe.py 1682 64 256 v:panel_db=1 > $O/pm.log 2>&1 || echo "group failed: $grp")
     python3 - "$O" <<'PY'
 import csv, glob, sys, collections
 O = sys.argv[1]
@@ -201,6 +201,28 @@ final3)  # kernel stats of the other workloads, config-5 PMC, the torchrun / RCC
   python tools/show_stats.py $O | head -40
   GFHIP_EXPERIMENTS=1 bash tools/pmc_collect.sh cfg5 ev_hop_lds4_kernel r04 > $O/pmc_cfg5.log 2>&1; tail -1 $O/pmc_cfg5.log | cut -c1-300; cp gpurun_out/pmc_cfg5/r04_cfg5_pmc.json $O/ 2>/dev/null
   timeout 600 bash tools/scale.sh cfg4 1 > $O/scale.log 2>&1; tail -6 $O/scale.log; mkdir -p $O/scale; cp gpurun_out/scale/cfg4_*.json $O/scale/ 2>/dev/null
+  ;;
+pwc)     # counters of the double-buffered panel kernel (the default at N = 1682), tap-stack mode
+  export PROBE_KHOP=1
+  for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" \
+             "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" \
+             "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+    rm -rf $O/pm; (export TMPDIR=/tmp PROBE_ONLY=1; timeout 100 rocprofv3 --pmc $grp --output-format csv -d $O/pm -o pmc -- python tools/panel_w_probe.py 1682 64 256 v:panel_db=1 > $O/pm.log 2>&1 || echo "group failed: $grp")
+    python3 - "$O" <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"{O}/pm/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "spmm_panel" in r["Kernel_Name"]:
+            agg[(r["Kernel_Name"].split("<")[0].split("::")[-1], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (kn, k), v in sorted(agg.items()):
+    print(f"{kn:24s} {k:36s} {sum(v)/len(v):16.0f}  ({len(v)} launches)")
+PY
+  done 2>&1 | tee $O/panel_db_counters.log
+  rm -rf $O/pm
   ;;
 swbar)  # XCD barriers: time and hit rate vs barriers per batch entry
   V="v:spmm_algo=3"; for l in ${LAGS:-0 1 2 4}; do V="$V v:spmm_algo=4+spmm_lag=$l"; done
