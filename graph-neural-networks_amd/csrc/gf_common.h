@@ -68,28 +68,15 @@ struct gf_csr_dev {
     int32_t* sell_col = nullptr;    // uniform values only: the columns of sell_ent alone, padding = -1 (half the entry stream)
     int32_t sell_uniform = 0;       // every stored value equals sell_uval
     float sell_uval = 0.f;
-    // STREAM image (gf_stream_image.h, round 4): the same scheduled rows as runs of 32 in-band steps for spmm_stream_kernel (long-lived
-    // waves, W = 32); slices longer than a run (hub rows) stay in a residual SELL image that spmm_sell_kernel serves.
-    int32_t st_runs = 0;            // 0 = no stream image
-    uint4* st_ent = nullptr;        // [st_runs][64 lanes]: lane (g, i) holds steps 4i .. 4i+3 of lane group g
-    float4* st_val = nullptr;       // same shape, weighted GSOs only
-    uint32_t* st_last = nullptr;    // [st_runs]  LAST mask of the run (bit u: step u ends a slice)
-    uint2* st_rows = nullptr;       // [st_runs][64 lanes]  output rows: lane (g, i) = rows of lane group g in slices i, i + 8 of the run
-    uint32_t* st_ctr = nullptr;     // [kStreamCtrSlots][8 XCDs][kStreamCtrPerXcd][kStreamCtrStride]: ticket counters, one slot per launch in rotation (zeroed by a memset node)
-    double st_pad = 0.0;            // padding steps / all steps (diagnostic)
-    int32_t st_pf_runs = 0;         // prefetch runs among st_runs (graphs with locality)
-    int32_t hub_slices = 0;         // residual SELL image: slices of more than 31 steps
-    int32_t* hub_kptr = nullptr;
-    int2* hub_ent = nullptr;
-    int32_t* hub_col = nullptr;     // uniform values only
-    int32_t* hub_rowid = nullptr;
-    // SWEEP image (gf_sweep_image.h, round 4): the source sweep with register-resident partial sums (spmm_sweep_kernel); uniform GSOs,
-    // N <= 131071, built when the row lists balance (fill >= 0.8: no hub rows)
-    int32_t sw_passes = 0, sw_steps = 0;
-    uint32_t* sw_ent = nullptr;     // [512 waves][sw_passes][sw_steps + 8]  entries (byte offset of the source row << 8 | slot)
-    uint32_t* sw_rows = nullptr;    // [512 waves][sw_passes][100 slots]     output byte offset of the slot's row
-    uint32_t* sw_gate = nullptr;    // [8 XCDs][34 x 16] barrier counters
-    double sw_fill = 0.0;
+    // MSWEEP image (gf_msweep_image.h, round 5): the source sweep with the partial sums of a batch entry in the XCD's registers and an
+    // fp32 MFMA as scatter-accumulate (spmm_msweep_kernel); built for graphs whose gather panel does not fit an XCD's L2
+    int32_t ms_sets = 0, ms_passes = 0, ms_rounds = 0;   // 0 = no image
+    int32_t ms_uniform = 0;
+    uint32_t* ms_ent = nullptr;     // [passes][128 waves][rounds + 2][8 positions][sets rounded up to 4]
+    float* ms_val = nullptr;        // same shape (weighted GSOs only)
+    uint32_t* ms_rows = nullptr;    // [passes][128 waves][sets][32]  output byte offsets
+    uint32_t* ms_gate = nullptr;    // XCD barrier counters, one slot per launch in rotation
+    double ms_fill = 0.0;
     // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes.  Work unit = OCTET (8 consecutive rows = one 128-byte
     // line of a column panel); octets are sorted by their longest row and a slice = 8 octets = one wavefront (lane l handles
     // row pn_oct[8s + l/8] * 8 + l%8), so the rows a wave walks together have similar lengths and every octet still stores a
@@ -141,10 +128,6 @@ constexpr int kChainBigW = GF_CHAIN_BIGW, kChainStorers = GF_CHAIN_STORERS;
 constexpr int32_t kPanelMaxNodes = 10239;   // 16 bytes per node + one zero slot in 160 KiB of LDS
 constexpr int32_t kPanelMaxDeg = 65535;
 
-constexpr int32_t kStreamCtrSlots = 16;      // launches whose ticket counters may be live at once (slots rotate)
-constexpr int32_t kStreamCtrPerXcd = 16;    // counters per XCD: one word serves ~30-90 returning atomics per microsecond
-constexpr int32_t kStreamCtrStride = 64;    // words between counters (256 bytes: a line of its own)
-
 struct gf_plan {
     int32_t n = 0;
     int64_t nnz = 0;
@@ -162,14 +145,11 @@ struct gf_tuning {
     int spmm_bt = 0;            // 0 = heuristic, else 1 / 2 / 4 batch entries per lane
     int spmm_spw = 0;           // 0 = default (2), else 1 / 2 / 4 consecutive slices per wave
     int spmm_generic = 0;       // 1 = force the generic one-thread-per-element kernel
-    int spmm_algo = 0;          // 0 = heuristic (stream kernel for W = 32 on large graphs, else SELL-8), 1 = CSR workgroup-staged kernel (first
-                                // version), 2 = stream kernel wherever it applies, 3 = SELL-8 always
-    int spmm_sd = 0;            // stream kernel: gathers in flight per lane, 0 = default, 8 | 16
-    int spmm_wps = 0;           // stream kernel: waves per SIMD, 0 = default, 4 | 6 | 8
-    int spmm_tk = -1;           // stream kernel: run hand-out, -1 = default, 0 = static stride, 1 = vector atomic, 2 = scalar atomic
-    int spmm_nc = 0;            // stream kernel: ticket counters per XCD, 0 = default, 1 .. 16
-    int spmm_lag = 1;           // sweep kernel: XCD barriers per pass of an entry pair (>= 1)
-    int spmm_spf = 0;           // stream image: prefetch runs for units whose new source rows are few, this many units ahead; 0 = none (set BEFORE gf_plan_create)
+    int spmm_algo = 0;          // 0 = default (the MFMA source sweep where gf_msweep_applicable says so, else SELL-8), 1 = CSR workgroup-staged kernel
+                                // (first version), 3 = SELL-8 always, 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED
+    int spmm_bar = 1;           // MFMA sweep: XCD barrier between batch entries (0 = free-running waves)
+    int spmm_srcmask = 0;       // MFMA sweep, timing experiments only (results wrong): AND mask on the gathered source offsets (confines them to a window)
+    int spmm_slack = 10;        // MFMA sweep image: rounds beyond the mean group length, in percent (set BEFORE gf_plan_create)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
     int spmm_ucap = 0;          // 0/16 = up to 16 gathers in flight per lane, 8 = up to 8 (fewer registers, more waves)
     int spmm_pf = -1;           // workgroups per tile that prefetch the next tile's gather panel into L2 (-1 = heuristic, 0 = off)
@@ -203,8 +183,10 @@ struct gf_tuning {
 extern gf_tuning g_tune;
 
 // internal launchers shared between translation units
-bool gf_sweep_applicable(const gf_csr_dev& m, int N, int B, int W);
-int gf_sweep_launch(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st);
+bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W);
+int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st);
+size_t gf_msweep_gate_bytes();
+constexpr int32_t kMsMinNodes = 32768;      // below: a batch entry's rows (N x 128 bytes) fit the 4 MiB L2 of an XCD and SELL-8 hits anyway
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
                        int F, int E, int K, int transpose_bank, hipStream_t st, int out_rows = 0, const float* mask = nullptr);
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)

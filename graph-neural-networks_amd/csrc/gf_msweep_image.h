@@ -1,0 +1,234 @@
+// gf_msweep_image.h -- host-side builder of the MSWEEP image (pure C++: gf_plan.hip uploads it, tools/msweep_image_check.cpp
+// interprets it on the CPU the way spmm_msweep_kernel executes it).
+//
+// What the image is for (round 5).  A node-major hop (graphML.py:158-161, one `x = torch.matmul(x, S)`) at N = 1e5
+// re-gathers every 128-byte signal row ~10 times; an XCD's 4 MiB L2 holds a third of a batch entry's 12.8 MB of rows, so a row-by-row
+// kernel misses on 58 % of its gathers.  The misses go away when all waves of an XCD walk the SOURCE rows together: a row is then
+// fetched over the fabric once and its other ~9 uses hit L2.  A wave that walks sources must keep the partial sums of ALL its
+// destination rows to the end -- 12.8 MB per batch entry, which only the XCD's register files hold (32 CUs x 512 KB) -- and must add
+// each gathered row to an accumulator that the DATA selects.  Round 4's sweep selected it by relative register indexing and was bound
+// by the scalar instructions that takes.  Here the selection is an MFMA operand:
+//
+//   v_mfma_f32_4x4x1_16b_f32   D_b[i][j] += A_b[i] * B_b[j]     16 blocks b = lane / 4, i = accumulator register 0..3, j = lane % 4
+//
+//   * a gather instruction loads 8 source rows (lane = 8 * position + fg, 16 bytes per lane: the four VGPRs hold features 4 fg + v);
+//     VGPR v is the B operand of MFMA v: position p feeds blocks 2p and 2p + 1, i.e. the 8 lanes of position p again;
+//   * the A operand is ONE VGPR: the edge weight in the lanes whose i = lane % 4 equals the destination SLOT, zero elsewhere.  The four
+//     MFMAs of a step add the gathered row of position p to slot i of position p in one accumulator SET (4 x 4 registers): a set holds
+//     8 positions x 4 slots = 32 destination rows x 32 features.  The slot is data; the set is code (static registers);
+//   * a wave owns S sets (S = 25: 800 rows, 400 of its 512 registers), an XCD's 128 waves (one per SIMD) own 102 400 rows: one batch
+//     entry in one pass.  The wave's program is T ROUNDS of S steps: round t, step s serves set s.  The group of 4 destination rows
+//     behind (set, position) lists the (source, slot) pairs of its rows sorted by source and spreads them over the T rounds so that
+//     round t holds sources near t * N / T: every wave of the XCD is at the same place of the source range at the same time, whatever
+//     set it is serving.  Rows are dealt to the groups by degree so that all groups hold (almost) the same number of entries;
+//   * fp32 MFMA is an exact fmaf chain and the rounds visit a row's sources in ascending order: bit for bit the sums of spmm_sell_kernel.
+//
+// Entry word (32 bits): bits 7..31 = byte offset of the source row inside the tap (row * 128), bits 0..3 = one-hot slot; a gap is
+// kMsPad: an offset beyond the tap (the buffer load's range check returns zeros without a memory request) and no slot bit.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <queue>
+#include <vector>
+
+constexpr int32_t kMsDepth = 5;                      // gather steps in flight per wave (ring of kMsDepth x 4 registers)
+constexpr int32_t kMsWavesPerXcd = 128;              // 32 CUs x 4 SIMDs x one 512-register wave
+constexpr int32_t kMsMaxSets = 25;                   // accumulator sets per wave: 25 x 16 = 400 registers
+constexpr uint32_t kMsPad = 0xffffff80u;             // entry of a gap / row offset of a slot without a row
+constexpr int32_t kMsMaxRounds = 4096;
+
+struct MsweepImage {
+    int32_t sets = 0;                                // S: 10, 15, 20 or 25 (a multiple of kMsDepth)
+    int32_t s4 = 0;                                  // S rounded up to a multiple of 4 (entries of a position are loaded 4 at a time)
+    int32_t passes = 0;                              // ceil(groups / (128 * S * 8)); one pass = one sweep of the sources per batch entry
+    int32_t rounds = 0;                              // T; the streams hold T + 2 rounds (the kernel's entry loads run two rounds ahead)
+    std::vector<uint32_t> ent;                       // [passes][128 waves][T + 2][8 positions][s4]
+    std::vector<float> val;                          // same shape, weighted GSOs only (empty when uniform)
+    std::vector<uint32_t> rows;                      // [passes][128 waves][S][32]  output byte offset (row * 128) of (set, position * 4 + slot), kMsPad = none
+    int64_t real_entries = 0;                        // fill = real_entries / (passes * 128 * S * 8 * T)
+    double fill() const { return passes ? (double)real_entries / ((double)passes * kMsWavesPerXcd * sets * 8 * rounds) : 0.0; }
+    size_t stream_words() const { return (size_t)(rounds + 2) * 8 * s4; }   // per (pass, wave)
+};
+
+// rowptr / col / val: CSR of the operator in ORIGINAL row order, columns ascending inside a row.  uniform: the values are not stored
+// (the kernel sums the gathered rows and scales once, as spmm_sell_kernel<UNI = 1> does).  slack_pct: rounds beyond the longest
+// group, in percent of the mean group length -- the room the placement has to keep round ~ source (12-20 % measured best).
+inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const int32_t* col, const float* val, bool uniform,
+                                      int32_t slack_pct = 15, int32_t max_passes = 1) {
+    MsweepImage im;
+    if (n <= 0 || (int64_t)n * 128 >= (int64_t)kMsPad) return im;
+    const int32_t groups = (n + 3) / 4;
+    // sets per wave: the smallest geometry that holds every group in max_passes passes
+    int32_t S = 0;
+    for (int32_t s = 2 * kMsDepth; s <= kMsMaxSets; s += kMsDepth)   // (the kernel reloads an entry quad a round ahead: >= 10 steps per round)
+        if ((int64_t)max_passes * kMsWavesPerXcd * s * 8 >= groups) { S = s; break; }
+    if (!S) return im;
+    const int32_t passes = (int32_t)((groups + (int64_t)kMsWavesPerXcd * S * 8 - 1) / ((int64_t)kMsWavesPerXcd * S * 8));
+    // rows -> groups of 4: longest row first, each to the group with the fewest entries so far that still has a free slot (the
+    // first `groups` rows seed one group each): every group ends with (almost) the same entry total -- the longest one sets T
+    std::vector<int32_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b]; });
+    std::vector<int32_t> grow((size_t)groups * 4, -1);
+    std::vector<int32_t> glen(groups, 0), gcnt(groups, 0);
+    {
+        std::priority_queue<std::pair<int32_t, int32_t>, std::vector<std::pair<int32_t, int32_t>>, std::greater<std::pair<int32_t, int32_t>>> open;
+        for (int32_t i = 0; i < n; ++i) {
+            const int32_t r = order[i], d = rowptr[r + 1] - rowptr[r];
+            int32_t g;
+            if (i < groups) g = i;
+            else {
+                g = open.top().second;
+                open.pop();
+            }
+            grow[(size_t)g * 4 + gcnt[g]++] = r;
+            glen[g] += d;
+            if (gcnt[g] < 4) open.push({glen[g], g});
+        }
+    }
+    int64_t total = 0;
+    int32_t longest = 0;
+    for (int32_t g = 0; g < groups; ++g) total += glen[g], longest = std::max(longest, glen[g]);
+    const double mean = (double)total / groups;
+    int32_t T = std::max(longest, (int32_t)std::ceil(mean * (100 + slack_pct) / 100.0));
+    T = std::max(T, 1);
+    if (T > kMsMaxRounds) return im;
+    im.sets = S;
+    im.s4 = (S + 3) / 4 * 4;
+    im.passes = passes;
+    im.rounds = T;
+    im.real_entries = total;
+    const size_t sw = im.stream_words();
+    im.ent.assign((size_t)passes * kMsWavesPerXcd * sw, kMsPad);
+    if (!uniform) im.val.assign(im.ent.size(), 0.f);
+    im.rows.assign((size_t)passes * kMsWavesPerXcd * S * 32, kMsPad);
+    // groups -> (pass, wave, set, position): consecutive groups go to consecutive WAVES first, then positions, then sets, then passes
+    struct Ent { int32_t src; int32_t slot; float v; };
+    std::vector<Ent> list;
+    std::vector<int32_t> f, bk;
+    for (int32_t g = 0; g < groups; ++g) {
+        const int32_t wave = g % kMsWavesPerXcd;
+        const int32_t rest = g / kMsWavesPerXcd;
+        const int32_t p = rest % 8, set = (rest / 8) % S, pass = rest / (8 * S);
+        list.clear();
+        for (int32_t slot = 0; slot < 4; ++slot) {
+            const int32_t r = grow[(size_t)g * 4 + slot];
+            if (r < 0) continue;
+            im.rows[(((size_t)pass * kMsWavesPerXcd + wave) * S + set) * 32 + p * 4 + slot] = (uint32_t)r << 7;
+            for (int32_t q = rowptr[r]; q < rowptr[r + 1]; ++q) list.push_back({col[q], slot, uniform ? 1.f : val[q]});
+        }
+        std::stable_sort(list.begin(), list.end(), [](const Ent& x, const Ent& y) { return x.src < y.src; });
+        const int32_t L = (int32_t)list.size();
+        // placement: round ~ source * T / n, strictly increasing.  f = earliest-feasible walk from the front (>= ideal), bk = latest-
+        // feasible walk from the back (<= ideal), both clamped to [k, T - (L - k)]; their midpoint is strictly increasing and halves the
+        // displacement of either.
+        f.resize(L);
+        bk.resize(L);
+        int32_t prev = -1;
+        for (int32_t k = 0; k < L; ++k) {
+            const int32_t ideal = (int32_t)((int64_t)list[k].src * T / n);
+            prev = std::max(ideal, prev + 1);
+            f[k] = prev;
+        }
+        int32_t nxt = T;
+        for (int32_t k = L - 1; k >= 0; --k) {
+            nxt = std::min(f[k], nxt - 1);
+            f[k] = nxt;
+        }
+        nxt = T;
+        for (int32_t k = L - 1; k >= 0; --k) {
+            const int32_t ideal = (int32_t)((int64_t)list[k].src * T / n);
+            nxt = std::min(ideal, nxt - 1);
+            bk[k] = nxt;
+        }
+        prev = -1;
+        for (int32_t k = 0; k < L; ++k) {
+            prev = std::max(bk[k], prev + 1);
+            bk[k] = prev;
+        }
+        uint32_t* e = im.ent.data() + ((size_t)pass * kMsWavesPerXcd + wave) * sw;
+        float* v = uniform ? nullptr : im.val.data() + ((size_t)pass * kMsWavesPerXcd + wave) * sw;
+        for (int32_t k = 0; k < L; ++k) {
+            const int32_t t = (f[k] + bk[k]) >> 1;
+            const size_t at = ((size_t)t * 8 + p) * im.s4 + set;
+            e[at] = ((uint32_t)list[k].src << 7) | (1u << list[k].slot);
+            if (v) v[at] = list[k].v;
+        }
+    }
+    return im;
+}
+
+// What spmm_msweep_kernel computes for ONE batch entry, in its own order of operations (per accumulator: fmaf in round order; the
+// slots a step does not address see fmaf(0, x, acc) = acc).  uniform: sum, then scale once by uval.
+inline void interpret_msweep_image(const MsweepImage& im, bool uniform, float uval, const float* X, float* Y, int32_t W) {
+    const size_t sw = im.stream_words();
+    std::vector<float> acc((size_t)im.sets * 32 * W);
+    for (int32_t pass = 0; pass < im.passes; ++pass)
+        for (int32_t wave = 0; wave < kMsWavesPerXcd; ++wave) {
+            std::fill(acc.begin(), acc.end(), 0.f);
+            const uint32_t* e = im.ent.data() + ((size_t)pass * kMsWavesPerXcd + wave) * sw;
+            const float* v = uniform ? nullptr : im.val.data() + ((size_t)pass * kMsWavesPerXcd + wave) * sw;
+            for (int32_t t = 0; t < im.rounds + 2; ++t)
+                for (int32_t s = 0; s < im.sets; ++s)
+                    for (int32_t p = 0; p < 8; ++p) {
+                        const size_t at = ((size_t)t * 8 + p) * im.s4 + s;
+                        const uint32_t w = e[at];
+                        if (!(w & 15u)) continue;
+                        const float a = uniform ? 1.f : v[at];
+                        const float* x = X + (size_t)(w >> 7) * W;
+                        for (int32_t slot = 0; slot < 4; ++slot)
+                            if (w & (1u << slot)) {
+                                float* d = acc.data() + ((size_t)s * 32 + p * 4 + slot) * W;
+                                for (int32_t k = 0; k < W; ++k) d[k] = fmaf(a, x[k], d[k]);
+                            }
+                    }
+            for (int32_t s = 0; s < im.sets; ++s)
+                for (int32_t j = 0; j < 32; ++j) {
+                    const uint32_t ro = im.rows[(((size_t)pass * kMsWavesPerXcd + wave) * im.sets + s) * 32 + j];
+                    if (ro == kMsPad) continue;
+                    const float* d = acc.data() + ((size_t)s * 32 + j) * W;
+                    for (int32_t k = 0; k < W; ++k) Y[(size_t)(ro >> 7) * W + k] = uniform ? d[k] * uval : d[k];
+                }
+        }
+}
+
+// Diagnostic: L2 hit rate of the row gathers of one batch entry if the XCD's 128 waves advance in lock step (round by round, set by
+// set) and the L2 is an LRU cache of `lines` 128-byte lines; the entry stream's own lines pass through the same cache.
+inline double simulate_msweep_hits(const MsweepImage& im, int32_t n, int32_t lines) {
+    const size_t sw = im.stream_words();
+    std::vector<int64_t> stamp(n, -1);               // time of the row's last use while it is resident, -1 = not resident
+    std::vector<std::pair<int64_t, int32_t>> fifo;   // (stamp, row) in time order; stale pairs (stamp changed since) are skipped at eviction
+    size_t head = 0;
+    int64_t resident = 0, now = 0, hits = 0, misses = 0;
+    auto evict = [&]() {
+        while (resident > lines && head < fifo.size()) {
+            const auto [t, r] = fifo[head++];
+            if (r < 0) { --resident; continue; }     // a line of the entry stream
+            if (stamp[r] == t) stamp[r] = -1, --resident;
+        }
+    };
+    const int64_t stream_per_round = (int64_t)kMsWavesPerXcd * 8 * im.s4 * 4 / 128;
+    for (int32_t pass = 0; pass < im.passes; ++pass)
+        for (int32_t t = 0; t < im.rounds; ++t) {
+            for (int64_t i = 0; i < stream_per_round; ++i) fifo.push_back({++now, -1}), ++resident;
+            for (int32_t s = 0; s < im.sets; ++s)
+                for (int32_t wave = 0; wave < kMsWavesPerXcd; ++wave) {
+                    const uint32_t* e = im.ent.data() + ((size_t)pass * kMsWavesPerXcd + wave) * sw;
+                    for (int32_t p = 0; p < 8; ++p) {
+                        const uint32_t w = e[((size_t)t * 8 + p) * im.s4 + s];
+                        if (!(w & 15u)) continue;
+                        const int32_t r = (int32_t)(w >> 7);
+                        if (stamp[r] >= 0) ++hits;
+                        else ++misses, ++resident;
+                        stamp[r] = ++now;
+                        fifo.push_back({now, r});
+                    }
+                }
+            evict();
+        }
+    return hits + misses ? (double)hits / (double)(hits + misses) : 0.0;
+}

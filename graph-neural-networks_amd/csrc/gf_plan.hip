@@ -15,8 +15,7 @@
 #include <vector>
 
 #include "gf_common.h"
-#include "gf_stream_image.h"
-#include "gf_sweep_image.h"
+#include "gf_msweep_image.h"
 
 // ---------------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -64,12 +63,9 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_spw")) g_tune.spmm_spw = value;
     else if (!strcmp(key, "spmm_generic")) g_tune.spmm_generic = value;
     else if (!strcmp(key, "spmm_algo")) g_tune.spmm_algo = value;
-    else if (!strcmp(key, "spmm_sd")) g_tune.spmm_sd = value;
-    else if (!strcmp(key, "spmm_wps")) g_tune.spmm_wps = value;
-    else if (!strcmp(key, "spmm_tk")) g_tune.spmm_tk = value;
-    else if (!strcmp(key, "spmm_nc")) g_tune.spmm_nc = value;
-    else if (!strcmp(key, "spmm_spf")) g_tune.spmm_spf = value;
-    else if (!strcmp(key, "spmm_lag")) g_tune.spmm_lag = value;
+    else if (!strcmp(key, "spmm_bar")) g_tune.spmm_bar = value;
+    else if (!strcmp(key, "spmm_srcmask")) g_tune.spmm_srcmask = value;
+    else if (!strcmp(key, "spmm_slack")) g_tune.spmm_slack = value;
     else if (!strcmp(key, "spmm_xcd")) g_tune.spmm_xcd = value;
     else if (!strcmp(key, "spmm_store")) g_tune.spmm_store = value;
     else if (!strcmp(key, "spmm_load")) g_tune.spmm_load = value;
@@ -329,22 +325,17 @@ std::vector<int32_t> locality_groups_cached(int32_t n, const HostCsr& a, int32_t
     return label;
 }
 
-// units: scheduled positions at which a locality group / sort window begins (the stream image packs each unit on its own)
 void schedule(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32_t>* groups, HostCsr& s, std::vector<int32_t>& rowid,
-              int32_t& max_deg, std::vector<int32_t>& units) {
+              int32_t& max_deg) {
     rowid.resize(n);
     std::iota(rowid.begin(), rowid.end(), 0);
-    units.clear();
     if (sorted && groups && (int32_t)groups->size() == n) {
         const std::vector<int32_t>& label = *groups;
         std::stable_sort(rowid.begin(), rowid.end(), [&](int32_t x, int32_t y) {
             if (label[x] != label[y]) return label[x] < label[y];
             return (a.rowptr[x + 1] - a.rowptr[x]) > (a.rowptr[y + 1] - a.rowptr[y]);
         });
-        for (int32_t p = 0; p < n; ++p)
-            if (p == 0 || label[rowid[p]] != label[rowid[p - 1]]) units.push_back(p);
     } else if (sorted) {
-        for (int32_t w0 = 0; w0 < n; w0 += kScheduleWindow) units.push_back(w0);
         for (int32_t w0 = 0; w0 < n; w0 += kScheduleWindow) {
             const int32_t w1 = std::min(n, w0 + kScheduleWindow);
             std::stable_sort(rowid.begin() + w0, rowid.begin() + w1, [&](int32_t x, int32_t y) {
@@ -381,8 +372,8 @@ int upload_panel(int32_t n, const HostCsr& a, gf_csr_dev& d, int64_t& bytes);
 
 int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32_t>* groups, gf_csr_dev& d, int64_t& bytes) {
     HostCsr s;
-    std::vector<int32_t> rowid, units;
-    schedule(n, a, sorted, groups, s, rowid, d.max_deg, units);
+    std::vector<int32_t> rowid;
+    schedule(n, a, sorted, groups, s, rowid, d.max_deg);
     int rc;
     if ((rc = upload(s.rowptr, &d.rowptr, bytes))) return rc;
     if ((rc = upload(s.col, &d.col, bytes))) return rc;
@@ -426,73 +417,21 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
             }
         if ((rc = upload(colv, &d.sell_col, bytes))) return rc;
     }
-    // STREAM image (gf_stream_image.h): 24-bit row numbers in store steps, 32-bit byte offsets of 128-byte rows in the kernel
-    if (n < (1 << 24) && (int64_t)n * 128 < (int64_t)kStreamNothing) {
-        StreamImage im = build_stream_image(n, s.rowptr.data(), s.col.data(), s.val.data(), rowid.data(), units.empty() ? nullptr : &units, g_tune.spmm_spf);
-        d.st_runs = im.n_runs;
-        d.st_pf_runs = im.pf_runs;
-        d.st_pad = im.n_runs ? (double)im.pad_steps / ((double)im.n_runs * kStreamRun) : 0.0;
-        if (im.n_runs) {
-            static_assert(sizeof(uint4) == 16 && sizeof(float4) == 16, "run layout");
-            GF_HIP(hipMalloc((void**)&d.st_ent, im.ent.size() * 4));
-            GF_HIP(hipMemcpy(d.st_ent, im.ent.data(), im.ent.size() * 4, hipMemcpyHostToDevice));
-            bytes += (int64_t)im.ent.size() * 4;
-            if (!uni) {
-                GF_HIP(hipMalloc((void**)&d.st_val, im.val.size() * 4));
-                GF_HIP(hipMemcpy(d.st_val, im.val.data(), im.val.size() * 4, hipMemcpyHostToDevice));
-                bytes += (int64_t)im.val.size() * 4;
-            }
-            GF_HIP(hipMalloc((void**)&d.st_last, im.last.size() * 4));
-            GF_HIP(hipMemcpy(d.st_last, im.last.data(), im.last.size() * 4, hipMemcpyHostToDevice));
-            GF_HIP(hipMalloc((void**)&d.st_rows, im.rows.size() * 4));
-            GF_HIP(hipMemcpy(d.st_rows, im.rows.data(), im.rows.size() * 4, hipMemcpyHostToDevice));
-            bytes += (int64_t)(im.last.size() + im.rows.size()) * 4;
-            GF_HIP(hipMalloc((void**)&d.st_ctr, (size_t)kStreamCtrSlots * 8 * kStreamCtrPerXcd * kStreamCtrStride * 4));
-            GF_HIP(hipMemset(d.st_ctr, 0, (size_t)kStreamCtrSlots * 8 * kStreamCtrPerXcd * kStreamCtrStride * 4));
-        }
-        // residual SELL image of the slices that do not fit a run
-        const int32_t nh = (int32_t)im.hub_slices.size();
-        d.hub_slices = nh;
-        if (nh) {
-            std::vector<int32_t> hk(nh + 1, 0), hr((size_t)nh * 8, -1);
-            for (int32_t i = 0; i < nh; ++i) hk[i + 1] = hk[i] + (kptr[im.hub_slices[i] + 1] - kptr[im.hub_slices[i]]);
-            std::vector<int2> he((size_t)hk[nh] * 8);
-            for (int32_t i = 0; i < nh; ++i) {
-                const int32_t sl = im.hub_slices[i];
-                std::copy(ent.begin() + (size_t)kptr[sl] * 8, ent.begin() + (size_t)kptr[sl + 1] * 8, he.begin() + (size_t)hk[i] * 8);
-                std::copy(rid.begin() + (size_t)sl * 8, rid.begin() + (size_t)sl * 8 + 8, hr.begin() + (size_t)i * 8);
-            }
-            if ((rc = upload(hk, &d.hub_kptr, bytes))) return rc;
-            if ((rc = upload(he, &d.hub_ent, bytes))) return rc;
-            if ((rc = upload(hr, &d.hub_rowid, bytes))) return rc;
-            if (uni) {
-                std::vector<int32_t> hc(he.size(), -1);
-                for (int32_t i = 0; i < nh; ++i) {
-                    const int32_t sl = im.hub_slices[i];
-                    for (int32_t r = 0; r < 8 && sl * 8 + r < n; ++r) {
-                        const int32_t p = sl * 8 + r;
-                        for (int32_t q = s.rowptr[p]; q < s.rowptr[p + 1]; ++q) hc[((size_t)hk[i] + (q - s.rowptr[p])) * 8 + r] = s.col[q];
-                    }
-                }
-                if ((rc = upload(hc, &d.hub_col, bytes))) return rc;
-            }
-        }
-    }
-    // SWEEP image (gf_sweep_image.h): uniform GSOs on graphs whose gather panel does not fit L2, when the row lists balance
-    if (uni && n > kPanelMaxNodes && n <= kSweepMaxNodes) {
-        SweepImage sw = build_sweep_image(n, a.rowptr.data(), a.col.data());
-        const double fill = (double)sw.real_entries / ((double)sw.passes * kSweepWavesPerXcd * sw.steps);
-        d.sw_fill = fill;
-        if (fill >= 0.8 || (sw.steps <= 4 * kSweepBlock && fill >= 0.5)) {   // (short lists: the rounding to 64 steps is most of the padding)
-            d.sw_passes = sw.passes;
-            d.sw_steps = sw.steps;
-            GF_HIP(hipMalloc((void**)&d.sw_ent, sw.ent.size() * 4));
-            GF_HIP(hipMemcpy(d.sw_ent, sw.ent.data(), sw.ent.size() * 4, hipMemcpyHostToDevice));
-            GF_HIP(hipMalloc((void**)&d.sw_rows, sw.rows.size() * 4));
-            GF_HIP(hipMemcpy(d.sw_rows, sw.rows.data(), sw.rows.size() * 4, hipMemcpyHostToDevice));
-            GF_HIP(hipMalloc((void**)&d.sw_gate, 8 * 34 * 16 * 4));
-            GF_HIP(hipMemset(d.sw_gate, 0, 8 * 34 * 16 * 4));
-            bytes += (int64_t)(sw.ent.size() + sw.rows.size()) * 4;
+    // MSWEEP image (gf_msweep_image.h): graphs whose gather panel does not fit L2, when the groups balance (no hub rows)
+    if (n >= kMsMinNodes) {
+        MsweepImage ms = build_msweep_image(n, a.rowptr.data(), a.col.data(), a.val.data(), uni, g_tune.spmm_slack, 1);
+        d.ms_fill = ms.fill();
+        if (ms.passes == 1 && ms.fill() >= 0.6) {
+            d.ms_sets = ms.sets;
+            d.ms_passes = ms.passes;
+            d.ms_rounds = ms.rounds;
+            d.ms_uniform = uni ? 1 : 0;
+            if ((rc = upload(ms.ent, &d.ms_ent, bytes))) return rc;
+            if (!uni && (rc = upload(ms.val, &d.ms_val, bytes))) return rc;
+            if ((rc = upload(ms.rows, &d.ms_rows, bytes))) return rc;
+            GF_HIP(hipMalloc((void**)&d.ms_gate, gf_msweep_gate_bytes()));
+            GF_HIP(hipMemset(d.ms_gate, 0, gf_msweep_gate_bytes()));
+            bytes += (int64_t)gf_msweep_gate_bytes();
         }
     }
     return upload_panel(n, a, d, bytes);
@@ -725,18 +664,10 @@ void free_csr(gf_csr_dev& d) {
     if (d.sell_ent) (void)hipFree(d.sell_ent);
     if (d.sell_col) (void)hipFree(d.sell_col);
     if (d.sell_rowid) (void)hipFree(d.sell_rowid);
-    if (d.st_ent) (void)hipFree(d.st_ent);
-    if (d.st_val) (void)hipFree(d.st_val);
-    if (d.st_last) (void)hipFree(d.st_last);
-    if (d.st_rows) (void)hipFree(d.st_rows);
-    if (d.st_ctr) (void)hipFree(d.st_ctr);
-    if (d.sw_ent) (void)hipFree(d.sw_ent);
-    if (d.sw_rows) (void)hipFree(d.sw_rows);
-    if (d.sw_gate) (void)hipFree(d.sw_gate);
-    if (d.hub_kptr) (void)hipFree(d.hub_kptr);
-    if (d.hub_ent) (void)hipFree(d.hub_ent);
-    if (d.hub_col) (void)hipFree(d.hub_col);
-    if (d.hub_rowid) (void)hipFree(d.hub_rowid);
+    if (d.ms_ent) (void)hipFree(d.ms_ent);
+    if (d.ms_val) (void)hipFree(d.ms_val);
+    if (d.ms_rows) (void)hipFree(d.ms_rows);
+    if (d.ms_gate) (void)hipFree(d.ms_gate);
     if (d.pn_slice) (void)hipFree(d.pn_slice);
     if (d.pn_oct) (void)hipFree(d.pn_oct);
     if (d.pn_col4) (void)hipFree(d.pn_col4);

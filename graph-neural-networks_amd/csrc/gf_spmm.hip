@@ -31,9 +31,7 @@
 #include <type_traits>
 
 #include "gf_common.h"
-#include "gf_stream_image.h"
 #include <utility>
-#include <atomic>
 
 namespace {
 
@@ -279,191 +277,6 @@ __global__ __launch_bounds__(kThreads) void spmm_sell_kernel(const int32_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Kernel S (round 4) -- long-lived waves on the STREAM image (gf_stream_image.h): W = 32 (one 128-byte row per 8-lane group).
-//   A wave owns nothing and looks nothing up: it takes a ticket = one RUN of 32 steps = one coalesced 16-byte load per lane (+ the
-//   run's LAST mask, a scalar, and its output rows, 8 bytes per lane) and executes the steps back to back: the gather of step u + D is
-//   issued when the data of step u is consumed (ring of D float4 per lane, compile-time slots, exact vmcnt counts from the compiler),
-//   across run boundaries -- the next run is loaded a run ahead.  Per step: ds_swizzle (the entry of the step after next reaches its
-//   lane group through the LDS crossbar; no LDS memory, no barrier), v_or (byte offset | lane offset), buffer_load_dwordx4 (padding =
-//   an offset past the tap: the range check returns zeros), s_waitcnt, 2 x v_pk_add_f32, s_bitcmp1 + s_cbranch on the LAST mask.
-//   Output rows are stored by inline asm (a store the compiler can see makes it wait with vmcnt(0) for every later gather: loads and
-//   stores return out of order with each other; the hardware counter still counts the store, which only makes the compiler's waits
-//   for loads conservative).
-//   XCD x serves batch entries x % lanes + lanes * e in order, runs part, part + parts, ... (as kernel A).  Runs are handed out in
-//   schedule order -- TK = 2: a scalar atomic on one of NC counters of the XCD (counter c hands out tickets c, c + NC, ...; waited
-//   for on the spot: it is not a vector-memory operation, so the gathers in flight keep landing); TK = 0: wave w of the XCD's nW
-//   waves takes tickets w, w + nW, ... -- so the rows in flight are a narrow front of the schedule.
-// ------------------------------------------------------------------------------------------------------------------
-template <int SRC>
-__device__ __forceinline__ unsigned bcast8(unsigned v) {  // value of lane (lane & ~7) | SRC, within each group of 8 lanes
-    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x18 | (SRC << 5));   // bitmask mode: and = 0b11000, or = SRC, xor = 0
-}
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-template <int D, int UNI>
-struct StreamState {
-    u32x4 x[D];       // gathered rows in flight
-    float v[D];       // their values (weighted streams)
-    f32x2 a01, a23;   // running sum of the slice
-    unsigned epend;   // entry of the next step to issue (already swizzled)
-    float vpend;
-};
-
-// entry of stream position V (0 .. 31: current run, 32 ..: next run)
-template <int V>
-__device__ __forceinline__ unsigned stream_entry(const uint4& Ec, const uint4& En) {
-    const uint4& E = V < kStreamRun ? Ec : En;
-    constexpr int c = V & 3, src = (V & 31) >> 2;
-    return bcast8<src>(c == 0 ? E.x : c == 1 ? E.y : c == 2 ? E.z : E.w);
-}
-template <int V>
-__device__ __forceinline__ float stream_value(const float4& Vc, const float4& Vn) {
-    const float4& E = V < kStreamRun ? Vc : Vn;
-    constexpr int c = V & 3, src = (V & 31) >> 2;
-    return __uint_as_float(bcast8<src>(__float_as_uint(c == 0 ? E.x : c == 1 ? E.y : c == 2 ? E.z : E.w)));
-}
-
-// issue the gather of stream position V (its entry is st.epend), then fetch the entry of position V + 1
-template <int V, int D, int UNI>
-__device__ __forceinline__ void stream_issue(StreamState<D, UNI>& st, const uint4& Ec, const uint4& En, const float4& Vc, const float4& Vn,
-                                             __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rn, unsigned li16) {
-    constexpr int s = V % D;
-    st.x[s] = __builtin_amdgcn_raw_buffer_load_b128(V < kStreamRun ? rc : rn, (int)(st.epend | li16), 0, 0);
-    if constexpr (UNI == 0) st.v[s] = st.vpend;
-    st.epend = stream_entry<V + 1>(Ec, En);
-    if constexpr (UNI == 0) st.vpend = stream_value<V + 1>(Vc, Vn);
-}
-
-template <int U, int D, int UNI>
-__device__ __forceinline__ void stream_consume(StreamState<D, UNI>& st, unsigned last, const uint2& R, float* __restrict__ obase, unsigned lane,
-                                               unsigned li16, float uval) {
-    constexpr int s = U % D;
-    const f32x2 x01 = {__uint_as_float(st.x[s].x), __uint_as_float(st.x[s].y)}, x23 = {__uint_as_float(st.x[s].z), __uint_as_float(st.x[s].w)};
-    if constexpr (UNI != 0) {
-        asm("v_pk_add_f32 %0, %0, %1" : "+v"(st.a01) : "v"(x01));
-        asm("v_pk_add_f32 %0, %0, %1" : "+v"(st.a23) : "v"(x23));
-    } else {
-        const f32x2 vv = {st.v[s], st.v[s]};
-        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(st.a01) : "v"(x01), "v"(vv));
-        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(st.a23) : "v"(x23), "v"(vv));
-    }
-    if (last & (1u << U)) {   // wave-uniform: last step of a slice -> store its 8 rows, restart the sums
-        const int nth = __builtin_popcount(last & ((1u << U) - 1u));                       // which slice of the run
-        const unsigned mine = (nth & 8) ? R.y : R.x;
-        const unsigned row = (unsigned)__builtin_amdgcn_ds_bpermute((int)(((lane & 0x38u) | (unsigned)(nth & 7)) << 2), (int)mine);
-        if (row != kStreamNoRow) {
-            f32x4 d = {st.a01.x, st.a01.y, st.a23.x, st.a23.y};
-            if constexpr (UNI != 0) d *= uval;
-            const unsigned off = (row << 7) | li16;
-            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(obase) : "memory");
-        }
-        st.a01 = f32x2{0.f, 0.f};
-        st.a23 = f32x2{0.f, 0.f};
-    }
-}
-
-template <int D, int UNI, int... Us>
-__device__ __forceinline__ void stream_prologue(StreamState<D, UNI>& st, const uint4& Ec, const uint4& En, const float4& Vc, const float4& Vn,
-                                                __amdgpu_buffer_rsrc_t rc, unsigned li16, std::integer_sequence<int, Us...>) {
-    (stream_issue<Us, D, UNI>(st, Ec, En, Vc, Vn, rc, rc, li16), ...);
-}
-
-template <int D, int UNI, int... Us>
-__device__ __forceinline__ void stream_run(StreamState<D, UNI>& st, const uint4& Ec, const uint4& En, const float4& Vc, const float4& Vn,
-                                           __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rn, unsigned last, const uint2& R,
-                                           float* __restrict__ oc, unsigned lane, unsigned li16, float uval, std::integer_sequence<int, Us...>) {
-    ((stream_consume<Us, D, UNI>(st, last, R, oc, lane, li16, uval), stream_issue<Us + D, D, UNI>(st, Ec, En, Vc, Vn, rc, rn, li16)), ...);
-}
-
-template <int D, int WPS, int UNI, int TK>
-__global__ __launch_bounds__(kThreads, WPS) void spmm_stream_kernel(const uint4* __restrict__ ent4, const float4* __restrict__ val4,
-                                                                    const unsigned* __restrict__ lastm, const uint2* __restrict__ rows2,
-                                                                    const float* __restrict__ Xin, float* __restrict__ Xout, int N, int B,
-                                                                    int nRuns, int lanes, int parts, unsigned* __restrict__ counters,
-                                                                    int NC, float uval) {
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned li16 = (lane & 7) * 16u;
-    const int xcd = blockIdx.x & 7;
-    const int lane_t = xcd % lanes, part = xcd / lanes;
-    if (part >= parts || lane_t >= B) return;
-    const unsigned nE = (unsigned)(B - lane_t + lanes - 1) / (unsigned)lanes;            // batch entries of this XCD
-    const unsigned nRp = (unsigned)(nRuns - part + parts - 1) / (unsigned)parts;         // runs of this partition
-    const unsigned total = nE * nRp;
-    const unsigned wid = (blockIdx.x >> 3) * (kThreads / 64) + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave of this XCD
-    const unsigned nW = (gridDim.x >> 3) * (kThreads / 64);
-    const unsigned cidx = TK == 0 ? 0u : wid % (unsigned)NC;
-    const unsigned* ctr = counters + ((size_t)xcd * kStreamCtrPerXcd + cidx) * kStreamCtrStride;
-    const unsigned tapBytes = (unsigned)N * 128u;
-    unsigned tstatic = wid;
-
-    auto take = [&]() -> unsigned {
-        unsigned t;
-        if constexpr (TK == 0) {
-            t = tstatic;
-            tstatic += nW;
-        } else {
-            t = 1u;
-            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ctr) : "memory");
-            t = t * (unsigned)NC + cidx;
-        }
-        return t;
-    };
-    struct Tk { bool valid; unsigned run; size_t boff; };
-    auto decode = [&](unsigned t) -> Tk {
-        Tk k;
-        k.valid = t < total;
-        const unsigned tt = k.valid ? t : 0u;
-        const unsigned e = tt / nRp, r = tt - e * nRp;
-        k.run = (unsigned)part + (unsigned)parts * r;
-        k.boff = (size_t)((unsigned)lane_t + (unsigned)lanes * e) * (size_t)tapBytes;
-        return k;
-    };
-    const char* xin = reinterpret_cast<const char*>(Xin);
-    char* xout = reinterpret_cast<char*>(Xout);
-    auto rsrc = [&](const Tk& k) { return __builtin_amdgcn_make_buffer_rsrc((void*)(xin + k.boff), 0, (int)tapBytes, 0x00020000); };
-
-    Tk cur = decode(take());
-    if (!cur.valid) return;
-    Tk nxt = decode(take());
-
-    StreamState<D, UNI> st;
-    st.a01 = f32x2{0.f, 0.f};
-    st.a23 = f32x2{0.f, 0.f};
-    uint4 Ec = ent4[(size_t)cur.run * 64 + lane], En = ent4[(size_t)nxt.run * 64 + lane];
-    float4 Vc = make_float4(0.f, 0.f, 0.f, 0.f), Vn = Vc;
-    if constexpr (UNI == 0) {
-        Vc = val4[(size_t)cur.run * 64 + lane];
-        Vn = val4[(size_t)nxt.run * 64 + lane];
-    }
-    unsigned lastc = lastm[cur.run], lastn = lastm[nxt.run];
-    uint2 Rc = rows2[(size_t)cur.run * 64 + lane], Rn = rows2[(size_t)nxt.run * 64 + lane];
-    __amdgpu_buffer_rsrc_t rc = rsrc(cur), rn = rsrc(nxt);
-    st.epend = stream_entry<0>(Ec, En);
-    st.vpend = 0.f;
-    if constexpr (UNI == 0) st.vpend = stream_value<0>(Vc, Vn);
-    stream_prologue<D, UNI>(st, Ec, En, Vc, Vn, rc, li16, std::make_integer_sequence<int, D>{});
-    for (;;) {
-        // steps 0 .. 31 of cur; their issue side runs D steps ahead, into nxt (whose run is in registers already)
-        stream_run<D, UNI>(st, Ec, En, Vc, Vn, rc, rn, lastc, Rc, reinterpret_cast<float*>(xout + cur.boff), lane, li16, uval,
-                           std::make_integer_sequence<int, kStreamRun>{});
-        if (!nxt.valid) break;
-        cur = nxt;
-        Ec = En;
-        Vc = Vn;
-        lastc = lastn;
-        Rc = Rn;
-        rc = rn;
-        nxt = decode(take());
-        En = ent4[(size_t)nxt.run * 64 + lane];
-        if constexpr (UNI == 0) Vn = val4[(size_t)nxt.run * 64 + lane];
-        lastn = lastm[nxt.run];
-        Rn = rows2[(size_t)nxt.run * 64 + lane];
-        rn = rsrc(nxt);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // Kernel B: CSR, workgroup-staged segment
 // ------------------------------------------------------------------------------------------------------------------
 template <int LG, int BT>
@@ -657,59 +470,6 @@ int launch_sell(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B
     return GF_OK;
 }
 
-// Kernel S launcher: persistent grid (WPS workgroups of 4 waves per CU), ticket counters of this launch zeroed by a memset node in
-// front of it (capturable; slots rotate so that launches in flight on other streams do not share counters), then -- if the plan has
-// slices longer than a run -- kernel A on the residual SELL image (disjoint output rows).
-bool stream_applicable(const gf_csr_dev& m, int N, int B, int W) {
-    if (W != 32 || m.st_runs <= 0 || !m.st_ent || !m.st_ctr) return false;
-    if ((int64_t)N * 128 >= (int64_t)kStreamNothing) return false;                    // 32-bit byte offsets inside a tap, "nothing" past its end
-    const bool uni = m.sell_uniform && g_tune.panel_uniform;
-    if (!uni && !m.st_val) return false;
-    const int lanes = B >= 8 ? 8 : B;
-    return ((int64_t)((B + lanes - 1) / lanes) * m.st_runs) < ((int64_t)1 << 31);    // tickets fit 32 bits
-}
-
-int launch_stream(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st) {
-    static std::atomic<unsigned> next_slot{0};
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
-    const int lanes = B >= 8 ? 8 : B, parts = 8 / lanes;
-    unsigned* ctr = m.st_ctr + (size_t)(next_slot.fetch_add(1) % kStreamCtrSlots) * 8 * kStreamCtrPerXcd * kStreamCtrStride;
-    const bool uni = m.sell_uniform && g_tune.panel_uniform;
-    const int tk = g_tune.spmm_tk == 0 ? 0 : 2;
-    const int nc = (g_tune.spmm_nc >= 1 && g_tune.spmm_nc <= kStreamCtrPerXcd) ? g_tune.spmm_nc : kStreamCtrPerXcd;
-    if (tk != 0) GF_HIP(hipMemsetAsync(ctr, 0, (size_t)8 * kStreamCtrPerXcd * kStreamCtrStride * sizeof(unsigned), st));
-    // (gathers in flight per lane, waves per SIMD)
-    const int wps = (g_tune.spmm_wps == 8 || g_tune.spmm_wps == 5 || g_tune.spmm_wps == 2 || g_tune.spmm_wps == 1) ? g_tune.spmm_wps : 4;
-    dim3 grid((unsigned)(cus * wps)), block(kThreads);
-#define GF_STREAM_T(DV, WV, UV, TV) \
-    hipLaunchKernelGGL((spmm_stream_kernel<DV, WV, UV, TV>), grid, block, 0, st, m.st_ent, m.st_val, m.st_last, m.st_rows, Xin, Xout, N, B, m.st_runs, lanes, parts, ctr, nc, m.sell_uval)
-#define GF_STREAM(DV, WV, UV) \
-    do { if (tk == 0) GF_STREAM_T(DV, WV, UV, 0); else GF_STREAM_T(DV, WV, UV, 2); } while (0)
-    if (!uni) GF_STREAM(8, 4, 0);            // a value per gather in flight: 8 deep is the largest spill-free shape
-    else if (wps == 8) GF_STREAM(8, 8, 1);
-    else if (wps == 5) GF_STREAM(16, 5, 1);
-    else if (wps == 2) GF_STREAM(16, 2, 1);
-    else if (wps == 1) GF_STREAM(16, 1, 1);
-    else GF_STREAM(16, 4, 1);
-#undef GF_STREAM_T
-#undef GF_STREAM
-    GF_LAUNCH_CHECK("spmm_stream_kernel");
-    if (m.hub_slices > 0) {
-        gf_csr_dev h = m;   // a view: the residual image in the SELL fields
-        h.n_slices = m.hub_slices;
-        h.sell_kptr = m.hub_kptr;
-        h.sell_ent = m.hub_ent;
-        h.sell_col = m.hub_col;
-        h.sell_rowid = m.hub_rowid;
-        return launch_sell<8, 1>(h, Xin, Xout, N, B, st);
-    }
-    return GF_OK;
-}
-
 template <int LG>
 int launch_vec(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st) {
     constexpr int RPB = kThreads / LG;
@@ -747,13 +507,12 @@ extern "C" int gf_spmm_hop(const gf_plan* plan, int32_t op, const float* Xin, fl
 
     const bool fits24 = (int64_t)N < (1 << 24) && (int64_t)N * W < (int64_t)INT32_MAX;  // __umul24 offsets
     if (!g_tune.spmm_generic && fits24) {
-        if (g_tune.spmm_algo == 2 && stream_applicable(m, N, B, W)) return launch_stream(m, Xin, Xout, N, B, st);
-        if (g_tune.spmm_algo == 4) {   // experiments: the sweep kernel or an error (never a silent fallback)
-            if (!gf_sweep_applicable(m, N, B, W)) {
-                gf_set_error("gf_spmm_hop: spmm_algo = 4 but the sweep kernel does not apply (W = %d, fill = %.3f, N = %d)", W, m.sw_fill, N);
+        if (g_tune.spmm_algo == 5) {   // experiments: the MFMA sweep or an error (never a silent fallback)
+            if (!gf_msweep_applicable(m, N, B, W)) {
+                gf_set_error("gf_spmm_hop: spmm_algo = 5 but the MFMA sweep does not apply (W = %d, B = %d, N = %d, fill = %.3f)", W, B, N, m.ms_fill);
                 return GF_ERR_UNSUPPORTED;
             }
-            return gf_sweep_launch(m, Xin, Xout, N, B, st);
+            return gf_msweep_launch(m, Xin, Xout, N, B, st);
         }
         if (g_tune.spmm_algo != 1) {
             switch (W) {

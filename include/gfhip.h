@@ -251,11 +251,8 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
 
 /* ---- tuning / debugging knobs (no reference counterpart; results are identical for every setting):
  * "spmm_bt" (0 = heuristic | 1 | 2 | 4), "spmm_spw" (0 = default | 1 | 2 | 4 slices per wave), "spmm_generic" (0/1),
- * "spmm_algo" (0 = SELL-8 wave kernel | 1 = CSR workgroup kernel | 2 = round-4 stream kernel: long-lived waves on an in-band run
- * stream, W = 32 | 3 = SELL-8 | 4 = round-4 sweep kernel: source sweep with the partial sums in vector registers, uniform GSOs,
- * W = 32, N <= 131071 while the entry lists fit LDS -- GF_ERR_UNSUPPORTED where it does not apply), "spmm_sd" / "spmm_wps" / "spmm_tk" / "spmm_nc" (stream kernel:
- * ring depth, waves per SIMD, ticket hand-out, counters per XCD), "spmm_spf" (stream image: prefetch runs this many schedule units
- * ahead, 0 = none; read by gf_plan_create), "spmm_lag" (sweep kernel: XCD barriers per pass, >= 1), "spmm_xcd" (0/1),
+ * "spmm_algo" (0 = default: the MFMA source sweep (gf_msweep.hip) where it applies, else the SELL-8 wave kernel | 1 = CSR workgroup
+ * kernel | 3 = SELL-8 always | 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED where it does not apply), "spmm_xcd" (0/1),
  * "spmm_group" (0/1 locality groups in the row schedule of graphs with N >= 32768; read by gf_plan_create),
  * "spmm_pf" (workgroups per tile prefetching the next gather panel, -1 = heuristic, 0 = off), "spmm_ucap" (0 | 8 | 16 gathers in flight per lane), "spmm_load" (0 = plain | 1 = non-temporal gather loads),
  * "spmm_store" (0 = plain | 1 = write-through sc1 | 2 = non-temporal output stores), "contract_generic" (0/1),

@@ -1,0 +1,115 @@
+"""spmm_msweep_kernel (round 5: source sweep with a batch entry's partial sums in the XCD's registers and an fp32 multi-block MFMA as
+scatter-accumulate, gf_msweep_image.h / gf_msweep.hip) against scipy in float64 and BIT FOR BIT against the SELL-8 kernel (same per-row
+summation order: ascending columns, one fmaf per entry).  Reference lines: the hop `x = torch.matmul(x, S)` of graphML.py:158-161."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from _util import relerr
+from alegnn_amd import _lib
+from alegnn_amd.gso import SparseGSO
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tune(**kw):
+    L = _lib.lib()
+    for k, v in kw.items():
+        _lib.check(L.gf_tune(k.encode(), int(v)), "gf_tune " + k)
+
+
+@pytest.fixture
+def knobs():
+    yield tune
+    tune(spmm_algo=0, spmm_bar=1, spmm_slack=10, spmm_group=1)
+
+
+def hop(plans, op, Xt, algo, **kw):
+    tune(spmm_algo=algo, **kw)
+    B, n, W = Xt.shape
+    out = torch.full((B, n, W), float("nan"), device=DEV)
+    _lib.check(_lib.lib().gf_spmm_hop(plans[0], op, Xt.data_ptr(), out.data_ptr(), B, W, stream()))
+    torch.cuda.synchronize()
+    return out
+
+
+def er(n, deg, seed, directed=False, weighted=False):
+    rng = np.random.RandomState(seed)
+    r = np.repeat(np.arange(n), deg)
+    c = rng.randint(0, n, size=r.size)
+    A = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(n, n))
+    if not directed:
+        A = A + A.T
+    A = (A > 0).astype(np.float64)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A = sp.lil_matrix(A)
+    A[3, :] = 0                                 # an empty row (and, undirected, a sparse column)
+    A = sp.csr_matrix(A)
+    A.eliminate_zeros()
+    if weighted:
+        A.data = rng.uniform(-1.0, 1.0, size=A.data.size)
+        return sp.csr_matrix(A)
+    return sp.csr_matrix(A * 0.0625)
+
+
+@pytest.mark.parametrize("bar", [1, 0])
+@pytest.mark.parametrize("n,deg,B,directed,weighted", [
+    (100000, 5, 24, False, False),      # config 4's shape: 25 sets per wave, three entries per XCD
+    (100000, 5, 9, False, True),        # weighted: the value stream
+    (40000, 5, 17, True, False),        # 10 sets, directed (forward and backward images differ)
+    (60000, 4, 40, False, False),       # 15 sets
+    (81000, 3, 8, False, True),         # 20 sets, weighted
+    (102400, 3, 11, False, False),      # the largest single-pass graph
+    (33000, 6, 8, True, True),
+])
+def test_msweep_hop_against_scipy_and_bitwise_against_sell(n, deg, B, directed, weighted, bar, knobs):
+    A = er(n, deg, seed=n + B, directed=directed, weighted=weighted)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    rng = np.random.RandomState(1)
+    X = rng.randn(B, n, 32).astype(np.float32)
+    Xt = torch.tensor(X, device=DEV)
+    for op, M in ((0, A.T.tocsr()), (1, A)):
+        ref = hop(plans, op, Xt, 3)
+        want = np.stack([M.astype(np.float64) @ X[b].astype(np.float64) for b in range(min(B, 4))])
+        assert relerr(ref[:4].cpu().numpy(), want) < 2e-6
+        for rep in range(3):                    # (launches in a row rotate through the barrier-counter slots)
+            got = hop(plans, op, Xt, 5, spmm_bar=bar)
+            assert torch.equal(got, ref), (op, n, B, bar, rep, int((got != ref).sum()), float((got - ref).abs().max()))
+
+
+def test_msweep_hop_soak_at_config4_size(knobs):
+    """Hand-scheduled registers, counted s_waitcnt, gathers in flight across the whole round loop: 20 launches at the bench size
+    (N = 1e5, ~1e6 entries, 64 batch entries: 8 per XCD back to back) must all reproduce SELL-8's bits, with and without the barrier."""
+    A = er(100000, 5, seed=11)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    Xt = torch.randn(64, 100000, 32, device=DEV)
+    ref = hop(plans, 0, Xt, 3)
+    for rep in range(20):
+        got = hop(plans, 0, Xt, 5, spmm_bar=rep & 1)
+        bad = int((got != ref).sum())
+        assert bad == 0, (rep, bad)
+
+
+def test_msweep_is_refused_where_it_does_not_apply(knobs):
+    """spmm_algo = 5 never falls back silently: other widths, small batches and graphs without an image are errors."""
+    A = er(40000, 5, seed=5)
+    plans = SparseGSO([A]).plans(DEV)
+    L = _lib.lib()
+    tune(spmm_algo=5)
+    for B, W in ((8, 16), (4, 32)):
+        X = torch.randn(B, 40000, W, device=DEV)
+        Y = torch.empty_like(X)
+        assert L.gf_spmm_hop(plans[0], 0, X.data_ptr(), Y.data_ptr(), B, W, stream()) != 0
+    small = SparseGSO([er(12000, 5, seed=6)]).plans(DEV)      # below kMsMinNodes: no image
+    X = torch.randn(8, 12000, 32, device=DEV)
+    Y = torch.empty_like(X)
+    assert L.gf_spmm_hop(small[0], 0, X.data_ptr(), Y.data_ptr(), 8, 32, stream()) != 0

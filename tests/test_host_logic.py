@@ -742,46 +742,21 @@ def test_locality_groups_are_cached_per_pattern_on_disk(tmp_path, monkeypatch):
     assert len(list(tmp_path.iterdir())) == 2
 
 
-def test_stream_image_on_cpu(tmp_path):
-    """The STREAM image of round 4 (csrc/gf_stream_image.h: runs of 32 in-band steps, LAST masks, output-row tables, residual hub slices,
-    prefetch runs) is pure host code: tools/stream_image_check.cpp builds it for random scheduled CSRs, interprets it the way
-    spmm_stream_kernel executes it and compares bit for bit with the row-by-row product (graphML.py:158-161 per batch entry)."""
+def test_msweep_image_on_cpu(tmp_path):
+    """The MSWEEP image of round 5 (csrc/gf_msweep_image.h: groups of four destination rows behind a (set, position) of a wave, their
+    (source, slot) entries spread over the rounds in source order) is pure host code: tools/msweep_image_check.cpp builds it for random
+    graphs, interprets it the way spmm_msweep_kernel executes it (one fmaf per entry, round by round) and compares bit for bit with the
+    row-by-row product in ascending column order (graphML.py:158-161 per batch entry)."""
     import shutil
     import subprocess
     if shutil.which("g++") is None:
         pytest.skip("no host compiler")
-    exe = str(tmp_path / "stream_image_check")
+    exe = str(tmp_path / "msweep_image_check")
     r = subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "graph-neural-networks_amd", "csrc"),
-                        os.path.join(ROOT, "tools", "stream_image_check.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
+                        os.path.join(ROOT, "tools", "msweep_image_check.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-3000:]
-
-
-def test_sweep_image_on_cpu(tmp_path):
-    """The SWEEP image (csrc/gf_sweep_image.h: per-half-wave entry lists sorted by source, slots = accumulator registers) is pure host
-    code: tools/sweep_image_check.cpp interprets it the way spmm_sweep_kernel executes it and compares bit for bit with the row sums in
-    ascending column order (graphML.py:158-161 per batch entry)."""
-    import shutil
-    import subprocess
-    if shutil.which("g++") is None:
-        pytest.skip("no host compiler")
-    exe = str(tmp_path / "sweep_image_check")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "graph-neural-networks_amd", "csrc"),
-                        os.path.join(ROOT, "tools", "sweep_image_check.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-3000:]
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-3000:]
-
-
-def test_sweep_kernel_register_map():
-    """spmm_sweep_kernel names its ring and accumulator registers by hand (v16-v23, v28-v127) inside inline asm: the compiler's own
-    instructions must stay below v16 and nothing may spill (tools/check_sweep_isa.py compiles gf_sweep.hip to ISA and checks)."""
-    import subprocess
-    if not os.path.exists("/opt/rocm/bin/hipcc"):
-        pytest.skip("no hipcc")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_sweep_isa.py")], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_asm_stores_never_read_mfma_results():
