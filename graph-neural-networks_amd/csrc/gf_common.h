@@ -148,6 +148,10 @@ struct gf_tuning {
     int spmm_algo = 0;          // 0 = default (the MFMA source sweep where gf_msweep_applicable says so, else SELL-8), 1 = CSR workgroup-staged kernel
                                 // (first version), 3 = SELL-8 always, 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED
     int spmm_bar = 1;           // MFMA sweep: XCD barrier between batch entries (0 = free-running waves)
+    int spmm_pfd = 0;           // MFMA sweep: scalar prefetch of the source rows this many rounds ahead (0 = off)
+    int spmm_fuse = 1;          // MFMA sweep: the K - 1 hops of gf_khop in one launch, entry by entry (0 = one launch per hop)
+    int spmm_depth = 0;         // MFMA sweep: gathers in flight per wave, 0 = default (10 for uniform GSOs with >= 15 sets per wave), 5
+    int spmm_stag = 0;          // MFMA sweep, experiments: XCD x starts x * spmm_stag * ~3.4 us late
     int spmm_srcmask = 0;       // MFMA sweep, timing experiments only (results wrong): AND mask on the gathered source offsets (confines them to a window)
     int spmm_slack = 10;        // MFMA sweep image: rounds beyond the mean group length, in percent (set BEFORE gf_plan_create)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
@@ -184,7 +188,8 @@ extern gf_tuning g_tune;
 
 // internal launchers shared between translation units
 bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W);
-int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st);
+// nhops hops in one launch: hop h reads Xin (h = 0) or Xtaps + (h - 1) * tapStride floats and writes Xtaps + h * tapStride floats
+int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, hipStream_t st);
 size_t gf_msweep_gate_bytes();
 constexpr int32_t kMsMinNodes = 32768;      // below: a batch entry's rows (N x 128 bytes) fit the 4 MiB L2 of an XCD and SELL-8 hits anyway
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,

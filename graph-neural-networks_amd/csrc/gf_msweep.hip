@@ -14,11 +14,13 @@
 // compiler keeps across the block lives in v0-v23):
 //     a0  .. a255          accumulators 0..255:   accumulator (set s, quad q, slot i) = number 16 s + 4 q + i
 //     v112 .. v255         accumulators 256..399  (MFMAs take their C/D operand from either file)
-//     v24 .. v43           ring: the 16 bytes per lane of the kMsDepth = 5 gathers in flight (store phase: four output quads + addresses)
+//   ring depth D = 5:
+//     v24 .. v43           ring: the 16 bytes per lane of the D gathers in flight (store phase: four output quads + addresses)
 //     v44 .. v48           their A operands (edge weight in the lanes of the destination slot, zero elsewhere)
 //     v49, v50, v108, v109 temporaries (gather offset / slot mask, alternating between steps)
 //     v52 .. v79           entries of this lane's position, one per step of a round (reloaded four at a time, a round ahead)
 //     v80 .. v107          their values (weighted GSOs)
+//   ring depth D = 10 (uniform GSOs: no value registers): ring v24 .. v63, A operands v64 .. v73, temporaries v74 .. v77, entries v78 .. v105
 // Vector-memory operations of the loop are issued in a fixed order, loads return in order: the s_waitcnt counts are computed by the
 // assembler from that order (MS_RLCOUNT).  Wait states the hardware does not interlock (VALU write -> MFMA read: 2; MFMA write ->
 // VALU / VMEM read: up to 19) are covered by distance: an A operand is written five steps before its MFMAs, accumulators are read
@@ -36,14 +38,30 @@ constexpr int kMsGateWords = 64;      // per XCD: one arrival counter on a 256-b
 constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be live at once (slots rotate)
 
 // Assembler macros (a basic asm statement: no operand substitution, `%` and `|` are the assembler's).  Defined once per module.
+#ifndef GF_MS_NT   // experiments (make variant): gathers with the non-temporal hint
+#define GF_MS_NT 0
+#endif
+#define GF_MS_STR2(x) #x
+#define GF_MS_STR(x) GF_MS_STR2(x)
 #define GF_MS_MACROS R"(
 .ifndef MS_MACROS_DEFINED
 .set MS_MACROS_DEFINED, 1
-.set MS_R0, 24
-.set MS_A0, 44
-.set MS_E0, 52
-.set MS_V0, 80
 .set MS_ACCV, 112
+.set MS_GATHER_NT, GF_MS_NT_VALUE
+.set MS_R0, 24
+.set MS_V0, 80
+.macro MS_SETMAP D
+  .set MS_A0, 24 + 4*(\D)
+  .if (\D) == 5
+    .set MS_TA0, 49
+    .set MS_TA1, 108
+    .set MS_E0, 52
+  .else
+    .set MS_TA0, 74
+    .set MS_TA1, 76
+    .set MS_E0, 78
+  .endif
+.endm
 .macro MS_MFMA s, q, k
   .if ((\s)*16 + (\q)*4) < 256
     v_mfma_f32_4x4x1_16b_f32 a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3], v[MS_A0+(\k)], v[MS_R0+4*(\k)+(\q)], a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3]
@@ -62,23 +80,33 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
     .set MS_I, MS_I+1
   .endr
 .endm
-.macro MS_RLCOUNT j, S
+// MS_CNT = entry reloads issued behind the gather of step n up to the gather of step n + D - 1 (a reload follows the steps 3, 7, ..
+// and S - 1 of every round)
+.macro MS_RLCOUNT n, S, D
   .set MS_CNT, 0
-  .irp d, 0,1,2,3,4
-    .set MS_SP, ((\j)+\d) % (\S)
+  .set MS_DD, 0
+  .rept \D
+    .set MS_SP, ((\n)+MS_DD) % (\S)
     .if ((MS_SP & 3) == 3) || (MS_SP == (\S)-1)
       .set MS_CNT, MS_CNT+1
     .endif
+    .set MS_DD, MS_DD+1
   .endr
 .endm
-.macro MS_ISSUE sp, k, par, S, UNI, rs, re, rv, vfg, vslot, vevoff, smask, snext
+// gather of step sp into ring slot k, its A operand, and -- behind the last step of an entry quad -- that quad of the round after
+// (rho = rounds between the loop iteration's first round and the round of this step)
+.macro MS_ISSUE sp, k, par, rho, S, UNI, RB, rs, re, rv, vfg, vslot, vevoff, smask, scur
   .if \par
-    .set MS_TA, 108
+    .set MS_TA, MS_TA1
   .else
-    .set MS_TA, 49
+    .set MS_TA, MS_TA0
   .endif
   v_and_or_b32 v[MS_TA], v[MS_E0+(\sp)], \smask, \vfg
-  buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA], \rs, 0 offen
+  .if MS_GATHER_NT
+    buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA], \rs, 0 offen nt
+  .else
+    buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA], \rs, 0 offen
+  .endif
   v_bfe_i32 v[MS_TA+1], v[MS_E0+(\sp)], \vslot, 1
   .if \UNI
     v_and_b32 v[MS_A0+(\k)], 1.0, v[MS_TA+1]
@@ -86,13 +114,16 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
     v_and_b32 v[MS_A0+(\k)], v[MS_V0+(\sp)], v[MS_TA+1]
   .endif
   .if (((\sp) & 3) == 3) || ((\sp) == (\S)-1)
-    buffer_load_dwordx4 v[MS_E0+((\sp)/4)*4:MS_E0+((\sp)/4)*4+3], \vevoff, \re, \snext offen offset:((\sp)/4)*16
+    buffer_load_dwordx4 v[MS_E0+((\sp)/4)*4:MS_E0+((\sp)/4)*4+3], \vevoff, \re, \scur offen offset:((\rho)+1)*(\RB)+((\sp)/4)*16
     .if (\UNI) == 0
-      buffer_load_dwordx4 v[MS_V0+((\sp)/4)*4:MS_V0+((\sp)/4)*4+3], \vevoff, \rv, \snext offen offset:((\sp)/4)*16
+      buffer_load_dwordx4 v[MS_V0+((\sp)/4)*4:MS_V0+((\sp)/4)*4+3], \vevoff, \rv, \scur offen offset:((\rho)+1)*(\RB)+((\sp)/4)*16
     .endif
   .endif
 .endm
-.macro MS_BODY S, UNI, RB, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, scur, snxt, sit
+// S sets, ring depth D, U rounds per loop iteration (U * S is a multiple of D: ring slots are static); scur = byte offset of the
+// iteration's first round in the entry stream, sit = iterations left
+.macro MS_BODY S, UNI, RB, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, uid
+  MS_SETMAP \D
   MS_ZERO \S
   .set MS_Q, 0
   .rept ((\S)+3)/4
@@ -103,36 +134,41 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
     .set MS_Q, MS_Q+1
   .endr
   s_waitcnt vmcnt(0)
-  .set MS_J, 0
-  .rept 5
-    MS_ISSUE MS_J, MS_J, (MS_J & 1), \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
-    .set MS_J, MS_J+1
+  .set MS_N, 0
+  .rept \D
+    MS_ISSUE MS_N, MS_N, (MS_N & 1), 0, \S, \UNI, \RB, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
+    .set MS_N, MS_N+1
   .endr
-MS_LOOP_\@:
-  .set MS_J, 0
-  .rept \S
-    MS_RLCOUNT MS_J, \S
-    s_waitcnt vmcnt(4 + MS_CNT*(2-(\UNI)))
-    MS_MFMA MS_J, 0, (MS_J % 5)
-    MS_MFMA MS_J, 1, (MS_J % 5)
-    MS_MFMA MS_J, 2, (MS_J % 5)
-    MS_MFMA MS_J, 3, (MS_J % 5)
-    .if MS_J + 5 < \S
-      MS_ISSUE (MS_J+5), (MS_J % 5), (MS_J & 1), \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
-    .else
-      MS_ISSUE (MS_J+5-(\S)), (MS_J % 5), (MS_J & 1), \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \snxt
+MS_LOOP_\uid:
+  .set MS_N, 0
+  .rept (\U)*(\S)
+    MS_RLCOUNT MS_N, \S, \D
+    s_waitcnt vmcnt((\D) - 1 + MS_CNT*(2-(\UNI)))
+    MS_MFMA (MS_N % (\S)), 0, (MS_N % (\D))
+    MS_MFMA (MS_N % (\S)), 1, (MS_N % (\D))
+    MS_MFMA (MS_N % (\S)), 2, (MS_N % (\D))
+    MS_MFMA (MS_N % (\S)), 3, (MS_N % (\D))
+    .if \PF
+      s_load_dword \sdummy, \xptr, \spfc offset:MS_N*0x4000
+      s_load_dword \sdummy, \xptr, \spfc offset:MS_N*0x4000+0x40
     .endif
-    .set MS_J, MS_J+1
+    MS_ISSUE ((MS_N+(\D)) % (\S)), (MS_N % (\D)), (MS_N & 1), ((MS_N+(\D)) / (\S)), \S, \UNI, \RB, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
+    .set MS_N, MS_N+1
   .endr
-  s_add_u32 \scur, \scur, \RB
-  s_add_u32 \snxt, \snxt, \RB
+  s_add_u32 \scur, \scur, (\U)*(\RB)
+  .if \PF
+    s_add_u32 \spfr, \spfr, \schunk
+    s_min_u32 \spfc, \spfr, \smaxpf
+  .endif
   s_sub_u32 \sit, \sit, 1
   s_cmp_lg_u32 \sit, 0
-  s_cbranch_scc1 MS_LOOP_\@
-  s_waitcnt vmcnt(0)
+  s_cbranch_scc1 MS_LOOP_\uid
+  // the D gathers in flight belong to round T (gaps); they and the last entry reloads must land before their registers are reused
+  s_waitcnt vmcnt(0) lgkmcnt(0)
   s_nop 7
   s_nop 7
   s_nop 7
+  // store: slot i of position p of set s = the row whose byte offset is word 4p + i of the set's line in the LDS row table
   ds_read_b128 v[MS_E0:MS_E0+3], \vrow
   .set MS_S, 0
   .rept \S
@@ -183,15 +219,20 @@ MS_LOOP_\@:
         GF_MS_A8(19), GF_MS_A8(20), GF_MS_A8(21), GF_MS_A8(22), GF_MS_A8(23), GF_MS_A8(24), "a250", "a251", "a252", "a253",        \
         "a254", "a255"
 
-template <int S, int UNI>
+template <int S, int UNI, int PF, int D>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restrict__ val, const uint32_t* __restrict__ rows,
-                        const float* __restrict__ Xin, float* __restrict__ Xout, int N, int B, int passes, int rounds,
-                        unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask) {
+                        const float* __restrict__ Xin, float* __restrict__ Xtaps, size_t tapStrideBytes, int nhops, int N, int B, int passes,
+                        int rounds, unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask, int pf_lead, int stagger,
+                        int nostore) {
     constexpr int S4 = (S + 3) / 4 * 4;
     constexpr unsigned kRoundBytes = 8u * S4 * 4u;
-    static_assert(S % kMsDepth == 0 && S >= 2 * kMsDepth && S <= kMsMaxSets, "ring slots are static; an entry quad is reloaded a round ahead");
+    constexpr int U = (S % D == 0) ? 1 : 2;                 // rounds per loop iteration: U * S steps are a multiple of the ring depth
+    static_assert((U * S) % D == 0 && S >= D + 5 && S <= kMsMaxSets && (D == 5 || (D == 10 && UNI)),
+                  "ring slots are static; an entry quad of round r + 1 is requested behind its last use in round r and must have been "
+                  "waited for (in-order returns) before the ring reaches round r + 1: S - D > 3; the deep ring takes the value registers");
     __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
+    asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT));
     asm volatile(GF_MS_MACROS);
     const unsigned lane = threadIdx.x & 63;
     const int xcd = blockIdx.x & 7;
@@ -203,13 +244,22 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     const unsigned evoff = pos * (S4 * 4u);                 // this lane's position inside a round of the entry stream
     const unsigned rowlds = (unsigned)(size_t)(&s_rows[wv][0]) + pos * 16u;   // (an LDS address is the low half of the generic pointer)
     const unsigned smask = 0xffffff80u & src_mask;
+    const unsigned chunkBytes = (unsigned)((N + rounds - 1) / rounds) * 128u;   // source rows per round
     unsigned* ctr = gate + (size_t)xcd * kMsGateWords;
     unsigned epoch = 0;
     int table_of = -1;
+    // (experiments) XCD x starts x * stagger * ~3.4 us late, so that the XCDs' store phases do not coincide
+    for (int i = 0; i < xcd * stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
-    for (int b = xcd; b < B; b += 8) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(Xin) + (size_t)b * tapBytes), 0, (int)tapBytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(Xout) + (size_t)b * tapBytes), 0, (int)tapBytes, 0x00020000);
+    // Batch entry b runs through all its hops before the XCD takes the next entry (hop h reads the tap hop h - 1 wrote: Xin for the
+    // first, then Xtaps + (h - 1) taps; it writes Xtaps + h taps): the rows a hop gathers for the first time were written by this XCD a
+    // moment ago -- the last ones are still in its L2, the others in the Infinity Cache instead of HBM.
+    for (int b = xcd; b < B; b += 8)
+      for (int hop = 0; hop < nhops; ++hop) {
+        const char* src = hop == 0 ? reinterpret_cast<const char*>(Xin) : reinterpret_cast<const char*>(Xtaps) + (size_t)(hop - 1) * tapStrideBytes;
+        char* dst = reinterpret_cast<char*>(Xtaps) + (size_t)hop * tapStrideBytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)b * tapBytes), 0, (int)tapBytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (size_t)b * tapBytes), 0, nostore ? 0 : (int)tapBytes, 0x00020000);
         for (int pass = 0; pass < passes; ++pass) {
             const size_t pw = (size_t)pass * kMsWavesPerXcd + wid;
             if (table_of != pass) {   // wave-private copy (LDS operations of one wave execute in order: no barrier)
@@ -218,34 +268,48 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             }
             const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(ent + pw * streamWords), 0, (int)(streamWords * 4), 0x00020000);
             const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)((UNI ? reinterpret_cast<const float*>(ent) : val) + pw * streamWords), 0, (int)(streamWords * 4), 0x00020000);
-            unsigned scur = kRoundBytes, snxt = 2u * kRoundBytes, sit = (unsigned)rounds;
-            asm volatile("MS_BODY %13, %14, %15, %3, %4, %5, %6, %7, %8, %9, %10, %11, %12, %0, %1, %2"
-                         : "+s"(scur), "+s"(snxt), "+s"(sit)
+            unsigned scur = 0, sit = (unsigned)(rounds / U);
+            // scalar prefetch (PF): in every step each wave touches one source row of the iteration pf_lead iterations ahead with two
+            // s_loads (both 64-byte halves) -- the first touch of a row then travels through the scalar cache's queue, not through the
+            // vector cache's, whose in-order returns would hold the wave's other gathers behind an HBM round trip
+            const unsigned smaxpf = tapBytes - (unsigned)(U * S) * 0x4000u - 128u;
+            unsigned spfr = (unsigned)pf_lead * (U * chunkBytes) + wid * 128u, spfc = spfr < smaxpf ? spfr : smaxpf, sdummy;
+            const char* xptr = src + (size_t)b * tapBytes;
+            asm volatile("MS_BODY %19, %20, %21, %22, %23, %24, %5, %6, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %0, %1, %2, %3, %4, %="
+                         : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy)
                          : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fg16), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
-                           "n"(S), "n"(UNI), "n"(kRoundBytes)
+                           "s"(xptr), "s"(smaxpf), "s"(U * chunkBytes), "s"(0), "n"(S), "n"(UNI), "n"(kRoundBytes), "n"(PF), "n"(D), "n"(U)
                          : GF_MS_CLOBBERS);
 
-            if (use_barrier) {
+            const bool dependent = nhops > 1 && pass == passes - 1 && hop + 1 < nhops;   // the next hop gathers what this one stores
+            if (use_barrier || dependent) {
                 // XCD barrier: one scalar atomic per workgroup on the XCD's counter (monotonic over the launch), then the first wave polls
                 // with returning scalar atomics (they execute in the L2: coherent, and they wait on lgkmcnt, not on the stores' vmcnt).
-                // Bounded: a barrier that does not open in time is passed anyway -- results never depend on it.
+                // Between entries it only keeps the XCD's waves together (bounded: passed anyway when it does not open in time, results
+                // do not depend on it).  Between the hops of an entry it orders this hop's stores (acknowledged by the XCD's L2: vmcnt(0))
+                // before the next hop's gathers from the other CUs: there a barrier that does not open (a workgroup that never became
+                // resident) ends the kernel with a trap -- a launch failure, never a wrong result.
                 ++epoch;
+                if (dependent) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (wv == 0) {
                     unsigned t = 1u;
                     asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ctr) : "memory");
                     const unsigned target = 32u * epoch;
-                    for (int spin = 0; t + 1u < target && spin < 4000; ++spin) {
+                    const int limit = dependent ? 4000000 : 4000;
+                    int spin = 0;
+                    for (; t + 1u < target && spin < limit; ++spin) {
                         __builtin_amdgcn_s_sleep(16);
                         t = 0u;
                         asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ctr) : "memory");
                         t -= 1u;   // (compared as "arrivals before mine", like the first read)
                     }
+                    if (dependent && t + 1u < target) __builtin_trap();
                 }
                 __builtin_amdgcn_s_barrier();
             }
         }
-    }
+      }
 }
 
 int cu_count() {
@@ -266,29 +330,45 @@ bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W) {
            (int64_t)N * 128 < (int64_t)kMsPad;
 }
 
-int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xout, int N, int B, hipStream_t st) {
+int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, hipStream_t st) {
     static std::atomic<unsigned> next_slot{0};
     unsigned* gate = m.ms_gate + (size_t)(next_slot.fetch_add(1) % kMsGateSlots) * 8 * kMsGateWords;
     const int use_barrier = g_tune.spmm_bar;
-    if (use_barrier) GF_HIP(hipMemsetAsync(gate, 0, 8 * kMsGateWords * sizeof(unsigned), st));
+    if (use_barrier || nhops > 1) GF_HIP(hipMemsetAsync(gate, 0, 8 * kMsGateWords * sizeof(unsigned), st));
     dim3 grid(256), block(kThreads);
     const unsigned src_mask = g_tune.spmm_srcmask ? (unsigned)g_tune.spmm_srcmask : 0xffffffffu;   // experiments (timing only): confine the gathers to a window
-#define GF_MS(SV, UV)                                                                                                              \
-    hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV>), grid, block, 0, st, m.ms_ent, m.ms_val, m.ms_rows, Xin, Xout, N, B, m.ms_passes, \
-                       m.ms_rounds, gate, use_barrier, m.sell_uval, src_mask)
-#define GF_MS_S(UV)                                   \
-    switch (m.ms_sets) {                              \
-        case 10: GF_MS(10, UV); break;                \
-        case 15: GF_MS(15, UV); break;                \
-        case 20: GF_MS(20, UV); break;                \
-        default: GF_MS(25, UV); break;                \
-    }
+    const bool pf = g_tune.spmm_pfd > 0;
+    const bool deep = m.ms_uniform && m.ms_sets >= 15 && g_tune.spmm_depth != 5;   // ring of 10 gathers (the value registers hold it)
+#define GF_MS(SV, UV, PV, DV)                                                                                                          \
+    hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV>), grid, block, 0, st, m.ms_ent, m.ms_val, m.ms_rows, Xin, Xtaps, (size_t)tapStride * 4, nhops, N, B, \
+                       m.ms_passes, m.ms_rounds, gate, use_barrier, m.sell_uval, src_mask, g_tune.spmm_pfd, g_tune.spmm_stag, g_tune.spmm_store == 3)
+#define GF_MS_P(SV, UV, DV)                            \
+    do {                                              \
+        if (pf) GF_MS(SV, UV, 1, DV);                 \
+        else GF_MS(SV, UV, 0, DV);                    \
+    } while (0)
+#define GF_MS_D(SV)                                   \
+    do {                                              \
+        if (deep) GF_MS_P(SV, 1, 10);                 \
+        else GF_MS_P(SV, 1, 5);                       \
+    } while (0)
     if (m.ms_uniform) {
-        GF_MS_S(1);
+        switch (m.ms_sets) {
+            case 10: GF_MS_P(10, 1, 5); break;
+            case 15: GF_MS_D(15); break;
+            case 20: GF_MS_D(20); break;
+            default: GF_MS_D(25); break;
+        }
     } else {
-        GF_MS_S(0);
+        switch (m.ms_sets) {
+            case 10: GF_MS_P(10, 0, 5); break;
+            case 15: GF_MS_P(15, 0, 5); break;
+            case 20: GF_MS_P(20, 0, 5); break;
+            default: GF_MS_P(25, 0, 5); break;
+        }
     }
-#undef GF_MS_S
+#undef GF_MS_D
+#undef GF_MS_P
 #undef GF_MS
     GF_LAUNCH_CHECK("spmm_msweep_kernel");
     return GF_OK;

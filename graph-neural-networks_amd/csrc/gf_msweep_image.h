@@ -96,6 +96,7 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
     const double mean = (double)total / groups;
     int32_t T = std::max(longest, (int32_t)std::ceil(mean * (100 + slack_pct) / 100.0));
     T = std::max(T, 1);
+    T += T & 1;                                      // (the kernel's loop body spans two rounds when S is odd)
     if (T > kMsMaxRounds) return im;
     im.sets = S;
     im.s4 = (S + 3) / 4 * 4;

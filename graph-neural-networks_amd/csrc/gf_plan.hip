@@ -64,6 +64,10 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_generic")) g_tune.spmm_generic = value;
     else if (!strcmp(key, "spmm_algo")) g_tune.spmm_algo = value;
     else if (!strcmp(key, "spmm_bar")) g_tune.spmm_bar = value;
+    else if (!strcmp(key, "spmm_pfd")) g_tune.spmm_pfd = value;
+    else if (!strcmp(key, "spmm_depth")) g_tune.spmm_depth = value;
+    else if (!strcmp(key, "spmm_fuse")) g_tune.spmm_fuse = value;
+    else if (!strcmp(key, "spmm_stag")) g_tune.spmm_stag = value;
     else if (!strcmp(key, "spmm_srcmask")) g_tune.spmm_srcmask = value;
     else if (!strcmp(key, "spmm_slack")) g_tune.spmm_slack = value;
     else if (!strcmp(key, "spmm_xcd")) g_tune.spmm_xcd = value;

@@ -512,7 +512,7 @@ extern "C" int gf_spmm_hop(const gf_plan* plan, int32_t op, const float* Xin, fl
                 gf_set_error("gf_spmm_hop: spmm_algo = 5 but the MFMA sweep does not apply (W = %d, B = %d, N = %d, fill = %.3f)", W, B, N, m.ms_fill);
                 return GF_ERR_UNSUPPORTED;
             }
-            return gf_msweep_launch(m, Xin, Xout, N, B, st);
+            return gf_msweep_launch(m, Xin, Xout, 0, 1, N, B, st);
         }
         if (g_tune.spmm_algo != 1) {
             switch (W) {
@@ -557,14 +557,44 @@ extern "C" int gf_khop(const gf_plan* const* plans, int32_t E, int32_t op, float
                          plans[0]->n);
     }
     const int64_t tap = (int64_t)B * plans[0]->n * W;
-    for (int e = 0; e < E; ++e)
+    for (int e = 0; e < E; ++e) {
+        // the MFMA sweep runs the K - 1 hops of an edge feature in ONE launch, batch entry by batch entry (gf_msweep.hip)
+        const gf_csr_dev& m = plans[e]->mat[op];
+        if (K > 2 && g_tune.spmm_algo == 5 && g_tune.spmm_fuse && !g_tune.spmm_generic && gf_msweep_applicable(m, plans[e]->n, B, W)) {
+            const int rc = gf_msweep_launch(m, Z, Z + (int64_t)(1 + e * (K - 1)) * tap, tap, K - 1, plans[e]->n, B, gf_stream(stream));
+            if (rc != GF_OK) return rc;
+            continue;
+        }
         for (int k = 1; k < K; ++k) {
             const float* src = (k == 1) ? Z : Z + (int64_t)(1 + e * (K - 1) + (k - 2)) * tap;
             float* dst = Z + (int64_t)(1 + e * (K - 1) + (k - 1)) * tap;
             const int rc = gf_spmm_hop(plans[e], op, src, dst, B, W, stream);
             if (rc != GF_OK) return rc;
         }
+    }
     return GF_OK;
+}
+
+extern "C" int gf_time_khop(const gf_plan* const* plans, int32_t E, int32_t op, float* Z, int32_t B, int32_t W, int32_t K, int32_t iters,
+                            void* stream, float* avg_ms) {
+    GF_REQUIRE_ARG(avg_ms && iters > 0, "gf_time_khop: bad iters / NULL avg_ms");
+    hipStream_t st = gf_stream(stream);
+    hipEvent_t e0, e1;
+    GF_HIP(hipEventCreate(&e0));
+    GF_HIP(hipEventCreate(&e1));
+    int rc = gf_khop(plans, E, op, Z, B, W, K, stream);  // warm-up (also validates arguments)
+    if (rc == GF_OK) {
+        GF_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < iters && rc == GF_OK; ++i) rc = gf_khop(plans, E, op, Z, B, W, K, stream);
+        GF_HIP(hipEventRecord(e1, st));
+        GF_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        GF_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 extern "C" int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* Xin, float* Xout, int32_t B, int32_t W,

@@ -102,14 +102,19 @@ def test_msweep_hop_soak_at_config4_size(knobs):
 def test_msweep_is_refused_where_it_does_not_apply(knobs):
     """spmm_algo = 5 never falls back silently: other widths, small batches and graphs without an image are errors."""
     A = er(40000, 5, seed=5)
-    plans = SparseGSO([A]).plans(DEV)
+    gso = SparseGSO([A])                                      # (the plans live as long as their SparseGSO)
+    plans = gso.plans(DEV)
     L = _lib.lib()
     tune(spmm_algo=5)
-    for B, W in ((8, 16), (4, 32)):
-        X = torch.randn(B, 40000, W, device=DEV)
+    rcs = []
+    for n, pl, B, W in ((40000, plans, 8, 16), (40000, plans, 4, 32)):
+        X = torch.randn(B, n, W, device=DEV)
         Y = torch.empty_like(X)
-        assert L.gf_spmm_hop(plans[0], 0, X.data_ptr(), Y.data_ptr(), B, W, stream()) != 0
-    small = SparseGSO([er(12000, 5, seed=6)]).plans(DEV)      # below kMsMinNodes: no image
+        rcs.append(int(L.gf_spmm_hop(pl[0], 0, X.data_ptr(), Y.data_ptr(), B, W, stream())))
+    gso_small = SparseGSO([er(12000, 5, seed=6)])             # below kMsMinNodes: no image
+    small = gso_small.plans(DEV)
     X = torch.randn(8, 12000, 32, device=DEV)
     Y = torch.empty_like(X)
-    assert L.gf_spmm_hop(small[0], 0, X.data_ptr(), Y.data_ptr(), 8, 32, stream()) != 0
+    rcs.append(int(L.gf_spmm_hop(small[0], 0, X.data_ptr(), Y.data_ptr(), 8, 32, stream())))
+    torch.cuda.synchronize()
+    assert all(rc != 0 for rc in rcs), rcs

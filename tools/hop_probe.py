@@ -59,7 +59,23 @@ else:
         X0 = torch.randn(B, N, W, device=dev); X1 = torch.empty_like(X0)
         ms = ctypes.c_float()
         ref = None
-        for var in (variants or [""]):
+        if os.environ.get("PROBE_CHAIN"):   # the K-1 hops of one gf_khop call on a tap stack, as the layer runs them: ms per hop
+            Z = torch.empty(K, B, N, W, device=dev)
+            Z[0].copy_(X0)
+            for var in (variants or [""]):
+                for kv in var.replace("v:", "").split("+"):
+                    if kv:
+                        k, v = kv.split("=")
+                        assert L.gf_tune(k.encode(), int(v)) == 0, k
+                Z[1:].fill_(float("nan"))
+                _lib.check(L.gf_time_khop(plans, 1, 0, Z.data_ptr(), B, W, K, max(iters, 3), st, ctypes.byref(ms)))
+                torch.cuda.synchronize()
+                same = "" if ref is None else f"  bitwise == first variant: {bool(torch.equal(ref, Z[1:]))}"
+                if ref is None:
+                    ref = Z[1:].clone()
+                print(f"khop chain {name} K={K} nnz={w.nnz} {var}: {ms.value / (K - 1):.4f} ms per hop ({ms.value:.4f} per call){same}", flush=True)
+            variants = ["__none__"]
+        for var in ([] if variants == ["__none__"] else (variants or [""])):
             for kv in var.replace("v:", "").split("+"):
                 if kv:
                     k, v = kv.split("=")
