@@ -346,14 +346,15 @@ def kernel_source_sha():
 def pmc_summary(workload, kernel, suffix="_pmc.json"):
     """Newest committed PMC summary (profiles/*<suffix>) for this workload and kernel, with whether it was taken on the kernel sources
     that are running now."""
-    best = None
+    best, running = None, kernel_source_sha()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix))):
         try:
             pm = json.load(open(f))
         except Exception:
             continue
         if pm.get("workload") == workload and pm.get("kernel") == kernel:
-            best = (f, pm)
+            if best is None or pm.get("kernel_src_sha") == running or best[1].get("kernel_src_sha") != running:
+                best = (f, pm)          # a summary taken on the running sources wins over any other; among equals the last by name
     if best is None:
         return None, None
     f, pm = best
@@ -400,12 +401,17 @@ def filter_hop_roofline(L, plans, name, B, N, W, K, nnz, dev):
             kern, hops = ("spmm_panel_db_kernel" if which == 2 else "spmm_panel_kernel"), 1
             ms.value /= (K - 1)
             note = "one hop per launch (the K-1 launches of a chain timed together, launch_ms = their mean), gathers from an LDS-resident panel"
-    else:                                                         # node-major, gathers through L2
-        X0 = torch.randn(B, N, W, device=dev)
-        X1 = torch.empty_like(X0)
-        _lib.check(L.gf_time_spmm_hop(plans[0], 0, X0.data_ptr(), X1.data_ptr(), B, W, 20, st, ctypes.byref(ms)))
-        kern, hops = "spmm_sell_kernel", 1
-        note = "one hop per launch, node-major rows gathered through L2 / Infinity Cache"
+    else:                                                         # node-major, gathers through L2: the chain the layer walks (tap k-1 -> tap k)
+        Z = torch.randn(K, B, N, W, device=dev)
+        _lib.check(L.gf_time_khop(plans, 1, 0, Z.data_ptr(), B, W, K, 10, st, ctypes.byref(ms)))
+        if L.gf_spmm_hop_kernel(plans[0], 0, B, W) == 1:
+            kern, hops = "spmm_msweep_kernel", K - 1
+            note = ("the K-1 hops of gf_khop in ONE launch, batch entry by batch entry: an XCD holds an entry's output rows in its register "
+                    "files, its waves walk the source rows together (every row leaves HBM once per hop), fp32 MFMA scatter-accumulate")
+        else:
+            kern, hops = "spmm_sell_kernel", 1
+            ms.value /= (K - 1)
+            note = "one hop per launch (the K-1 launches of a chain timed together, launch_ms = their mean), node-major rows gathered through L2 / Infinity Cache"
     nbytes = hops * hop_bytes(B, N, W, nnz)
     achieved = nbytes / (ms.value * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(name, kern)

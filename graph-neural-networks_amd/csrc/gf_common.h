@@ -148,12 +148,13 @@ struct gf_tuning {
     int spmm_algo = 0;          // 0 = default (the MFMA source sweep where gf_msweep_applicable says so, else SELL-8), 1 = CSR workgroup-staged kernel
                                 // (first version), 3 = SELL-8 always, 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED
     int spmm_bar = 1;           // MFMA sweep: XCD barrier between batch entries (0 = free-running waves)
-    int spmm_pfd = 0;           // MFMA sweep: scalar prefetch of the source rows this many rounds ahead (0 = off)
+    int spmm_pfd = 8;           // MFMA sweep: scalar prefetch of the source rows this many loop iterations ahead (0 = off)
+    int spmm_trace = 0;         // MFMA sweep, experiments: record phase time stamps (gf_debug_msweep_trace)
     int spmm_fuse = 1;          // MFMA sweep: the K - 1 hops of gf_khop in one launch, entry by entry (0 = one launch per hop)
     int spmm_depth = 0;         // MFMA sweep: gathers in flight per wave, 0 = default (10 for uniform GSOs with >= 15 sets per wave), 5
     int spmm_stag = 0;          // MFMA sweep, experiments: XCD x starts x * spmm_stag * ~3.4 us late
     int spmm_srcmask = 0;       // MFMA sweep, timing experiments only (results wrong): AND mask on the gathered source offsets (confines them to a window)
-    int spmm_slack = 10;        // MFMA sweep image: rounds beyond the mean group length, in percent (set BEFORE gf_plan_create)
+    int spmm_slack = 5;         // MFMA sweep image: rounds beyond the mean group length, in percent (set BEFORE gf_plan_create)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
     int spmm_ucap = 0;          // 0/16 = up to 16 gathers in flight per lane, 8 = up to 8 (fewer registers, more waves)
     int spmm_pf = -1;           // workgroups per tile that prefetch the next tile's gather panel into L2 (-1 = heuristic, 0 = off)
@@ -191,7 +192,8 @@ bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W);
 // nhops hops in one launch: hop h reads Xin (h = 0) or Xtaps + (h - 1) * tapStride floats and writes Xtaps + h * tapStride floats
 int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, hipStream_t st);
 size_t gf_msweep_gate_bytes();
-constexpr int32_t kMsMinNodes = 32768;      // below: a batch entry's rows (N x 128 bytes) fit the 4 MiB L2 of an XCD and SELL-8 hits anyway
+constexpr int32_t kMsMinNodes = 32768;      // an image is built from here on (below, a batch entry's rows -- N x 128 bytes -- fit the 4 MiB L2 of an XCD)
+constexpr int32_t kMsDefaultMinNodes = 49152;   // the default hop uses it from here on (measured: SELL-8 wins at 33k / 40k, the sweep from 50k on)
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
                        int F, int E, int K, int transpose_bank, hipStream_t st, int out_rows = 0, const float* mask = nullptr);
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)

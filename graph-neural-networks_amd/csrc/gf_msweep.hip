@@ -114,26 +114,27 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
     v_and_b32 v[MS_A0+(\k)], v[MS_V0+(\sp)], v[MS_TA+1]
   .endif
   .if (((\sp) & 3) == 3) || ((\sp) == (\S)-1)
-    buffer_load_dwordx4 v[MS_E0+((\sp)/4)*4:MS_E0+((\sp)/4)*4+3], \vevoff, \re, \scur offen offset:((\rho)+1)*(\RB)+((\sp)/4)*16
+    buffer_load_dwordx4 v[MS_E0+((\sp)/4)*4:MS_E0+((\sp)/4)*4+3], \vevoff, \re, \scur offen offset:((\rho)+1)*(\RB)+((\sp)/4)*128
     .if (\UNI) == 0
-      buffer_load_dwordx4 v[MS_V0+((\sp)/4)*4:MS_V0+((\sp)/4)*4+3], \vevoff, \rv, \scur offen offset:((\rho)+1)*(\RB)+((\sp)/4)*16
+      buffer_load_dwordx4 v[MS_V0+((\sp)/4)*4:MS_V0+((\sp)/4)*4+3], \vevoff, \rv, \scur offen offset:((\rho)+1)*(\RB)+((\sp)/4)*128
     .endif
   .endif
 .endm
 // S sets, ring depth D, U rounds per loop iteration (U * S is a multiple of D: ring slots are static); scur = byte offset of the
 // iteration's first round in the entry stream, sit = iterations left
-.macro MS_BODY S, UNI, RB, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, uid
+.macro MS_BODY S, UNI, RB, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, stl0, stl1, uid
   MS_SETMAP \D
   MS_ZERO \S
   .set MS_Q, 0
   .rept ((\S)+3)/4
-    buffer_load_dwordx4 v[MS_E0+4*MS_Q:MS_E0+4*MS_Q+3], \vevoff, \re, 0 offen offset:MS_Q*16
+    buffer_load_dwordx4 v[MS_E0+4*MS_Q:MS_E0+4*MS_Q+3], \vevoff, \re, 0 offen offset:MS_Q*128
     .if (\UNI) == 0
-      buffer_load_dwordx4 v[MS_V0+4*MS_Q:MS_V0+4*MS_Q+3], \vevoff, \rv, 0 offen offset:MS_Q*16
+      buffer_load_dwordx4 v[MS_V0+4*MS_Q:MS_V0+4*MS_Q+3], \vevoff, \rv, 0 offen offset:MS_Q*128
     .endif
     .set MS_Q, MS_Q+1
   .endr
   s_waitcnt vmcnt(0)
+  s_memtime \stl0
   .set MS_N, 0
   .rept \D
     MS_ISSUE MS_N, MS_N, (MS_N & 1), 0, \S, \UNI, \RB, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
@@ -163,6 +164,7 @@ MS_LOOP_\uid:
   s_sub_u32 \sit, \sit, 1
   s_cmp_lg_u32 \sit, 0
   s_cbranch_scc1 MS_LOOP_\uid
+  s_memtime \stl1
   // the D gathers in flight belong to round T (gaps); they and the last entry reloads must land before their registers are reused
   s_waitcnt vmcnt(0) lgkmcnt(0)
   s_nop 7
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restrict__ val, const uint32_t* __restrict__ rows,
                         const float* __restrict__ Xin, float* __restrict__ Xtaps, size_t tapStrideBytes, int nhops, int N, int B, int passes,
                         int rounds, unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask, int pf_lead, int stagger,
-                        int nostore) {
+                        int nostore, unsigned long long* __restrict__ trace) {
     constexpr int S4 = (S + 3) / 4 * 4;
     constexpr unsigned kRoundBytes = 8u * S4 * 4u;
     constexpr int U = (S % D == 0) ? 1 : 2;                 // rounds per loop iteration: U * S steps are a multiple of the ring depth
@@ -241,7 +243,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     const unsigned pos = lane >> 3, fg16 = (lane & 7u) * 16u, slotbit = lane & 3u;
     const unsigned tapBytes = (unsigned)N * 128u;
     const size_t streamWords = (size_t)(rounds + 2) * 8 * S4;
-    const unsigned evoff = pos * (S4 * 4u);                 // this lane's position inside a round of the entry stream
+    const unsigned evoff = pos * 16u;                       // this lane's position inside an entry quad's 128-byte line
     const unsigned rowlds = (unsigned)(size_t)(&s_rows[wv][0]) + pos * 16u;   // (an LDS address is the low half of the generic pointer)
     const unsigned smask = 0xffffff80u & src_mask;
     const unsigned chunkBytes = (unsigned)((N + rounds - 1) / rounds) * 128u;   // source rows per round
@@ -275,11 +277,14 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             const unsigned smaxpf = tapBytes - (unsigned)(U * S) * 0x4000u - 128u;
             unsigned spfr = (unsigned)pf_lead * (U * chunkBytes) + wid * 128u, spfc = spfr < smaxpf ? spfr : smaxpf, sdummy;
             const char* xptr = src + (size_t)b * tapBytes;
-            asm volatile("MS_BODY %19, %20, %21, %22, %23, %24, %5, %6, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %0, %1, %2, %3, %4, %="
-                         : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy)
+            unsigned long long tl0, tl1;
+            const unsigned long long t0 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+            asm volatile("MS_BODY %21, %22, %23, %24, %25, %26, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
+                         : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy), "=&s"(tl0), "=&s"(tl1)
                          : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fg16), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
                            "s"(xptr), "s"(smaxpf), "s"(U * chunkBytes), "s"(0), "n"(S), "n"(UNI), "n"(kRoundBytes), "n"(PF), "n"(D), "n"(U)
                          : GF_MS_CLOBBERS);
+            const unsigned long long t1 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
             const bool dependent = nhops > 1 && pass == passes - 1 && hop + 1 < nhops;   // the next hop gathers what this one stores
             if (use_barrier || dependent) {
@@ -308,9 +313,16 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                 }
                 __builtin_amdgcn_s_barrier();
             }
+            if (trace && wid == 0 && lane == 0 && epoch <= 64) {   // (experiments) phase stamps of the XCD's first wave: entry start, previous
+                unsigned long long* t = trace + ((size_t)xcd * 64 + (epoch - 1)) * 8;   // stores drained + entries loaded, loop end, stores issued, barrier passed
+                t[0] = t0; t[1] = tl0; t[2] = tl1; t[3] = t1; t[4] = __builtin_amdgcn_s_memtime();
+            }
         }
       }
 }
+
+unsigned long long* g_trace = nullptr;
+constexpr size_t kTraceBytes = 8 * 64 * 8 * sizeof(unsigned long long);
 
 int cu_count() {
     static const int cus = [] {
@@ -337,11 +349,17 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     if (use_barrier || nhops > 1) GF_HIP(hipMemsetAsync(gate, 0, 8 * kMsGateWords * sizeof(unsigned), st));
     dim3 grid(256), block(kThreads);
     const unsigned src_mask = g_tune.spmm_srcmask ? (unsigned)g_tune.spmm_srcmask : 0xffffffffu;   // experiments (timing only): confine the gathers to a window
+    unsigned long long* trace = nullptr;
+    if (g_tune.spmm_trace) {   // (experiments) 8 XCDs x 64 (entry, hop) slots x 8 stamps, read back with gf_debug_msweep_trace
+        if (!g_trace) GF_HIP(hipMalloc((void**)&g_trace, kTraceBytes));
+        GF_HIP(hipMemsetAsync(g_trace, 0, kTraceBytes, st));
+        trace = g_trace;
+    }
     const bool pf = g_tune.spmm_pfd > 0;
     const bool deep = m.ms_uniform && m.ms_sets >= 15 && g_tune.spmm_depth != 5;   // ring of 10 gathers (the value registers hold it)
 #define GF_MS(SV, UV, PV, DV)                                                                                                          \
     hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV>), grid, block, 0, st, m.ms_ent, m.ms_val, m.ms_rows, Xin, Xtaps, (size_t)tapStride * 4, nhops, N, B, \
-                       m.ms_passes, m.ms_rounds, gate, use_barrier, m.sell_uval, src_mask, g_tune.spmm_pfd, g_tune.spmm_stag, g_tune.spmm_store == 3)
+                       m.ms_passes, m.ms_rounds, gate, use_barrier, m.sell_uval, src_mask, g_tune.spmm_pfd, g_tune.spmm_stag, g_tune.spmm_store == 3, trace)
 #define GF_MS_P(SV, UV, DV)                            \
     do {                                              \
         if (pf) GF_MS(SV, UV, 1, DV);                 \
@@ -371,6 +389,13 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
 #undef GF_MS_P
 #undef GF_MS
     GF_LAUNCH_CHECK("spmm_msweep_kernel");
+    return GF_OK;
+}
+
+extern "C" int gf_debug_msweep_trace(unsigned long long* out) {   // [8][64][8]; experiments only (filled when gf_tune("spmm_trace", 1))
+    GF_REQUIRE_ARG(out != nullptr && g_trace != nullptr, "gf_debug_msweep_trace: no trace");
+    GF_HIP(hipDeviceSynchronize());
+    GF_HIP(hipMemcpy(out, g_trace, kTraceBytes, hipMemcpyDeviceToHost));
     return GF_OK;
 }
 

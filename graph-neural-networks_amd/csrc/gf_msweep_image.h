@@ -46,12 +46,13 @@ struct MsweepImage {
     int32_t s4 = 0;                                  // S rounded up to a multiple of 4 (entries of a position are loaded 4 at a time)
     int32_t passes = 0;                              // ceil(groups / (128 * S * 8)); one pass = one sweep of the sources per batch entry
     int32_t rounds = 0;                              // T; the streams hold T + 2 rounds (the kernel's entry loads run two rounds ahead)
-    std::vector<uint32_t> ent;                       // [passes][128 waves][T + 2][8 positions][s4]
+    std::vector<uint32_t> ent;                       // [passes][128 waves][T + 2][s4 / 4 quads][8 positions][4]: the 8 positions' entries of 4 consecutive steps share a 128-byte line
     std::vector<float> val;                          // same shape, weighted GSOs only (empty when uniform)
     std::vector<uint32_t> rows;                      // [passes][128 waves][S][32]  output byte offset (row * 128) of (set, position * 4 + slot), kMsPad = none
     int64_t real_entries = 0;                        // fill = real_entries / (passes * 128 * S * 8 * T)
     double fill() const { return passes ? (double)real_entries / ((double)passes * kMsWavesPerXcd * sets * 8 * rounds) : 0.0; }
     size_t stream_words() const { return (size_t)(rounds + 2) * 8 * s4; }   // per (pass, wave)
+    size_t at(int32_t t, int32_t p, int32_t step) const { return ((size_t)t * (s4 / 4) + step / 4) * 32 + (size_t)p * 4 + (step & 3); }
 };
 
 // rowptr / col / val: CSR of the operator in ORIGINAL row order, columns ascending inside a row.  uniform: the values are not stored
@@ -155,7 +156,7 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
         float* v = uniform ? nullptr : im.val.data() + ((size_t)pass * kMsWavesPerXcd + wave) * sw;
         for (int32_t k = 0; k < L; ++k) {
             const int32_t t = (f[k] + bk[k]) >> 1;
-            const size_t at = ((size_t)t * 8 + p) * im.s4 + set;
+            const size_t at = im.at(t, p, set);
             e[at] = ((uint32_t)list[k].src << 7) | (1u << list[k].slot);
             if (v) v[at] = list[k].v;
         }
@@ -176,7 +177,7 @@ inline void interpret_msweep_image(const MsweepImage& im, bool uniform, float uv
             for (int32_t t = 0; t < im.rounds + 2; ++t)
                 for (int32_t s = 0; s < im.sets; ++s)
                     for (int32_t p = 0; p < 8; ++p) {
-                        const size_t at = ((size_t)t * 8 + p) * im.s4 + s;
+                        const size_t at = im.at(t, p, s);
                         const uint32_t w = e[at];
                         if (!(w & 15u)) continue;
                         const float a = uniform ? 1.f : v[at];
@@ -220,7 +221,7 @@ inline double simulate_msweep_hits(const MsweepImage& im, int32_t n, int32_t lin
                 for (int32_t wave = 0; wave < kMsWavesPerXcd; ++wave) {
                     const uint32_t* e = im.ent.data() + ((size_t)pass * kMsWavesPerXcd + wave) * sw;
                     for (int32_t p = 0; p < 8; ++p) {
-                        const uint32_t w = e[((size_t)t * 8 + p) * im.s4 + s];
+                        const uint32_t w = e[im.at(t, p, s)];
                         if (!(w & 15u)) continue;
                         const int32_t r = (int32_t)(w >> 7);
                         if (stamp[r] >= 0) ++hits;

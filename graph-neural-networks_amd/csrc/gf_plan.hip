@@ -67,6 +67,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_pfd")) g_tune.spmm_pfd = value;
     else if (!strcmp(key, "spmm_depth")) g_tune.spmm_depth = value;
     else if (!strcmp(key, "spmm_fuse")) g_tune.spmm_fuse = value;
+    else if (!strcmp(key, "spmm_trace")) g_tune.spmm_trace = value;
     else if (!strcmp(key, "spmm_stag")) g_tune.spmm_stag = value;
     else if (!strcmp(key, "spmm_srcmask")) g_tune.spmm_srcmask = value;
     else if (!strcmp(key, "spmm_slack")) g_tune.spmm_slack = value;

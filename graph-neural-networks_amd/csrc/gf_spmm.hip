@@ -507,6 +507,7 @@ extern "C" int gf_spmm_hop(const gf_plan* plan, int32_t op, const float* Xin, fl
 
     const bool fits24 = (int64_t)N < (1 << 24) && (int64_t)N * W < (int64_t)INT32_MAX;  // __umul24 offsets
     if (!g_tune.spmm_generic && fits24) {
+        if (g_tune.spmm_algo == 0 && N >= kMsDefaultMinNodes && gf_msweep_applicable(m, N, B, W)) return gf_msweep_launch(m, Xin, Xout, 0, 1, N, B, st);
         if (g_tune.spmm_algo == 5) {   // experiments: the MFMA sweep or an error (never a silent fallback)
             if (!gf_msweep_applicable(m, N, B, W)) {
                 gf_set_error("gf_spmm_hop: spmm_algo = 5 but the MFMA sweep does not apply (W = %d, B = %d, N = %d, fill = %.3f)", W, B, N, m.ms_fill);
@@ -547,6 +548,20 @@ extern "C" int gf_spmm_hop(const gf_plan* plan, int32_t op, const float* Xin, fl
     return GF_OK;
 }
 
+// 1 when gf_spmm_hop / gf_khop run the MFMA source sweep for this call (the default from kMsDefaultMinNodes nodes on, or spmm_algo = 5)
+static bool gf_hop_uses_msweep(const gf_plan* plan, int op, int B, int W) {
+    const gf_csr_dev& m = plan->mat[op];
+    const int N = plan->n;
+    const bool fits24 = (int64_t)N < (1 << 24) && (int64_t)N * W < (int64_t)INT32_MAX;
+    if (g_tune.spmm_generic || !fits24 || !gf_msweep_applicable(m, N, B, W)) return false;
+    return g_tune.spmm_algo == 5 || (g_tune.spmm_algo == 0 && N >= kMsDefaultMinNodes);
+}
+
+extern "C" int gf_spmm_hop_kernel(const gf_plan* plan, int32_t op, int32_t B, int32_t W) {
+    GF_REQUIRE_ARG(plan != nullptr && (op == GF_OP_FWD || op == GF_OP_BWD) && B > 0 && W > 0, "gf_spmm_hop_kernel: bad argument");
+    return gf_hop_uses_msweep(plan, op, B, W) ? 1 : 0;
+}
+
 extern "C" int gf_khop(const gf_plan* const* plans, int32_t E, int32_t op, float* Z, int32_t B, int32_t W, int32_t K,
                        void* stream) {
     GF_REQUIRE_ARG(plans && Z, "gf_khop: NULL argument");
@@ -560,7 +575,7 @@ extern "C" int gf_khop(const gf_plan* const* plans, int32_t E, int32_t op, float
     for (int e = 0; e < E; ++e) {
         // the MFMA sweep runs the K - 1 hops of an edge feature in ONE launch, batch entry by batch entry (gf_msweep.hip)
         const gf_csr_dev& m = plans[e]->mat[op];
-        if (K > 2 && g_tune.spmm_algo == 5 && g_tune.spmm_fuse && !g_tune.spmm_generic && gf_msweep_applicable(m, plans[e]->n, B, W)) {
+        if (K > 2 && g_tune.spmm_fuse && gf_hop_uses_msweep(plans[e], op, B, W)) {
             const int rc = gf_msweep_launch(m, Z, Z + (int64_t)(1 + e * (K - 1)) * tap, tap, K - 1, plans[e]->n, B, gf_stream(stream));
             if (rc != GF_OK) return rc;
             continue;

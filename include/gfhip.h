@@ -246,6 +246,9 @@ int gf_lsigf_backward_ex(const gf_plan* const* plans, int32_t E, const float* dy
 
 /* ---- measurement hook: run ONE hop `iters` times on `stream` bracketed by HIP events on that stream and return
  * the average milliseconds per launch (bench.py's roofline leg; hipEvents see the launch stream, torch events may not). */
+/* which kernel a node-major hop of this shape runs: 1 = spmm_msweep_kernel (the MFMA source sweep, gf_msweep.hip: W = 32, graphs from 49 152
+ * nodes on whose row groups balance, B >= 8; gf_khop then runs the K-1 hops of an edge feature in ONE launch), 0 = spmm_sell_kernel / the others */
+int gf_spmm_hop_kernel(const gf_plan* plan, int32_t op, int32_t B, int32_t W);
 int gf_time_khop(const gf_plan* const* plans, int32_t E, int32_t op, float* Z, int32_t B, int32_t W, int32_t K, int32_t iters,
                  void* stream, float* avg_ms);   /* the same for one gf_khop call (the K-1 hops of every edge feature on a tap stack) */
 int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* X_out, int32_t B, int32_t W,

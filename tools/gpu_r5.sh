@@ -2,6 +2,7 @@
 # Round-5 GPU sessions (one gpurun call each): bash tools/gpu_r5.sh <stage> ; logs under gpurun_out/r05_<stage>/
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp GFHIP_EXPERIMENTS=1
 S=$1; O=gpurun_out/r05_$S; mkdir -p $O
+case $S in a|b|c|d|e|f|g) export PROBE_SINGLE=1;; esac   # (the first sessions timed single hops; tools/hop_probe.py now times the chain)
 pmc() {  # pmc <tag> <counters...> -- <hop_probe args>: one rocprofv3 pass, per-kernel averages
   local tag=$1; shift; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
   rm -rf $O/pm; timeout 200 rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d $O/pm -o pmc -- python tools/hop_probe.py "$@" > $O/pm_$tag.log 2>&1 || echo "pmc pass failed: $tag"
@@ -99,5 +100,18 @@ i)  # the flaky refusal test x5; slack; NT gathers; leads
     PROBE_CHAIN=1 timeout 300 python tools/hop_probe.py cfg4 5 spmm_slack=$sl v:spmm_algo=3 v:$K+spmm_pfd=6 v:$K+spmm_pfd=8 2>&1 | grep "khop chain" | tee -a $O/khop_slack.log
   done
   GFHIP_LIB=$PWD/graph-neural-networks_amd/alegnn_amd/libgfhip_nt.so PROBE_CHAIN=1 timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=3 v:$K+spmm_pfd=6 v:$K+spmm_pfd=0 2>&1 | grep "khop chain" | tee $O/khop_nt.log
+  ;;
+j)  # entry quads as 128-byte lines
+  timeout 600 python -m pytest tests/test_gpu_msweep.py -x -q > $O/pytest_msweep.log 2>&1; tail -2 $O/pytest_msweep.log
+  K="spmm_algo=5+spmm_srcmask=0+spmm_stag=0+spmm_store=2+spmm_depth=10+spmm_fuse=1+spmm_bar=1"
+  PROBE_CHAIN=1 timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=3 v:$K+spmm_pfd=0 v:$K+spmm_pfd=6 v:$K+spmm_pfd=8 v:$K+spmm_pfd=8+spmm_bar=0 v:$K+spmm_pfd=8+spmm_depth=5 2>&1 | grep "khop chain" | tee -a $O/khop.log
+  timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=3 v:$K+spmm_pfd=8 v:$K+spmm_pfd=8+spmm_store=3 v:$K+spmm_pfd=0+spmm_store=3+spmm_srcmask=1048448 2>&1 | grep "spmm hop" | tee $O/hop.log
+  pmc tcp TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum -- cfg4 3 v:$K+spmm_pfd=8 | tee $O/pmc.log
+  ;;
+k)  # where an entry's time goes
+  K="spmm_srcmask=0 spmm_store=2 spmm_depth=10 spmm_fuse=1 spmm_bar=1 spmm_pfd=8"
+  timeout 300 python tools/msweep_trace.py $K spmm_stag=0 2>&1 | tail -12 | tee $O/trace_stag0.log
+  timeout 300 python tools/msweep_trace.py $K spmm_stag=3 2>&1 | tail -12 | tee $O/trace_stag3.log
+  timeout 300 python tools/msweep_trace.py $K spmm_stag=0 spmm_store=3 2>&1 | tail -12 | tee $O/trace_nostore.log
   ;;
 esac

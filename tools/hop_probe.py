@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Launch the dominant kernel of a bench.py workload a few times, nothing else on the stream after set-up: the target of
 `rocprofv3 --pmc ...` / `--kernel-trace --stats` (tools/pmc_collect.sh).  Usage: hop_probe.py <workload> [iters] [key=val ...]
-An argument `k=v+k=v+...` is a VARIANT: the node-major hop is timed once per variant on the same plan (A/B on one box, one process)."""
+An argument `k=v+k=v+...` is a VARIANT: the node-major K-hop chain (one gf_khop call on a tap stack, as the layer runs it; PROBE_SINGLE=1: one
+hop out of and into separate buffers) is timed once per variant on the same plan (A/B on one box, one process)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-neural-networks_amd")]
@@ -59,7 +60,7 @@ else:
         X0 = torch.randn(B, N, W, device=dev); X1 = torch.empty_like(X0)
         ms = ctypes.c_float()
         ref = None
-        if os.environ.get("PROBE_CHAIN"):   # the K-1 hops of one gf_khop call on a tap stack, as the layer runs them: ms per hop
+        if not os.environ.get("PROBE_SINGLE"):   # the K-1 hops of one gf_khop call on a tap stack, as the layer runs them: ms per hop
             Z = torch.empty(K, B, N, W, device=dev)
             Z[0].copy_(X0)
             for var in (variants or [""]):
