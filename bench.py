@@ -204,11 +204,14 @@ def main():
     warmup = args.warmup if args.warmup is not None else wl["warmup"]
     w = Workload(args.workload, wl, dev, rank)
     parallel.broadcast_parameters(w.module)
-    # One flat gradient bucket + ONE all-reduce per step under data parallelism; a single process has nothing to reduce and, like the
-    # trainer (modules/training.py), lets backward write the gradients (no bucket: at config 5 the bucket is the 4.7 GB of per-edge
-    # taps, and zeroing + accumulating into it costs 3.4 ms per step that no single-GPU training step pays).
+    # One flat gradient bucket + ONE all-reduce per step under data parallelism.  The step is THE SAME at every N: a single process
+    # zeroes the bucket and lets backward accumulate into its views too (it only skips the collective), so the N = 1 line and the
+    # N > 1 lines of a scaling curve time the same work.  Exception, stated on the line (config.grad_handling):
+    # the EVGF workload on a single process, whose bucket would be the 4.7 GB of per-edge taps (3.4 ms per step of zeroing and
+    # accumulating that no single-GPU training step pays); it is not part of the driver's scaling runs.
     params = [p for p in w.module.parameters() if p.requires_grad]
-    bucket = parallel.GradBucket(params) if distributed else None
+    use_bucket = distributed or wl["kind"] != "evgf"
+    bucket = parallel.GradBucket(params) if use_bucket else None
 
     ar_events = []                                                 # (start, end) HIP events around the all-reduce, filled only while ar_probe is on
     ar_probe = [False]
@@ -307,6 +310,8 @@ def main():
         cfg = dict(workload=args.workload, description=wl["desc"], graph=wl["graph"], N=wl["N"], nnz=w.nnz, batch_per_gpu=B,
                    global_batch=B * world, K=wl["K"], E=1, **({"T": wl["T"], "H": wl["H"]} if "T" in wl else {}), parallelism=f"batch-dp{world}", grad_bucket_bytes=(bucket.nbytes() if bucket is not None else sum(p.numel() * 4 for p in params)),
                    rccl_ranks=(dist.get_world_size() if distributed else 0), hip_graph=use_graph,
+                   grad_handling=("flat bucket: zeroed every step, backward accumulates into its views" + (", one all-reduce" if distributed else ", no collective (one rank)")
+                                  if bucket is not None else "p.grad = None before backward (no bucket)"),
                    devices=[torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())][:world])
         cfg.update({k: wl[k] for k in ("G", "F", "dimF", "sel", "pool", "alpha", "mlp") if k in wl})
         out = dict(metric="edges*taps/sec (GraphFilter fwd+bwd)", value=value, unit="edges*taps/s", n_gpus=world, steps=steps,

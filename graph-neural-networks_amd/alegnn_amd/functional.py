@@ -157,7 +157,7 @@ class _LSIGFChainFunction(torch.autograd.Function):
     those of the separate layers: outputs and gradients are bitwise the same."""
 
     @staticmethod
-    def forward(ctx, x, gso, relu_last, *params):
+    def forward(ctx, x, gso, relu_last, grad_mode, *params):
         L = _lib.lib()
         nl = len(params) // 2
         hs = [params[2 * l].contiguous() for l in range(nl)]
@@ -167,8 +167,9 @@ class _LSIGFChainFunction(torch.autograd.Function):
         x = x.contiguous()
         dev = x.device
         # The backward needs every layer's tap stack; a forward nobody differentiates (evaluation under no_grad, frozen inputs and
-        # parameters) needs only two at a time: layer l's and the one layer l writes its output into.
-        keep = any(ctx.needs_input_grad)
+        # parameters) needs only two at a time: layer l's and the one layer l writes its output into.  needs_input_grad mirrors
+        # requires_grad whatever the grad mode, and inside forward() grad mode is always off: the caller samples it (grad_mode).
+        keep = bool(grad_mode) and any(ctx.needs_input_grad)
         stacks = [None] * nl
 
         def stack_of(l):
@@ -232,7 +233,7 @@ class _LSIGFChainFunction(torch.autograd.Function):
                                                   hs[l].data_ptr(), Ps[l].data_ptr(), _ptr(out), _ptr(dh), _ptr(db), _ptr(ws), ws_bytes, B, G, F_, K, N,
                                                   flags, _ptr(mask), st), "gf_lsigf_backward_ex")
                 grads[2 * l], grads[2 * l + 1] = dh, db
-        return (dx, None, None, *grads)
+        return (dx, None, None, None, *grads)
 
 
 def lsigf_chain_supported(gso, x, layers):
@@ -278,7 +279,7 @@ def LSIGF_chain(layers, S, x):
             if b is not None and Fp != F_:
                 b = torch.nn.functional.pad(b, (0, 0, 0, Fp - F_))
         params += [h, b]
-    y = _LSIGFChainFunction.apply(x, gso, bool(layers[-1][2]), *params)
+    y = _LSIGFChainFunction.apply(x, gso, bool(layers[-1][2]), torch.is_grad_enabled(), *params)
     F_last = layers[-1][0].shape[0]
     return y[:, :F_last].contiguous() if y.shape[1] != F_last else y
 

@@ -117,14 +117,19 @@ class SelectionGNN(nn.Module):
             return
         self.coarsening = False       # more than one edge feature: selection pooling (architectures.py:224, :257)
         if sparse_in:
-            if self._order_name is not None:
-                raise NotImplementedError("node reordering needs the dense GSO (it is O(N^3) host work); pass order=None "
-                                          "with a sparse GSO, or reorder the graph beforehand")
+            # superset of the reference (its permFunction takes the dense [E,N,N] array, architectures.py:203-256): 'Degree' is O(nnz)
+            # on the sparse matrices; 'EDS' / 'SpectralProxies' densify for the ORDER up to graphTools.kDenseOrderingMaxNodes nodes
             self._gso = SparseGSO.from_any(GSO)
+            if self._order_name is not None:
+                mats, order = graphTools.perm_sparse(self._gso.mats, self._order_name)
+                self._gso = SparseGSO(mats)
+                self.order = order
+            else:
+                self.order = list(range(self._gso.N))
             self.E = self._gso.E
             self.S = self._gso
-            self.order = list(range(self._gso.N))
-            self._identity_order = True
+            self._identity_order = list(self.order) == list(range(len(self.order)))
+            self._order_index = None
             return
         if isinstance(GSO, torch.Tensor):
             GSO = GSO.detach().cpu().numpy()

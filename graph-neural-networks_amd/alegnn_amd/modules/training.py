@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ..parallel import GradBucket, broadcast_parameters
+from ..parallel import GradBucket, broadcast, broadcast_parameters
 
 
 def _world():
@@ -225,7 +225,7 @@ class Trainer:
         order = np.random.permutation(self.data.nTrain)
         if self.world > 1:
             t = torch.as_tensor(order, dtype=torch.int64, device=self.bucket.flat.device)
-            dist.broadcast(t, src=0)
+            broadcast(t, src=0)
             order = t.cpu().numpy()
         return [int(i) for i in order]
 

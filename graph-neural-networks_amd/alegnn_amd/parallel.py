@@ -20,6 +20,32 @@ import torch.distributed as dist
 _FORCE = os.environ.get("GFHIP_FORCE_COLLECTIVES", "0") == "1"
 
 
+def _stage_through_host(t, group=None):
+    """True when the collective has to go through a host copy: the "gloo" backend with a device tensor (a debugging / test
+    configuration -- e.g. two ranks sharing one GPU; RCCL reduces device buffers in place)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t, group=None):
+    if _stage_through_host(t, group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def broadcast(t, src=0, group=None):
+    if _stage_through_host(t, group):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 class GradBucket:
     """All parameter gradients as views into one contiguous buffer; ``allreduce_mean()`` is a single collective.
 
@@ -51,7 +77,7 @@ class GradBucket:
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(self.group)
             if world > 1 or _FORCE:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                all_reduce_sum(self.flat, self.group)
                 self.flat.div_(world)
         return self.flat
 
@@ -76,4 +102,4 @@ def broadcast_parameters(module, src=0):
     """Make every rank start from rank ``src``'s parameters (replicas must be identical for DP to be exact)."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE):
         for p in module.parameters():
-            dist.broadcast(p.data, src=src)
+            broadcast(p.data, src=src)

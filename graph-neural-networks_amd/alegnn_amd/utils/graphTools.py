@@ -75,6 +75,40 @@ def permEDS(S):
     return _apply_order(S3, order, scalar), order.tolist()
 
 
+# ---- the same orderings for GSOs that only exist sparse (superset: the reference's functions take a dense array) ------------------
+kDenseOrderingMaxNodes = 4096   # EDS / SpectralProxies need the eigendecomposition of the dense N x N matrix: O(N^3) host work
+
+
+def perm_sparse(mats, name):
+    """(list of reordered CSR matrices, order) for a list of scipy sparse N x N matrices (one per edge feature) and an ordering name
+    (None | 'Degree' | 'EDS' | 'SpectralProxies': graphTools.py:990-1161, as architectures.py:203-256 applies them).
+    'Degree' works on the sparse matrices (column sums over all edge features, highest first: O(nnz)).  Where several nodes have the
+    SAME degree their relative order is whatever numpy's argsort makes of the sums, as in the reference; a sum accumulated over a sparse
+    column can differ from the dense one in the last bit, so such ties may come out in another (equally valid) order than on the
+    dense copy of the same graph.  'EDS' / 'SpectralProxies' need the dense eigendecomposition: up to kDenseOrderingMaxNodes nodes the
+    matrices are densified for the computation of the ORDER only; beyond that they are refused."""
+    mats = [sp.csr_matrix(m) for m in mats]
+    n = mats[0].shape[0]
+    if name is None:
+        return mats, list(range(n))
+    if name == 'Degree':
+        d = np.zeros(n)
+        for m in mats:
+            d = d + np.asarray(m.sum(axis=0)).ravel()                     # column sums (np.sum(S, axis=1) of the [E,N,N] array), summed over e
+        order = np.flip(np.argsort(d), 0)
+    elif name in ('EDS', 'SpectralProxies'):
+        if n > kDenseOrderingMaxNodes:
+            raise NotImplementedError(f"order='{name}' needs the eigendecomposition of the dense {n} x {n} GSO (O(N^3) host work); it is "
+                                      f"available up to {kDenseOrderingMaxNodes} nodes -- use order='Degree' / None, or reorder the graph beforehand")
+        dense = np.stack([np.asarray(m.todense()) for m in mats])
+        _, order = (permEDS if name == 'EDS' else permSpectralProxies)(dense)
+        order = np.asarray(order)
+    else:
+        raise ValueError(f"unknown ordering '{name}'")
+    out = [sp.csr_matrix(m[order][:, order]) for m in mats]
+    return out, [int(i) for i in order]
+
+
 def edge_pattern(S) -> sp.csr_matrix:
     """Boolean N x N CSR with an entry wherever sum_e |S_e| > zeroTolerance (graphTools.py:424-432).
     S: dense [E,N,N] / [N,N] array, scipy sparse, or a list of scipy sparse (one per edge feature)."""

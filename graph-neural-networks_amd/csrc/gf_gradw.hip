@@ -744,9 +744,10 @@ int gf_bwd_fused_panel_launch(const float* Pp, const float* X0p, const float* h,
 #define GF_BF(TT, GG, FF)                                                                                                      \
     do {                                                                                                                        \
         auto kern = node_major ? bwd_fused_panel_kernel<TT, GG, FF, 1> : bwd_fused_panel_kernel<TT, GG, FF, 0>;                 \
-        if (lds > 64 * 1024) attr = gf_grant_lds((const void*)kern, lds); \
-        hipLaunchKernelGGL(kern, dim3(g.strips, g.numGI), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
-                           Nout, B, E, K, g.rowsPerWave, dx_panels, maskp, G, g.numGI, g.passes, g.ctp);                        \
+        if (lds > 64 * 1024) attr = gf_grant_lds((const void*)kern, lds);                                                       \
+        if (attr == hipSuccess)   /* (a refused LDS grant is reported below, not turned into an invalid launch) */               \
+            hipLaunchKernelGGL(kern, dim3(g.strips, g.numGI), dim3(kThreads), lds, st, Pp, X0p, h, dx, ws, ws + g.off_partial_b, (int)g.R, N, \
+                               Nout, B, E, K, g.rowsPerWave, dx_panels, maskp, G, g.numGI, g.passes, g.ctp);                    \
     } while (0)
 #define GF_BF64(TT, GG)                                                                                                         \
     do {                                                                                                                        \

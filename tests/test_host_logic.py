@@ -213,6 +213,33 @@ def test_selection_gnn_ctor_options():
     assert sparse_net.N == [50, 50] and sparse_net.GFL[0].N == 50
 
 
+def test_node_orderings_on_sparse_gsos():
+    """order= with a GSO that only exists sparse (round 5; the reference's permFunction takes the dense array, architectures.py:203-256):
+    'Degree' on CSR gives the dense result whenever the degrees are distinct up to rounding -- on the reference's own SBM graph the
+    degree SEQUENCE is identical and the reordered matrix is a simultaneous row / column permutation of S; 'EDS' and 'SpectralProxies'
+    densify for the order (small graphs) and are refused beyond graphTools.kDenseOrderingMaxNodes nodes."""
+    from alegnn_amd.utils import graphTools
+    d = load(os.path.join(GOLDEN, "selgnn_cfg1_sbm100.npz"))
+    S = d["S"][0]
+    g = dict(np.load(os.path.join(GOLDEN, "graphtools_sbm100.npz")))
+    for name in ("Degree", "EDS", "SpectralProxies"):
+        net = SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [100], gml.NoPool, [1], [], sp.csr_matrix(S), order=name)
+        order = np.asarray(net.order)
+        assert sorted(order.tolist()) == list(range(100))
+        assert np.array_equal(net.S.mats[0].toarray(), S[order][:, order])          # S_e[order][:, order], as graphTools.py:1046-1048
+        ref_order = np.asarray(g["order_" + name])
+        if name == "Degree":                                                         # same degrees position by position (ties may swap)
+            deg = S.sum(axis=0)
+            assert np.allclose(deg[order], deg[ref_order], rtol=0, atol=1e-12)
+        else:
+            assert order.tolist() == ref_order.tolist()
+    big = sp.identity(graphTools.kDenseOrderingMaxNodes + 1, format="csr")
+    with pytest.raises(NotImplementedError):
+        SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [big.shape[0]], gml.NoPool, [1], [], big, order="EDS")
+    net = SelectionGNN([1, 8], [3], True, torch.nn.ReLU, [big.shape[0]], gml.NoPool, [1], [], big, order="Degree")   # O(nnz): any size
+    assert len(net.order) == big.shape[0]
+
+
 @pytest.mark.parametrize("name", ["sbm100_L2", "fbego_L3"])
 def test_graclus_coarsening_matches_reference(name):
     """coarsen() against the reference's own outputs (graphs level by level, fake nodes, node order), and the
