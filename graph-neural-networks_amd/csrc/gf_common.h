@@ -147,8 +147,9 @@ struct gf_tuning {
     int spmm_generic = 0;       // 1 = force the generic one-thread-per-element kernel
     int spmm_algo = 0;          // 0 = default (the MFMA source sweep where gf_msweep_applicable says so, else SELL-8), 1 = CSR workgroup-staged kernel
                                 // (first version), 3 = SELL-8 always, 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED
-    int spmm_bar = 1;           // MFMA sweep: XCD barrier between batch entries (0 = free-running waves)
-    int spmm_pfd = 8;           // MFMA sweep: scalar prefetch of the source rows this many loop iterations ahead (0 = off)
+    int spmm_bar = 0;           // MFMA sweep: XCD barrier between batch entries too (0 = only between the hops of an entry, where the next hop reads what this one stored)
+    int spmm_pfd = 12;          // MFMA sweep: scalar prefetch of the source rows this many loop iterations ahead (0 = off; measured best: 12 of the 21
+                                // iterations of config 4 -- the prefetch then runs during the first 40 % of an entry, while the previous stores drain)
     int spmm_trace = 0;         // MFMA sweep, experiments: record phase time stamps (gf_debug_msweep_trace)
     int spmm_fuse = 1;          // MFMA sweep: the K - 1 hops of gf_khop in one launch, entry by entry (0 = one launch per hop)
     int spmm_depth = 0;         // MFMA sweep: gathers in flight per wave, 0 = default (10 for uniform GSOs with >= 15 sets per wave), 5

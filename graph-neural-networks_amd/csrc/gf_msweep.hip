@@ -14,13 +14,12 @@
 // compiler keeps across the block lives in v0-v23):
 //     a0  .. a255          accumulators 0..255:   accumulator (set s, quad q, slot i) = number 16 s + 4 q + i
 //     v112 .. v255         accumulators 256..399  (MFMAs take their C/D operand from either file)
-//   ring depth D = 5:
-//     v24 .. v43           ring: the 16 bytes per lane of the D gathers in flight (store phase: four output quads + addresses)
-//     v44 .. v48           their A operands (edge weight in the lanes of the destination slot, zero elsewhere)
-//     v49, v50, v108, v109 temporaries (gather offset / slot mask, alternating between steps)
-//     v52 .. v79           entries of this lane's position, one per step of a round (reloaded four at a time, a round ahead)
-//     v80 .. v107          their values (weighted GSOs)
-//   ring depth D = 10 (uniform GSOs: no value registers): ring v24 .. v63, A operands v64 .. v73, temporaries v74 .. v77, entries v78 .. v105
+//     v24 .. v63           ring: the 16 bytes per lane of the D = 10 gathers in flight (store phase: four output quads + addresses)
+//     v64 .. v73           their A operands (edge weight in the lanes of the destination slot, zero elsewhere)
+//     v74 .. v81           temporaries {entry, value, gather offset, slot mask} x step parity
+//     v82 .. v89           entry buffers of the even / odd rounds: ONE 16-byte load per lane and round (lane 8 p + i: quad i = steps 4 i .. 4 i + 3
+//                          of position p); a step's entry reaches the position's 8 lanes through two DPP moves (quad broadcast, then quad copy)
+//     v90 .. v97           value buffers (weighted GSOs)
 // Vector-memory operations of the loop are issued in a fixed order, loads return in order: the s_waitcnt counts are computed by the
 // assembler from that order (MS_RLCOUNT).  Wait states the hardware does not interlock (VALU write -> MFMA read: 2; MFMA write ->
 // VALU / VMEM read: up to 19) are covered by distance: an A operand is written five steps before its MFMAs, accumulators are read
@@ -49,18 +48,11 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
 .set MS_ACCV, 112
 .set MS_GATHER_NT, GF_MS_NT_VALUE
 .set MS_R0, 24
-.set MS_V0, 80
 .macro MS_SETMAP D
   .set MS_A0, 24 + 4*(\D)
-  .if (\D) == 5
-    .set MS_TA0, 49
-    .set MS_TA1, 108
-    .set MS_E0, 52
-  .else
-    .set MS_TA0, 74
-    .set MS_TA1, 76
-    .set MS_E0, 78
-  .endif
+  .set MS_T0, (24 + 5*(\D) + 1) & 0xfffe  // 8 temporaries: {entry, value, offset, mask} x step parity (register tuples start at even numbers)
+  .set MS_E0, MS_T0 + 8              // entry buffers: rounds of even / odd parity, 4 registers each (lane 8 p + i holds quad i of position p)
+  .set MS_V0, MS_E0 + 8              // value buffers (weighted GSOs)
 .endm
 .macro MS_MFMA s, q, k
   .if ((\s)*16 + (\q)*4) < 256
@@ -80,83 +72,108 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
     .set MS_I, MS_I+1
   .endr
 .endm
-// MS_CNT = entry reloads issued behind the gather of step n up to the gather of step n + D - 1 (a reload follows the steps 3, 7, ..
-// and S - 1 of every round)
+// MS_CNT = entry-buffer reloads issued behind the gather of step n up to the gather of step n + D - 1 (one reload per round, behind the
+// gather of the round's last step S - 1)
 .macro MS_RLCOUNT n, S, D
   .set MS_CNT, 0
   .set MS_DD, 0
   .rept \D
-    .set MS_SP, ((\n)+MS_DD) % (\S)
-    .if ((MS_SP & 3) == 3) || (MS_SP == (\S)-1)
+    .if (((\n)+MS_DD) % (\S)) == (\S)-1
       .set MS_CNT, MS_CNT+1
     .endif
     .set MS_DD, MS_DD+1
   .endr
 .endm
-// gather of step sp into ring slot k, its A operand, and -- behind the last step of an entry quad -- that quad of the round after
-// (rho = rounds between the loop iteration's first round and the round of this step)
-.macro MS_ISSUE sp, k, par, rho, S, UNI, RB, rs, re, rv, vfg, vslot, vevoff, smask, scur
-  .if \par
-    .set MS_TA, MS_TA1
+// Step sp of a round whose entries sit in buffer `buf` (round parity): lane 8 p + i of the buffer's register sp % 4 holds the entry of
+// position p for step 4 i + sp % 4.  MS_BCAST1 broadcasts lane (sp / 4) % 4 inside every quad, MS_BCAST2 copies the quad that holds it
+// over the position's other quad (rows of 16 lanes = two positions; banks = quads): two DPP moves, with >= 2 instructions between them.
+.macro MS_BCAST1 dst, src, sp
+  v_mov_b32_dpp v[\dst], v[\src] quad_perm:[((\sp)/4)%4,((\sp)/4)%4,((\sp)/4)%4,((\sp)/4)%4] row_mask:0xf bank_mask:0xf
+.endm
+.macro MS_BCAST2 dst, sp
+  .if ((\sp)/16) == 0
+    v_mov_b32_dpp v[\dst], v[\dst] row_shr:4 row_mask:0xf bank_mask:0xa
   .else
-    .set MS_TA, MS_TA0
+    v_mov_b32_dpp v[\dst], v[\dst] row_shl:4 row_mask:0xf bank_mask:0x5
   .endif
-  v_and_or_b32 v[MS_TA], v[MS_E0+(\sp)], \smask, \vfg
+.endm
+// gather of step sp into ring slot k and its A operand (the entry / value were broadcast into the temporaries of parity `par`), and --
+// behind the last step of a round -- the reload of that round's buffer with the round two later
+.macro MS_ISSUE sp, k, par, buf, rho, S, UNI, rs, re, rv, vfg, vslot, vevoff, smask, scur
+  .set MS_TA, MS_T0 + 4*(\par)
+  v_and_or_b32 v[MS_TA+2], v[MS_TA], \smask, \vfg
   .if MS_GATHER_NT
-    buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA], \rs, 0 offen nt
+    buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2], \rs, 0 offen nt
   .else
-    buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA], \rs, 0 offen
+    buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2], \rs, 0 offen
   .endif
-  v_bfe_i32 v[MS_TA+1], v[MS_E0+(\sp)], \vslot, 1
+  v_bfe_i32 v[MS_TA+3], v[MS_TA], \vslot, 1
   .if \UNI
-    v_and_b32 v[MS_A0+(\k)], 1.0, v[MS_TA+1]
+    v_and_b32 v[MS_A0+(\k)], 1.0, v[MS_TA+3]
   .else
-    v_and_b32 v[MS_A0+(\k)], v[MS_V0+(\sp)], v[MS_TA+1]
+    v_and_b32 v[MS_A0+(\k)], v[MS_TA+1], v[MS_TA+3]
   .endif
-  .if (((\sp) & 3) == 3) || ((\sp) == (\S)-1)
-    buffer_load_dwordx4 v[MS_E0+((\sp)/4)*4:MS_E0+((\sp)/4)*4+3], \vevoff, \re, \scur offen offset:((\rho)+1)*(\RB)+((\sp)/4)*128
+  .if (\sp) == (\S)-1
+    buffer_load_dwordx4 v[MS_E0+4*(\buf):MS_E0+4*(\buf)+3], \vevoff, \re, \scur offen offset:((\rho)+2)*1024
     .if (\UNI) == 0
-      buffer_load_dwordx4 v[MS_V0+((\sp)/4)*4:MS_V0+((\sp)/4)*4+3], \vevoff, \rv, \scur offen offset:((\rho)+1)*(\RB)+((\sp)/4)*128
+      buffer_load_dwordx4 v[MS_V0+4*(\buf):MS_V0+4*(\buf)+3], \vevoff, \rv, \scur offen offset:((\rho)+2)*1024
     .endif
   .endif
 .endm
-// S sets, ring depth D, U rounds per loop iteration (U * S is a multiple of D: ring slots are static); scur = byte offset of the
-// iteration's first round in the entry stream, sit = iterations left
+// S sets, ring depth D, two rounds per loop iteration (the entry buffers alternate by round parity; 2 S steps must be a multiple of D: ring
+// slots are static); scur = byte offset of the iteration's first round in the entry stream, sit = iterations left
 .macro MS_BODY S, UNI, RB, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, stl0, stl1, uid
   MS_SETMAP \D
   MS_ZERO \S
-  .set MS_Q, 0
-  .rept ((\S)+3)/4
-    buffer_load_dwordx4 v[MS_E0+4*MS_Q:MS_E0+4*MS_Q+3], \vevoff, \re, 0 offen offset:MS_Q*128
-    .if (\UNI) == 0
-      buffer_load_dwordx4 v[MS_V0+4*MS_Q:MS_V0+4*MS_Q+3], \vevoff, \rv, 0 offen offset:MS_Q*128
-    .endif
-    .set MS_Q, MS_Q+1
-  .endr
+  buffer_load_dwordx4 v[MS_E0:MS_E0+3], \vevoff, \re, 0 offen
+  buffer_load_dwordx4 v[MS_E0+4:MS_E0+7], \vevoff, \re, 0 offen offset:1024
+  .if (\UNI) == 0
+    buffer_load_dwordx4 v[MS_V0:MS_V0+3], \vevoff, \rv, 0 offen
+    buffer_load_dwordx4 v[MS_V0+4:MS_V0+7], \vevoff, \rv, 0 offen offset:1024
+  .endif
   s_waitcnt vmcnt(0)
   s_memtime \stl0
   .set MS_N, 0
   .rept \D
-    MS_ISSUE MS_N, MS_N, (MS_N & 1), 0, \S, \UNI, \RB, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
+    MS_BCAST1 (MS_T0+4*(MS_N&1)), (MS_E0+(MS_N%4)), MS_N
+    .if (\UNI) == 0
+      MS_BCAST1 (MS_T0+4*(MS_N&1)+1), (MS_V0+(MS_N%4)), MS_N
+    .endif
+    s_nop 1
+    MS_BCAST2 (MS_T0+4*(MS_N&1)), MS_N
+    .if (\UNI) == 0
+      MS_BCAST2 (MS_T0+4*(MS_N&1)+1), MS_N
+    .endif
+    MS_ISSUE MS_N, MS_N, (MS_N & 1), 0, 0, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
     .set MS_N, MS_N+1
   .endr
 MS_LOOP_\uid:
   .set MS_N, 0
-  .rept (\U)*(\S)
+  .rept 2*(\S)
+    .set MS_SP, (MS_N+(\D)) % (\S)              // the step whose gather this step issues, its round (0 .. 2 past the iteration's first) and buffer
+    .set MS_RHO, (MS_N+(\D)) / (\S)
     MS_RLCOUNT MS_N, \S, \D
     s_waitcnt vmcnt((\D) - 1 + MS_CNT*(2-(\UNI)))
+    MS_BCAST1 (MS_T0+4*(MS_N&1)), (MS_E0+4*(MS_RHO&1)+(MS_SP%4)), MS_SP
+    .if (\UNI) == 0
+      MS_BCAST1 (MS_T0+4*(MS_N&1)+1), (MS_V0+4*(MS_RHO&1)+(MS_SP%4)), MS_SP
+    .endif
     MS_MFMA (MS_N % (\S)), 0, (MS_N % (\D))
     MS_MFMA (MS_N % (\S)), 1, (MS_N % (\D))
+    MS_BCAST2 (MS_T0+4*(MS_N&1)), MS_SP
+    .if (\UNI) == 0
+      MS_BCAST2 (MS_T0+4*(MS_N&1)+1), MS_SP
+    .endif
     MS_MFMA (MS_N % (\S)), 2, (MS_N % (\D))
     MS_MFMA (MS_N % (\S)), 3, (MS_N % (\D))
     .if \PF
       s_load_dword \sdummy, \xptr, \spfc offset:MS_N*0x4000
       s_load_dword \sdummy, \xptr, \spfc offset:MS_N*0x4000+0x40
     .endif
-    MS_ISSUE ((MS_N+(\D)) % (\S)), (MS_N % (\D)), (MS_N & 1), ((MS_N+(\D)) / (\S)), \S, \UNI, \RB, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
+    MS_ISSUE MS_SP, (MS_N % (\D)), (MS_N & 1), (MS_RHO & 1), MS_RHO, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
     .set MS_N, MS_N+1
   .endr
-  s_add_u32 \scur, \scur, (\U)*(\RB)
+  s_add_u32 \scur, \scur, 2048
   .if \PF
     s_add_u32 \spfr, \spfr, \schunk
     s_min_u32 \spfc, \spfr, \smaxpf
@@ -227,12 +244,12 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                         const float* __restrict__ Xin, float* __restrict__ Xtaps, size_t tapStrideBytes, int nhops, int N, int B, int passes,
                         int rounds, unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask, int pf_lead, int stagger,
                         int nostore, unsigned long long* __restrict__ trace) {
-    constexpr int S4 = (S + 3) / 4 * 4;
-    constexpr unsigned kRoundBytes = 8u * S4 * 4u;
-    constexpr int U = (S % D == 0) ? 1 : 2;                 // rounds per loop iteration: U * S steps are a multiple of the ring depth
-    static_assert((U * S) % D == 0 && S >= D + 5 && S <= kMsMaxSets && (D == 5 || (D == 10 && UNI)),
-                  "ring slots are static; an entry quad of round r + 1 is requested behind its last use in round r and must have been "
-                  "waited for (in-order returns) before the ring reaches round r + 1: S - D > 3; the deep ring takes the value registers");
+    constexpr unsigned kRoundBytes = 1024u;                 // a round of the entry stream: 8 positions x 8 quads x 16 bytes
+    constexpr int U = 2;                                    // rounds per loop iteration (the two entry buffers alternate by round parity)
+    static_assert((U * S) % D == 0 && D < S && S <= kMsMaxSets && S <= 32,
+                  "ring slots are static: 2 S steps are a multiple of the depth; a round's buffer is reloaded (for the round two later) behind "
+                  "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
+                  "inside the two rounds of an iteration (12-bit instruction offsets)");
     __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
     asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT));
     asm volatile(GF_MS_MACROS);
@@ -242,8 +259,8 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     const unsigned wid = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) * (kThreads / 64) + wv));   // wave of this XCD
     const unsigned pos = lane >> 3, fg16 = (lane & 7u) * 16u, slotbit = lane & 3u;
     const unsigned tapBytes = (unsigned)N * 128u;
-    const size_t streamWords = (size_t)(rounds + 2) * 8 * S4;
-    const unsigned evoff = pos * 16u;                       // this lane's position inside an entry quad's 128-byte line
+    const size_t streamWords = (size_t)(rounds + 2) * 256;
+    const unsigned evoff = lane * 16u;                      // this lane's 16 bytes of a round of the entry stream (lane 8 p + i: quad i of position p)
     const unsigned rowlds = (unsigned)(size_t)(&s_rows[wv][0]) + pos * 16u;   // (an LDS address is the low half of the generic pointer)
     const unsigned smask = 0xffffff80u & src_mask;
     const unsigned chunkBytes = (unsigned)((N + rounds - 1) / rounds) * 128u;   // source rows per round
@@ -356,7 +373,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
         trace = g_trace;
     }
     const bool pf = g_tune.spmm_pfd > 0;
-    const bool deep = m.ms_uniform && m.ms_sets >= 15 && g_tune.spmm_depth != 5;   // ring of 10 gathers (the value registers hold it)
+    const bool deep = g_tune.spmm_depth != 5;   // ring of 10 gathers; 5: experiments
 #define GF_MS(SV, UV, PV, DV)                                                                                                          \
     hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV>), grid, block, 0, st, m.ms_ent, m.ms_val, m.ms_rows, Xin, Xtaps, (size_t)tapStride * 4, nhops, N, B, \
                        m.ms_passes, m.ms_rounds, gate, use_barrier, m.sell_uval, src_mask, g_tune.spmm_pfd, g_tune.spmm_stag, g_tune.spmm_store == 3, trace)
@@ -365,24 +382,24 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
         if (pf) GF_MS(SV, UV, 1, DV);                 \
         else GF_MS(SV, UV, 0, DV);                    \
     } while (0)
-#define GF_MS_D(SV)                                   \
+#define GF_MS_D(SV, UV)                               \
     do {                                              \
-        if (deep) GF_MS_P(SV, 1, 10);                 \
-        else GF_MS_P(SV, 1, 5);                       \
+        if (deep) GF_MS_P(SV, UV, 10);                \
+        else GF_MS_P(SV, UV, 5);                      \
     } while (0)
     if (m.ms_uniform) {
         switch (m.ms_sets) {
             case 10: GF_MS_P(10, 1, 5); break;
-            case 15: GF_MS_D(15); break;
-            case 20: GF_MS_D(20); break;
-            default: GF_MS_D(25); break;
+            case 15: GF_MS_D(15, 1); break;
+            case 20: GF_MS_D(20, 1); break;
+            default: GF_MS_D(25, 1); break;
         }
     } else {
         switch (m.ms_sets) {
             case 10: GF_MS_P(10, 0, 5); break;
-            case 15: GF_MS_P(15, 0, 5); break;
-            case 20: GF_MS_P(20, 0, 5); break;
-            default: GF_MS_P(25, 0, 5); break;
+            case 15: GF_MS_D(15, 0); break;
+            case 20: GF_MS_D(20, 0); break;
+            default: GF_MS_D(25, 0); break;
         }
     }
 #undef GF_MS_D

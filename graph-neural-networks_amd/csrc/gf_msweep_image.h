@@ -46,13 +46,15 @@ struct MsweepImage {
     int32_t s4 = 0;                                  // S rounded up to a multiple of 4 (entries of a position are loaded 4 at a time)
     int32_t passes = 0;                              // ceil(groups / (128 * S * 8)); one pass = one sweep of the sources per batch entry
     int32_t rounds = 0;                              // T; the streams hold T + 2 rounds (the kernel's entry loads run two rounds ahead)
-    std::vector<uint32_t> ent;                       // [passes][128 waves][T + 2][s4 / 4 quads][8 positions][4]: the 8 positions' entries of 4 consecutive steps share a 128-byte line
+    std::vector<uint32_t> ent;                       // [passes][128 waves][T + 2][8 positions][8 quads][4]: a round is 1 KB -- lane 8 p + i of the wave loads
+                                                     // quad i (steps 4 i .. 4 i + 3) of position p with ONE 16-byte load per round; the kernel hands
+                                                     // a step's entry to the position's 8 lanes with two DPP moves
     std::vector<float> val;                          // same shape, weighted GSOs only (empty when uniform)
     std::vector<uint32_t> rows;                      // [passes][128 waves][S][32]  output byte offset (row * 128) of (set, position * 4 + slot), kMsPad = none
     int64_t real_entries = 0;                        // fill = real_entries / (passes * 128 * S * 8 * T)
     double fill() const { return passes ? (double)real_entries / ((double)passes * kMsWavesPerXcd * sets * 8 * rounds) : 0.0; }
-    size_t stream_words() const { return (size_t)(rounds + 2) * 8 * s4; }   // per (pass, wave)
-    size_t at(int32_t t, int32_t p, int32_t step) const { return ((size_t)t * (s4 / 4) + step / 4) * 32 + (size_t)p * 4 + (step & 3); }
+    size_t stream_words() const { return (size_t)(rounds + 2) * 256; }   // per (pass, wave)
+    size_t at(int32_t t, int32_t p, int32_t step) const { return (size_t)t * 256 + (size_t)p * 32 + (step / 4) * 4 + (step & 3); }
 };
 
 // rowptr / col / val: CSR of the operator in ORIGINAL row order, columns ascending inside a row.  uniform: the values are not stored
@@ -69,19 +71,29 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
         if ((int64_t)max_passes * kMsWavesPerXcd * s * 8 >= groups) { S = s; break; }
     if (!S) return im;
     const int32_t passes = (int32_t)((groups + (int64_t)kMsWavesPerXcd * S * 8 - 1) / ((int64_t)kMsWavesPerXcd * S * 8));
-    // rows -> groups of 4: longest row first, each to the group with the fewest entries so far that still has a free slot (the
-    // first `groups` rows seed one group each): every group ends with (almost) the same entry total -- the longest one sets T
-    std::vector<int32_t> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b]; });
-    std::vector<int32_t> grow((size_t)groups * 4, -1);
-    std::vector<int32_t> glen(groups, 0), gcnt(groups, 0);
-    {
+    // rows -> sets: BAND j = rows [4096 j, 4096 (j + 1)) is one accumulator set of the whole XCD (128 waves x 8 positions x 4 slots), and the
+    // LOWEST bands get the LAST sets: a wave stores its sets in order, so the rows written last -- the ones still in the XCD's L2 when the
+    // next hop of the fused chain starts its sweep at source row 0 -- are the rows that sweep gathers first.
+    // rows of a band -> groups of 4: longest row first, each to the group with the fewest entries so far that still has a free slot (the
+    // first rows seed one group each): every group ends with (almost) the same entry total -- the longest one sets T
+    const int32_t band_rows = kMsWavesPerXcd * 8 * 4;
+    const int32_t bands = (n + band_rows - 1) / band_rows;
+    const int32_t band_groups = kMsWavesPerXcd * 8;
+    const int32_t groups_all = bands * band_groups;       // (group slots; the last band may leave some empty)
+    std::vector<int32_t> grow((size_t)groups_all * 4, -1);
+    std::vector<int32_t> glen(groups_all, 0), gcnt(groups_all, 0);
+    std::vector<int32_t> order;
+    for (int32_t j = 0; j < bands; ++j) {
+        const int32_t r0 = j * band_rows, r1 = std::min(n, r0 + band_rows);
+        const int32_t ng = (r1 - r0 + 3) / 4;
+        order.resize(r1 - r0);
+        std::iota(order.begin(), order.end(), r0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b]; });
         std::priority_queue<std::pair<int32_t, int32_t>, std::vector<std::pair<int32_t, int32_t>>, std::greater<std::pair<int32_t, int32_t>>> open;
-        for (int32_t i = 0; i < n; ++i) {
+        for (int32_t i = 0; i < r1 - r0; ++i) {
             const int32_t r = order[i], d = rowptr[r + 1] - rowptr[r];
             int32_t g;
-            if (i < groups) g = i;
+            if (i < ng) g = j * band_groups + i;
             else {
                 g = open.top().second;
                 open.pop();
@@ -93,7 +105,7 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
     }
     int64_t total = 0;
     int32_t longest = 0;
-    for (int32_t g = 0; g < groups; ++g) total += glen[g], longest = std::max(longest, glen[g]);
+    for (int32_t g = 0; g < groups_all; ++g) total += glen[g], longest = std::max(longest, glen[g]);
     const double mean = (double)total / groups;
     int32_t T = std::max(longest, (int32_t)std::ceil(mean * (100 + slack_pct) / 100.0));
     T = std::max(T, 1);
@@ -108,14 +120,15 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
     im.ent.assign((size_t)passes * kMsWavesPerXcd * sw, kMsPad);
     if (!uniform) im.val.assign(im.ent.size(), 0.f);
     im.rows.assign((size_t)passes * kMsWavesPerXcd * S * 32, kMsPad);
-    // groups -> (pass, wave, set, position): consecutive groups go to consecutive WAVES first, then positions, then sets, then passes
+    // groups of a band -> (wave, position): consecutive groups go to consecutive WAVES first, then positions
     struct Ent { int32_t src; int32_t slot; float v; };
     std::vector<Ent> list;
     std::vector<int32_t> f, bk;
-    for (int32_t g = 0; g < groups; ++g) {
-        const int32_t wave = g % kMsWavesPerXcd;
-        const int32_t rest = g / kMsWavesPerXcd;
-        const int32_t p = rest % 8, set = (rest / 8) % S, pass = rest / (8 * S);
+    for (int32_t g = 0; g < groups_all; ++g) {
+        if (gcnt[g] == 0) continue;
+        const int32_t band = g / band_groups, gl = g % band_groups;
+        const int32_t wave = gl % kMsWavesPerXcd, p = gl / kMsWavesPerXcd;
+        const int32_t pass = band / S, set = S - 1 - band % S;            // low bands = last sets
         list.clear();
         for (int32_t slot = 0; slot < 4; ++slot) {
             const int32_t r = grow[(size_t)g * 4 + slot];
@@ -213,7 +226,7 @@ inline double simulate_msweep_hits(const MsweepImage& im, int32_t n, int32_t lin
             if (stamp[r] == t) stamp[r] = -1, --resident;
         }
     };
-    const int64_t stream_per_round = (int64_t)kMsWavesPerXcd * 8 * im.s4 * 4 / 128;
+    const int64_t stream_per_round = (int64_t)kMsWavesPerXcd * 1024 / 128;
     for (int32_t pass = 0; pass < im.passes; ++pass)
         for (int32_t t = 0; t < im.rounds; ++t) {
             for (int64_t i = 0; i < stream_per_round; ++i) fifo.push_back({++now, -1}), ++resident;

@@ -27,7 +27,7 @@ def tune(**kw):
 @pytest.fixture
 def knobs():
     yield tune
-    tune(spmm_algo=0, spmm_bar=1, spmm_slack=5, spmm_group=1, spmm_pfd=8)
+    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=12)
 
 
 def hop(plans, op, Xt, algo, **kw):
@@ -97,6 +97,37 @@ def test_msweep_hop_soak_at_config4_size(knobs):
         got = hop(plans, 0, Xt, 5, spmm_bar=rep & 1)
         bad = int((got != ref).sum())
         assert bad == 0, (rep, bad)
+
+
+@pytest.mark.parametrize("n,deg,B,K,weighted", [(60000, 4, 16, 4, False), (100000, 5, 24, 5, False), (52000, 5, 9, 3, True)])
+def test_msweep_fused_khop_chain_is_bitwise_the_per_hop_launches(n, deg, B, K, weighted, knobs):
+    """gf_khop with the MFMA sweep runs the K-1 hops of an edge feature in ONE launch, batch entry by batch entry: hop h gathers the rows
+    hop h-1 of the same launch stored (ordered by vmcnt(0) + the XCD barrier).  The tap stack must equal, bit for bit, the one the
+    per-hop SELL-8 launches build -- in the default configuration (spmm_algo = 0: these graphs are above the default threshold), with
+    the fusion off, and for both orientations."""
+    A = er(n, deg, seed=n + K, weighted=weighted)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    L = _lib.lib()
+    x0 = torch.randn(B, n, 32, device=DEV)
+
+    def chain(op, **kw):
+        tune(**kw)
+        Z = torch.full((K, B, n, 32), float("nan"), device=DEV)
+        Z[0].copy_(x0)
+        _lib.check(L.gf_khop(plans, 1, op, Z.data_ptr(), B, 32, K, stream()))
+        torch.cuda.synchronize()
+        return Z
+
+    for op in (0, 1):
+        ref = chain(op, spmm_algo=3)
+        assert L.gf_spmm_hop_kernel(plans[0], op, B, 32) == 0
+        for kw in (dict(spmm_algo=0, spmm_fuse=1), dict(spmm_algo=0, spmm_fuse=0), dict(spmm_algo=5, spmm_fuse=1, spmm_bar=1)):
+            for rep in range(2):
+                got = chain(op, **kw)
+                assert L.gf_spmm_hop_kernel(plans[0], op, B, 32) == 1
+                assert torch.equal(got, ref), (op, kw, rep, int((got != ref).sum()))
+    tune(spmm_fuse=1)
 
 
 def test_msweep_is_refused_where_it_does_not_apply(knobs):

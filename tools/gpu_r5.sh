@@ -114,4 +114,9 @@ k)  # where an entry's time goes
   timeout 300 python tools/msweep_trace.py $K spmm_stag=3 2>&1 | tail -12 | tee $O/trace_stag3.log
   timeout 300 python tools/msweep_trace.py $K spmm_stag=0 spmm_store=3 2>&1 | tail -12 | tee $O/trace_nostore.log
   ;;
+l)  # row bands -> sets (low rows stored last: still in L2 when the next hop of the fused chain starts)
+  timeout 600 python -m pytest tests/test_gpu_msweep.py -x -q > $O/pytest_msweep.log 2>&1; tail -2 $O/pytest_msweep.log
+  timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=3 v:spmm_algo=0 v:spmm_algo=0+spmm_fuse=0 v:spmm_algo=0+spmm_fuse=1+spmm_bar=0 2>&1 | grep "khop chain" | tee $O/khop.log
+  pmc l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- cfg4 3 v:spmm_algo=0 v:spmm_algo=0+spmm_fuse=0 | tee $O/pmc.log
+  ;;
 esac
