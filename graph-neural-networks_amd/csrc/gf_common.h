@@ -150,6 +150,7 @@ struct gf_tuning {
     int spmm_bar = 0;           // MFMA sweep: XCD barrier between batch entries too (0 = only between the hops of an entry, where the next hop reads what this one stored)
     int spmm_pfd = 12;          // MFMA sweep: scalar prefetch of the source rows this many loop iterations ahead (0 = off; measured best: 12 of the 21
                                 // iterations of config 4 -- the prefetch then runs during the first 40 % of an entry, while the previous stores drain)
+    int spmm_passes = 2;        // MFMA sweep image: passes (sweeps of the sources) allowed per batch entry -- 1: N <= 102 400, 2: up to 204 800 (set BEFORE gf_plan_create)
     int spmm_trace = 0;         // MFMA sweep, experiments: record phase time stamps (gf_debug_msweep_trace)
     int spmm_fuse = 1;          // MFMA sweep: the K - 1 hops of gf_khop in one launch, entry by entry (0 = one launch per hop)
     int spmm_depth = 0;         // MFMA sweep: gathers in flight per wave, 0 = default (10 for uniform GSOs with >= 15 sets per wave), 5

@@ -68,6 +68,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_depth")) g_tune.spmm_depth = value;
     else if (!strcmp(key, "spmm_fuse")) g_tune.spmm_fuse = value;
     else if (!strcmp(key, "spmm_trace")) g_tune.spmm_trace = value;
+    else if (!strcmp(key, "spmm_passes")) g_tune.spmm_passes = value;
     else if (!strcmp(key, "spmm_stag")) g_tune.spmm_stag = value;
     else if (!strcmp(key, "spmm_srcmask")) g_tune.spmm_srcmask = value;
     else if (!strcmp(key, "spmm_slack")) g_tune.spmm_slack = value;
@@ -424,9 +425,9 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
     }
     // MSWEEP image (gf_msweep_image.h): graphs whose gather panel does not fit L2, when the groups balance (no hub rows)
     if (n >= kMsMinNodes) {
-        MsweepImage ms = build_msweep_image(n, a.rowptr.data(), a.col.data(), a.val.data(), uni, g_tune.spmm_slack, 1);
+        MsweepImage ms = build_msweep_image(n, a.rowptr.data(), a.col.data(), a.val.data(), uni, g_tune.spmm_slack, g_tune.spmm_passes > 0 ? g_tune.spmm_passes : 1);
         d.ms_fill = ms.fill();
-        if (ms.passes == 1 && ms.fill() >= 0.6) {
+        if (ms.passes >= 1 && ms.passes <= 2 && ms.fill() >= 0.6) {
             d.ms_sets = ms.sets;
             d.ms_passes = ms.passes;
             d.ms_rounds = ms.rounds;

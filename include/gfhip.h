@@ -257,7 +257,11 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
 /* ---- tuning / debugging knobs (no reference counterpart; results are identical for every setting):
  * "spmm_bt" (0 = heuristic | 1 | 2 | 4), "spmm_spw" (0 = default | 1 | 2 | 4 slices per wave), "spmm_generic" (0/1),
  * "spmm_algo" (0 = default: the MFMA source sweep (gf_msweep.hip) where it applies, else the SELL-8 wave kernel | 1 = CSR workgroup
- * kernel | 3 = SELL-8 always | 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED where it does not apply), "spmm_xcd" (0/1),
+ * kernel | 3 = SELL-8 always | 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED where it does not apply), the sweep's own knobs:
+ * "spmm_fuse" (0/1 the K-1 hops of gf_khop in one launch), "spmm_bar" (0/1 XCD barrier between batch entries too), "spmm_pfd" (scalar
+ * prefetch lead in loop iterations, 0 = off), "spmm_depth" (0 = 10 gathers in flight | 5), "spmm_slack" / "spmm_passes" (image: rounds
+ * beyond the mean group length in percent, passes allowed per batch entry; read by gf_plan_create), timing-only: "spmm_srcmask",
+ * "spmm_stag", "spmm_trace"; "spmm_xcd" (0/1),
  * "spmm_group" (0/1 locality groups in the row schedule of graphs with N >= 32768; read by gf_plan_create),
  * "spmm_pf" (workgroups per tile prefetching the next gather panel, -1 = heuristic, 0 = off), "spmm_ucap" (0 | 8 | 16 gathers in flight per lane), "spmm_load" (0 = plain | 1 = non-temporal gather loads),
  * "spmm_store" (0 = plain | 1 = write-through sc1 | 2 = non-temporal output stores), "contract_generic" (0/1),

@@ -67,6 +67,8 @@ def er(n, deg, seed, directed=False, weighted=False):
     (60000, 4, 40, False, False),       # 15 sets
     (81000, 3, 8, False, True),         # 20 sets, weighted
     (102400, 3, 11, False, False),      # the largest single-pass graph
+    (130000, 3, 9, False, False),       # two passes per batch entry (each sweeps the sources for half of the rows)
+    (204800, 2, 8, False, True),        # the largest graph with an image
     (33000, 6, 8, True, True),
 ])
 def test_msweep_hop_against_scipy_and_bitwise_against_sell(n, deg, B, directed, weighted, bar, knobs):
@@ -99,7 +101,7 @@ def test_msweep_hop_soak_at_config4_size(knobs):
         assert bad == 0, (rep, bad)
 
 
-@pytest.mark.parametrize("n,deg,B,K,weighted", [(60000, 4, 16, 4, False), (100000, 5, 24, 5, False), (52000, 5, 9, 3, True)])
+@pytest.mark.parametrize("n,deg,B,K,weighted", [(60000, 4, 16, 4, False), (100000, 5, 24, 5, False), (52000, 5, 9, 3, True), (140000, 3, 8, 3, False)])
 def test_msweep_fused_khop_chain_is_bitwise_the_per_hop_launches(n, deg, B, K, weighted, knobs):
     """gf_khop with the MFMA sweep runs the K-1 hops of an edge feature in ONE launch, batch entry by batch entry: hop h gathers the rows
     hop h-1 of the same launch stored (ordered by vmcnt(0) + the XCD barrier).  The tap stack must equal, bit for bit, the one the

@@ -16,8 +16,12 @@ def tune(**kw):
 cases = [(33000, 10, False, 128), (40000, 10, False, 128), (60000, 10, False, 128), (80000, 10, False, 128), (100000, 10, False, 128),
          (100000, 10, True, 128), (60000, 10, True, 128), (100000, 10, False, 100), (100000, 10, False, 16), (100000, 10, False, 8),
          (100000, 20, False, 64), (100000, 4, False, 128), (50000, 10, False, 256)]
-if len(sys.argv) > 1:
-    cases = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+args = [a for a in sys.argv[1:] if "=" not in a]
+for kv in sys.argv[1:]:
+    if "=" in kv:
+        k, v = kv.split("="); tune(**{k: int(v)})
+if args:
+    cases = [tuple(int(x) for x in a.split(",")) for a in args]
 K = 5
 for n, deg, weighted, B in cases:
     A = graphgen.er(n, avg_degree=float(deg), seed=1)
