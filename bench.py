@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None, help="batch entries of the workload timed on the CPU")
+    ap.add_argument("--comparator", action="store_true", help="also time the UNMODIFIED dense formulation (graphML.py:152-175 in torch ops, dense S) on "
+                    "this GPU through PyTorch-ROCm for filter workloads of any size (default: only where dense S is small, N <= 20k)")
     ap.add_argument("--detail", action="store_true", help="per-building-block timings to stderr (filter workloads)")
     ap.add_argument("--no-graph", action="store_true", help="launch-bound workloads (cfg1): eager launches instead of one HIP-graph replay per step")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="gf_tune knob (needs GFHIP_EXPERIMENTS=1; repeatable)")
@@ -302,6 +304,7 @@ def main():
     if args.detail and rank == 0 and wl["kind"] == "filter":
         detail = kernel_breakdown(L, w, wl)
         log("breakdown_ms", json.dumps(detail))
+    comparator = dense_reference_on_gpu(w, wl, args.comparator) if rank == 0 and world == 1 else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = CPU_BASELINES[wl["kind"]](w, wl, args.cpu_sample or wl["cpu_sample"])
@@ -317,6 +320,9 @@ def main():
         out = dict(metric="edges*taps/sec (GraphFilter fwd+bwd)", value=value, unit="edges*taps/s", n_gpus=world, steps=steps,
                    warmup=warmup, ms_per_step=ms_per_step, ms_per_step_median=ms_median, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic", config=cfg, roofline=roofline, cpu_baseline=cpu)
+        if comparator is not None:
+            comparator["speedup_of_this_library"] = round(comparator["ms_per_step"] / ms_per_step, 2)
+            out["no_rewrite_comparator"] = comparator
         if dist_info is not None:
             out["distributed"] = dist_info
         if mfma is not None:
@@ -657,6 +663,44 @@ def cpu_db(w, wl, sample):
     return dict(value=n * w.units / dt, unit="edges*taps/s", cores=th, host_cores=ncores, kind="port", seconds=round(dt, 3),
                 sample=f"GRNN_DB restatement (oracle/db_oracle.py, CPU torch, fwd + autograd bwd), {n} of the batch's {wl['B']} samples, all {wl['T']} steps, "
                        f"{th} threads (fastest of 1 / 8 / 32)")
+
+
+def dense_reference_on_gpu(w, wl, force):
+    """SURVEY.md 8d's optional third column: the reference's own formulation -- dense S [1,N,N], one torch.matmul per tap, the taps grown by
+    torch.cat, permute + matmul + permute for the bank (graphML.py:152-175) -- run UNMODIFIED in torch ops on this GPU (rocBLAS GEMMs),
+    forward + backward, same inputs and parameters as the timed step.  Filter workloads; by default only where dense S is small."""
+    if wl["kind"] != "filter" or (wl["N"] > 20_000 and not force):
+        return None
+    dev, N, K = w.dev, wl["N"], wl["K"]
+    S = torch.zeros((1, N, N), dtype=torch.float32, device=dev)
+    coo = w.A.tocoo()
+    S[0, torch.as_tensor(coo.row, device=dev, dtype=torch.int64), torch.as_tensor(coo.col, device=dev, dtype=torch.int64)] = torch.as_tensor(coo.data, dtype=torch.float32, device=dev)
+    h = w.module.weight.detach().clone().requires_grad_(True)
+    b = w.module.bias.detach().clone().requires_grad_(True)
+    x = w.x.detach().clone().requires_grad_(True)
+    Fo, E, _, G = h.shape
+
+    def step():
+        for t in (h, b, x):
+            t.grad = None
+        B = x.shape[0]
+        cur = x.reshape(B, 1, G, N)
+        z = x.reshape(B, 1, 1, G, N).repeat(1, E, 1, 1, 1)
+        for _ in range(1, K):                                   # :158-161
+            cur = torch.matmul(cur, S.reshape(1, E, N, N))
+            z = torch.cat((z, cur.reshape(B, E, 1, G, N)), dim=2)
+        y = torch.matmul(z.permute(0, 4, 1, 2, 3).reshape(B, N, E * K * G), h.reshape(Fo, E * K * G).permute(1, 0)).permute(0, 2, 1) + b   # :170-175
+        y.backward(w.dy if hasattr(w, "dy") else torch.ones_like(y))
+    step()
+    torch.cuda.synchronize()
+    n = 3 if N <= 20_000 else 1
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return dict(kind="reference formulation unmodified (dense S, torch.matmul / cat / permute) on this GPU via PyTorch-ROCm", ms_per_step=round(ms, 3),
+                value=wl["B"] * w.nnz * K / (ms * 1e-3), unit="edges*taps/s", dense_S_bytes=int(N) * int(N) * 4, steps=n)
 
 
 CPU_BASELINES = {"db": cpu_db, "filter": cpu_filter, "selgnn": cpu_selgnn, "evgf": cpu_evgf}
