@@ -65,12 +65,13 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
     MsweepImage im;
     if (n <= 0 || (int64_t)n * 128 >= (int64_t)kMsPad) return im;
     const int32_t groups = (n + 3) / 4;
-    // sets per wave: the smallest geometry that holds every group in max_passes passes
+    // passes: as few as the largest geometry (25 sets per wave) allows -- every pass sweeps the sources again; sets per wave: the smallest
+    // geometry that holds every group in that many passes
+    const int32_t passes = (int32_t)((groups + (int64_t)kMsWavesPerXcd * kMsMaxSets * 8 - 1) / ((int64_t)kMsWavesPerXcd * kMsMaxSets * 8));
     int32_t S = 0;
-    for (int32_t s = 2 * kMsDepth; s <= kMsMaxSets; s += kMsDepth)   // (the kernel reloads an entry quad a round ahead: >= 10 steps per round)
-        if ((int64_t)max_passes * kMsWavesPerXcd * s * 8 >= groups) { S = s; break; }
-    if (!S) return im;
-    const int32_t passes = (int32_t)((groups + (int64_t)kMsWavesPerXcd * S * 8 - 1) / ((int64_t)kMsWavesPerXcd * S * 8));
+    for (int32_t s = 2 * kMsDepth; s <= kMsMaxSets; s += kMsDepth)   // (the kernel's ring needs >= 10 steps per round)
+        if ((int64_t)passes * kMsWavesPerXcd * s * 8 >= groups) { S = s; break; }
+    if (!S || passes > max_passes) return im;
     // rows -> sets: BAND j = rows [4096 j, 4096 (j + 1)) is one accumulator set of the whole XCD (128 waves x 8 positions x 4 slots), and the
     // LOWEST bands get the LAST sets: a wave stores its sets in order, so the rows written last -- the ones still in the XCD's L2 when the
     // next hop of the fused chain starts its sweep at source row 0 -- are the rows that sweep gathers first.
