@@ -215,8 +215,8 @@ class _LSIGFChainFunction(torch.autograd.Function):
             for l in range(nl - 1, -1, -1):
                 F_, _, K, G = hs[l].shape
                 last, first = l == nl - 1, l == 0
-                need_dh = ctx.needs_input_grad[3 + 2 * l]
-                need_db = ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
+                need_dh = ctx.needs_input_grad[4 + 2 * l]                 # (inputs: x, gso, relu_last, grad_mode, then h_l, b_l per layer)
+                need_db = ctx.has_bias[l] and ctx.needs_input_grad[5 + 2 * l]
                 dh = torch.empty_like(hs[l]) if need_dh else None
                 db = torch.empty((F_, 1), dtype=torch.float32, device=dev) if need_db else None
                 ws, ws_bytes = None, 0
