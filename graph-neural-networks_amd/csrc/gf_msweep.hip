@@ -40,6 +40,9 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
 #ifndef GF_MS_NT   // experiments (make variant): gathers with the non-temporal hint
 #define GF_MS_NT 0
 #endif
+#ifndef GF_MS_STPLAIN   // output rows with plain stores (1, default) or non-temporal ones (0; make variant): plain stores leave the rows in the XCD's
+#define GF_MS_STPLAIN 1 // L2, and the rows stored LAST are the lowest bands -- the ones the next hop of the fused chain gathers first (1.24 -> 1.13 ms at config 4)
+#endif
 #define GF_MS_STR2(x) #x
 #define GF_MS_STR(x) GF_MS_STR2(x)
 #define GF_MS_MACROS R"(
@@ -47,6 +50,7 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
 .set MS_MACROS_DEFINED, 1
 .set MS_ACCV, 112
 .set MS_GATHER_NT, GF_MS_NT_VALUE
+.set MS_STORE_PLAIN, GF_MS_STPLAIN_VALUE
 .set MS_R0, 24
 .macro MS_SETMAP D
   .set MS_A0, 24 + 4*(\D)
@@ -217,7 +221,11 @@ MS_LOOP_\uid:
         .set MS_Q, MS_Q+1
       .endr
       v_add_u32 v[MS_R0+16+MS_I], v[MS_E0+4*(MS_S&1)+MS_I], \vfg
-      buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen nt
+      .if MS_STORE_PLAIN
+        buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen
+      .else
+        buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen nt
+      .endif
       .set MS_I, MS_I+1
     .endr
     .set MS_S, MS_S+1
@@ -251,7 +259,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                   "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
                   "inside the two rounds of an iteration (12-bit instruction offsets)");
     __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
-    asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT));
+    asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN));
     asm volatile(GF_MS_MACROS);
     const unsigned lane = threadIdx.x & 63;
     const int xcd = blockIdx.x & 7;

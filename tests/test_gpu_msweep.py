@@ -27,7 +27,7 @@ def tune(**kw):
 @pytest.fixture
 def knobs():
     yield tune
-    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=12)
+    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=16)
 
 
 def hop(plans, op, Xt, algo, **kw):
