@@ -33,8 +33,8 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMsGateWords = 64;      // per XCD: one arrival counter on a 256-byte line of its own
-constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be live at once (slots rotate)
+constexpr int kMsGateWords = 64;      // per XCD: the arrival counter (word 0) and the generation word (word 16) of its barrier, 256 bytes of their own
+constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at once on different streams (slots rotate; zeroed once, at plan creation)
 
 // Assembler macros (a basic asm statement: no operand substitution, `%` and `|` are the assembler's).  Defined once per module.
 #ifndef GF_MS_NT   // experiments (make variant): gathers with the non-temporal hint
@@ -128,13 +128,13 @@ constexpr int kMsGateSlots = 16;      // launches whose barrier counters may be 
 // slots are static); scur = byte offset of the iteration's first round in the entry stream, sit = iterations left
 .macro MS_BODY S, UNI, RB, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, stl0, stl1, uid
   MS_SETMAP \D
-  MS_ZERO \S
   buffer_load_dwordx4 v[MS_E0:MS_E0+3], \vevoff, \re, 0 offen
   buffer_load_dwordx4 v[MS_E0+4:MS_E0+7], \vevoff, \re, 0 offen offset:1024
   .if (\UNI) == 0
     buffer_load_dwordx4 v[MS_V0:MS_V0+3], \vevoff, \rv, 0 offen
     buffer_load_dwordx4 v[MS_V0+4:MS_V0+7], \vevoff, \rv, 0 offen offset:1024
   .endif
+  MS_ZERO \S
   s_waitcnt vmcnt(0)
   s_memtime \stl0
   .set MS_N, 0
@@ -273,7 +273,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     const unsigned smask = 0xffffff80u & src_mask;
     const unsigned chunkBytes = (unsigned)((N + rounds - 1) / rounds) * 128u;   // source rows per round
     unsigned* ctr = gate + (size_t)xcd * kMsGateWords;
-    unsigned epoch = 0;
+    unsigned slot = 0;                                      // (entry, hop, pass) bodies done: the trace slot
     int table_of = -1;
     // (experiments) XCD x starts x * stagger * ~3.4 us late, so that the XCDs' store phases do not coincide
     for (int i = 0; i < xcd * stagger; ++i) __builtin_amdgcn_s_sleep(127);
@@ -312,34 +312,39 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             const unsigned long long t1 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
             const bool dependent = nhops > 1 && pass == passes - 1 && hop + 1 < nhops;   // the next hop gathers what this one stores
+            ++slot;
             if (use_barrier || dependent) {
-                // XCD barrier: one scalar atomic per workgroup on the XCD's counter (monotonic over the launch), then the first wave polls
-                // with returning scalar atomics (they execute in the L2: coherent, and they wait on lgkmcnt, not on the stores' vmcnt).
-                // Between entries it only keeps the XCD's waves together (bounded: passed anyway when it does not open in time, results
-                // do not depend on it).  Between the hops of an entry it orders this hop's stores (acknowledged by the XCD's L2: vmcnt(0))
-                // before the next hop's gathers from the other CUs: there a barrier that does not open (a workgroup that never became
-                // resident) ends the kernel with a trap -- a launch failure, never a wrong result.
-                ++epoch;
+                // XCD barrier, self-resetting (no state to zero between launches: a captured launch replays as is): the workgroups of an
+                // XCD add 1 to the XCD's arrival counter; the 32nd takes the counter back to 0 and advances the generation word, the others
+                // poll the generation they read BEFORE arriving (it cannot move until all 32, they included, have arrived).  Scalar atomics:
+                // they execute in the XCD's L2 and wait on lgkmcnt, not on the stores' vmcnt.  Between the hops of an entry the barrier
+                // orders this hop's stores (acknowledged by the L2: vmcnt(0)) before the next hop's gathers from the other CUs.  The launch
+                // is cooperative, so all 256 workgroups are resident; a barrier that still does not open within ~2 s (a wrong guess about the
+                // workgroup -> XCD placement) ends the kernel with a trap: a launch failure, never a wrong result.
                 if (dependent) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (wv == 0) {
-                    unsigned t = 1u;
+                    unsigned g0 = 0u, t = 1u, g = 0u;
+                    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(g0) : "s"(ctr + 16) : "memory");
                     asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ctr) : "memory");
-                    const unsigned target = 32u * epoch;
-                    const int limit = dependent ? 4000000 : 4000;
-                    int spin = 0;
-                    for (; t + 1u < target && spin < limit; ++spin) {
-                        __builtin_amdgcn_s_sleep(16);
-                        t = 0u;
-                        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ctr) : "memory");
-                        t -= 1u;   // (compared as "arrivals before mine", like the first read)
+                    if (t == 31u) {
+                        unsigned m32 = 32u, one = 1u;
+                        asm volatile("s_atomic_sub %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(m32) : "s"(ctr) : "memory");
+                        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(one) : "s"(ctr + 16) : "memory");
+                    } else {
+                        int spin = 0;
+                        for (g = g0; g == g0 && spin < 4000000; ++spin) {
+                            __builtin_amdgcn_s_sleep(16);
+                            g = 0u;
+                            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(g) : "s"(ctr + 16) : "memory");
+                        }
+                        if (g == g0) __builtin_trap();
                     }
-                    if (dependent && t + 1u < target) __builtin_trap();
                 }
                 __builtin_amdgcn_s_barrier();
             }
-            if (trace && wid == 0 && lane == 0 && epoch <= 64) {   // (experiments) phase stamps of the XCD's first wave: entry start, previous
-                unsigned long long* t = trace + ((size_t)xcd * 64 + (epoch - 1)) * 8;   // stores drained + entries loaded, loop end, stores issued, barrier passed
+            if (trace && wid == 0 && lane == 0 && slot <= 64) {   // (experiments) phase stamps of the XCD's first wave: entry start, previous
+                unsigned long long* t = trace + ((size_t)xcd * 64 + (slot - 1)) * 8;   // stores drained + entries loaded, loop end, stores issued, barrier passed
                 t[0] = t0; t[1] = tl0; t[2] = tl1; t[3] = t1; t[4] = __builtin_amdgcn_s_memtime();
             }
         }
@@ -371,7 +376,6 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     static std::atomic<unsigned> next_slot{0};
     unsigned* gate = m.ms_gate + (size_t)(next_slot.fetch_add(1) % kMsGateSlots) * 8 * kMsGateWords;
     const int use_barrier = g_tune.spmm_bar;
-    if (use_barrier || nhops > 1) GF_HIP(hipMemsetAsync(gate, 0, 8 * kMsGateWords * sizeof(unsigned), st));
     dim3 grid(256), block(kThreads);
     const unsigned src_mask = g_tune.spmm_srcmask ? (unsigned)g_tune.spmm_srcmask : 0xffffffffu;   // experiments (timing only): confine the gathers to a window
     unsigned long long* trace = nullptr;
@@ -382,9 +386,28 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     }
     const bool pf = g_tune.spmm_pfd > 0;
     const bool deep = g_tune.spmm_depth != 5;   // ring of 10 gathers; 5: experiments
+    // A fused chain depends on its XCD barriers (hop h + 1 gathers what hop h stored): it is launched COOPERATIVELY -- the runtime starts the
+    // grid only when all 256 workgroups can be resident together (another stream's kernel on some CUs delays the launch instead of leaving
+    // workgroups spinning at a barrier that cannot open).  A single hop has no such dependence and takes the plain launch.
+    const uint32_t* a_ent = m.ms_ent;
+    const float* a_val = m.ms_val;
+    const uint32_t* a_rows = m.ms_rows;
+    size_t a_stride = (size_t)tapStride * 4;
+    int a_nhops = nhops, a_N = N, a_B = B, a_passes = m.ms_passes, a_rounds = m.ms_rounds, a_bar = use_barrier, a_pfd = g_tune.spmm_pfd,
+        a_stag = g_tune.spmm_stag, a_nostore = g_tune.spmm_store == 3;
+    float a_uval = m.sell_uval;
+    unsigned a_mask = src_mask;
+    void* args[] = {&a_ent, &a_val, &a_rows, &Xin, &Xtaps, &a_stride, &a_nhops, &a_N, &a_B, &a_passes, &a_rounds, &gate, &a_bar, &a_uval, &a_mask,
+                    &a_pfd, &a_stag, &a_nostore, &trace};
+    hipError_t lerr = hipSuccess;
 #define GF_MS(SV, UV, PV, DV)                                                                                                          \
-    hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV>), grid, block, 0, st, m.ms_ent, m.ms_val, m.ms_rows, Xin, Xtaps, (size_t)tapStride * 4, nhops, N, B, \
-                       m.ms_passes, m.ms_rounds, gate, use_barrier, m.sell_uval, src_mask, g_tune.spmm_pfd, g_tune.spmm_stag, g_tune.spmm_store == 3, trace)
+    do {                                                                                                                               \
+        if (nhops > 1 || use_barrier)                                                                                                  \
+            lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV>, grid, block, args, 0, st);              \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV>), grid, block, 0, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
+                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_stag, a_nostore, trace);                      \
+    } while (0)
 #define GF_MS_P(SV, UV, DV)                            \
     do {                                              \
         if (pf) GF_MS(SV, UV, 1, DV);                 \
@@ -413,6 +436,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
 #undef GF_MS_D
 #undef GF_MS_P
 #undef GF_MS
+    GF_HIP(lerr);
     GF_LAUNCH_CHECK("spmm_msweep_kernel");
     return GF_OK;
 }

@@ -132,6 +132,35 @@ def test_msweep_fused_khop_chain_is_bitwise_the_per_hop_launches(n, deg, B, K, w
     tune(spmm_fuse=1)
 
 
+def test_msweep_chain_replays_from_a_hip_graph(knobs):
+    """The trainer's hipGraph mode captures whole steps: the fused chain (a memset node for its barrier counters + one cooperative launch)
+    must be capturable and replay to the same bits."""
+    n, B, K = 60000, 16, 4
+    A = er(n, 4, seed=21)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    L = _lib.lib()
+    tune(spmm_algo=0)
+    Z = torch.full((K, B, n, 32), float("nan"), device=DEV)
+    Z[0].normal_()
+    _lib.check(L.gf_khop(plans, 1, 0, Z.data_ptr(), B, 32, K, stream()))
+    torch.cuda.synchronize()
+    ref = Z.clone()
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        _lib.check(L.gf_khop(plans, 1, 0, Z.data_ptr(), B, 32, K, side.cuda_stream))
+    torch.cuda.current_stream(DEV).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _lib.check(L.gf_khop(plans, 1, 0, Z.data_ptr(), B, 32, K, stream()))
+    for rep in range(3):
+        Z[1:].fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(Z, ref), rep
+
+
 def test_msweep_is_refused_where_it_does_not_apply(knobs):
     """spmm_algo = 5 never falls back silently: other widths, small batches and graphs without an image are errors."""
     A = er(40000, 5, seed=5)
