@@ -77,6 +77,7 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
     // next hop of the fused chain starts its sweep at source row 0 -- are the rows that sweep gathers first.
     // rows of a band -> groups of 4: longest row first, each to the group with the fewest entries so far that still has a free slot (the
     // first rows seed one group each): every group ends with (almost) the same entry total -- the longest one sets T
+    const int32_t cap = (int32_t)std::ceil((double)rowptr[n] / groups * (100 + slack_pct) / 100.0);   // rounds the slack asks for (before rounding to even)
     const int32_t band_rows = kMsWavesPerXcd * 8 * 4;
     const int32_t bands = (n + band_rows - 1) / band_rows;
     const int32_t band_groups = kMsWavesPerXcd * 8;
@@ -102,6 +103,31 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
             grow[(size_t)g * 4 + gcnt[g]++] = r;
             glen[g] += d;
             if (gcnt[g] < 4) open.push({glen[g], g});
+        }
+        // The greedy deal leaves a few groups of a band above the others (its last rows have no choice left), and the LONGEST group of all
+        // bands sets the number of rounds every wave walks.  Local repair: while a group of the band is longer than the cap (the rounds the
+        // slack asks for anyway), swap one of its rows with a shorter row of the band's shortest group if that lowers the longer of the two.
+        for (int32_t iter = 0; iter < 4096; ++iter) {
+            int32_t hi = j * band_groups, lo = hi;
+            for (int32_t g = j * band_groups; g < j * band_groups + ng; ++g) {
+                if (glen[g] > glen[hi]) hi = g;
+                if (glen[g] < glen[lo]) lo = g;
+            }
+            if (glen[hi] <= cap || glen[hi] - glen[lo] < 2) break;
+            int32_t best = 0, ba = -1, bb = -1;
+            const int32_t gap = glen[hi] - glen[lo];
+            for (int32_t a = 0; a < gcnt[hi]; ++a)
+                for (int32_t b = 0; b < gcnt[lo]; ++b) {
+                    const int32_t ra = grow[(size_t)hi * 4 + a], rb = grow[(size_t)lo * 4 + b];
+                    const int32_t delta = (rowptr[ra + 1] - rowptr[ra]) - (rowptr[rb + 1] - rowptr[rb]);
+                    if (delta > 0 && delta < gap && std::min(delta, gap - delta) > best) best = std::min(delta, gap - delta), ba = a, bb = b;
+                }
+            if (ba < 0) break;
+            const int32_t ra = grow[(size_t)hi * 4 + ba], rb = grow[(size_t)lo * 4 + bb];
+            const int32_t delta = (rowptr[ra + 1] - rowptr[ra]) - (rowptr[rb + 1] - rowptr[rb]);
+            std::swap(grow[(size_t)hi * 4 + ba], grow[(size_t)lo * 4 + bb]);
+            glen[hi] -= delta;
+            glen[lo] += delta;
         }
     }
     int64_t total = 0;

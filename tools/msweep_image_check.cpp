@@ -55,6 +55,22 @@ static int check(int32_t n, double avg_deg, int hubs, uint32_t seed, int W, bool
 
 int main(int argc, char** argv) {
     int bad = 0;
+    if (argc > 2 && !strcmp(argv[1], "csr")) {   // a CSR dumped as int32: n, nnz, rowptr[n + 1], col[nnz]  (tools/msweep_image_check csr <file> [slack])
+        FILE* f = fopen(argv[2], "rb");
+        int32_t n = 0, nnz = 0;
+        if (!f || fread(&n, 4, 1, f) != 1 || fread(&nnz, 4, 1, f) != 1) return 2;
+        std::vector<int32_t> rp(n + 1), col(nnz);
+        if (fread(rp.data(), 4, n + 1, f) != (size_t)n + 1 || fread(col.data(), 4, nnz, f) != (size_t)nnz) return 2;
+        fclose(f);
+        std::vector<float> val(nnz, 1.f);
+        for (int i = 3; i < std::max(argc, 4); ++i) {
+            const int slack = i < argc ? atoi(argv[i]) : 5;
+            MsweepImage im = build_msweep_image(n, rp.data(), col.data(), val.data(), true, slack, 2);
+            printf("n=%d nnz=%d slack=%d: sets=%d passes=%d rounds=%d fill=%.4f  LRU hit rate %.3f (28k lines)\n", n, nnz, slack, im.sets, im.passes, im.rounds, im.fill(),
+                   im.passes ? simulate_msweep_hits(im, n, 28000) : 0.0);
+        }
+        return 0;
+    }
     if (argc > 1) {   // exploration: n slack...
         const int32_t n = atoi(argv[1]);
         for (int i = 2; i < argc; ++i) bad += check(n, 10.0, 0, 4, 1, true, atoi(argv[i]), 1, true);
