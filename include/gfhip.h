@@ -280,6 +280,10 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * environment variable GFHIP_EXPERIMENTS=1 was set when the library was loaded; without it the tuning state is the built-in
  * default and immutable, i.e. the product path reads no mutable global state.  Every setting gives identical results. */
 int gf_tune(const char* key, int32_t value);
+/* experiments: the phase time stamps of the last spmm_msweep_kernel launch made with gf_tune("spmm_trace", 1) -- out[8 XCDs][64 (entry, hop)
+ * slots][8] shader-clock stamps of the XCD's first wave: {body start, round loop start, round loop end, stores issued, barrier passed, 0, 0, 0}
+ * (tools/msweep_trace.py).  Synchronises the device. */
+int gf_debug_msweep_trace(unsigned long long* out);
 
 #ifdef __cplusplus
 }
