@@ -4,8 +4,9 @@
 // One workgroup of four waves per CU (one 512-register wave per SIMD), 256 workgroups; workgroup L runs on XCD L % 8 (observed
 // dispatch order: a wrong guess costs speed, never correctness).  XCD x works through batch entries x, x + 8, ...: its 128 waves hold
 // the entry's whole output (S sets x 32 rows x 32 features per wave) in accumulator registers, walk the entry's source rows together
-// (T rounds of S steps; a step = one 8-row gather + four v_mfma_f32_4x4x1_16b_f32), store, and meet at an XCD barrier before the
-// next entry.
+// (T rounds of S steps; a step = one 8-row gather + four v_mfma_f32_4x4x1_16b_f32) and store; the K - 1 hops of an entry run back to
+// back in one launch with an XCD barrier between them (hop h + 1 gathers what hop h stored -- with plain stores, so that the rows
+// stored last, the lowest row bands, are still in the XCD's L2 when the next hop's sweep starts with them).
 //
 // The body of a (batch entry, pass) is ONE inline-asm block written with assembler macros (MS_* below): hipcc's scheduler and register
 // allocator cannot express this kernel -- given the same program as C++ with builtins it hoisted the gathers into vmcnt(0) groups,
@@ -22,8 +23,8 @@
 //     v90 .. v97           value buffers (weighted GSOs)
 // Vector-memory operations of the loop are issued in a fixed order, loads return in order: the s_waitcnt counts are computed by the
 // assembler from that order (MS_RLCOUNT).  Wait states the hardware does not interlock (VALU write -> MFMA read: 2; MFMA write ->
-// VALU / VMEM read: up to 19) are covered by distance: an A operand is written five steps before its MFMAs, accumulators are read
-// only after the loop (s_nop block in MS_BODY).
+// VALU / VMEM read: up to 19) are covered by distance: an A operand is written D steps before its MFMAs, the two DPP moves of an entry
+// have two MFMAs between them (VALU write -> DPP read: 2), accumulators are read only after the loop (s_nop block in MS_BODY).
 #include <stdlib.h>
 #include <atomic>
 
@@ -279,8 +280,8 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     for (int i = 0; i < xcd * stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     // Batch entry b runs through all its hops before the XCD takes the next entry (hop h reads the tap hop h - 1 wrote: Xin for the
-    // first, then Xtaps + (h - 1) taps; it writes Xtaps + h taps): the rows a hop gathers for the first time were written by this XCD a
-    // moment ago -- the last ones are still in its L2, the others in the Infinity Cache instead of HBM.
+    // first, then Xtaps + (h - 1) taps; it writes Xtaps + h taps): the rows a hop gathers first were written by this XCD a moment ago
+    // and are still in its L2 (the image stores the lowest row bands last).
     for (int b = xcd; b < B; b += 8)
       for (int hop = 0; hop < nhops; ++hop) {
         const char* src = hop == 0 ? reinterpret_cast<const char*>(Xin) : reinterpret_cast<const char*>(Xtaps) + (size_t)(hop - 1) * tapStrideBytes;

@@ -20,7 +20,8 @@
 //     entry in one pass.  The wave's program is T ROUNDS of S steps: round t, step s serves set s.  The group of 4 destination rows
 //     behind (set, position) lists the (source, slot) pairs of its rows sorted by source and spreads them over the T rounds so that
 //     round t holds sources near t * N / T: every wave of the XCD is at the same place of the source range at the same time, whatever
-//     set it is serving.  Rows are dealt to the groups by degree so that all groups hold (almost) the same number of entries;
+//     set it is serving.  Rows are dealt to the groups by degree so that all groups hold (almost) the same number of entries (bands of
+//     consecutive row ids = sets, lowest band = last set: stored last, gathered first by the next hop);
 //   * fp32 MFMA is an exact fmaf chain and the rounds visit a row's sources in ascending order: bit for bit the sums of spmm_sell_kernel.
 //
 // Entry word (32 bits): bits 7..31 = byte offset of the source row inside the tap (row * 128), bits 0..3 = one-hot slot; a gap is
@@ -58,8 +59,8 @@ struct MsweepImage {
 };
 
 // rowptr / col / val: CSR of the operator in ORIGINAL row order, columns ascending inside a row.  uniform: the values are not stored
-// (the kernel sums the gathered rows and scales once, as spmm_sell_kernel<UNI = 1> does).  slack_pct: rounds beyond the longest
-// group, in percent of the mean group length -- the room the placement has to keep round ~ source (12-20 % measured best).
+// (the kernel sums the gathered rows and scales once, as spmm_sell_kernel<UNI = 1> does).  slack_pct: rounds beyond the MEAN
+// group length, in percent -- the room the placement has to keep round ~ source (config 4: 5 % -> T = 42 for groups of 39.1: measured best).
 inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const int32_t* col, const float* val, bool uniform,
                                       int32_t slack_pct = 15, int32_t max_passes = 1) {
     MsweepImage im;
@@ -72,22 +73,24 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
     for (int32_t s = 2 * kMsDepth; s <= kMsMaxSets; s += kMsDepth)   // (the kernel's ring needs >= 10 steps per round)
         if ((int64_t)passes * kMsWavesPerXcd * s * 8 >= groups) { S = s; break; }
     if (!S || passes > max_passes) return im;
-    // rows -> sets: BAND j = rows [4096 j, 4096 (j + 1)) is one accumulator set of the whole XCD (128 waves x 8 positions x 4 slots), and the
+    // rows -> sets: a BAND of consecutive row ids is one accumulator set of the whole XCD (128 waves x 8 positions x up to 4 slots), and the
     // LOWEST bands get the LAST sets: a wave stores its sets in order, so the rows written last -- the ones still in the XCD's L2 when the
     // next hop of the fused chain starts its sweep at source row 0 -- are the rows that sweep gathers first.
-    // rows of a band -> groups of 4: longest row first, each to the group with the fewest entries so far that still has a free slot (the
+    // rows of a band -> groups of 3 or 4: longest row first, each to the group with the fewest entries so far that still has a free slot (the
     // first rows seed one group each): every group ends with (almost) the same entry total -- the longest one sets T
-    const int32_t cap = (int32_t)std::ceil((double)rowptr[n] / groups * (100 + slack_pct) / 100.0);   // rounds the slack asks for (before rounding to even)
-    const int32_t band_rows = kMsWavesPerXcd * 8 * 4;
-    const int32_t bands = (n + band_rows - 1) / band_rows;
+    const int32_t cap = (int32_t)std::ceil((double)rowptr[n] / std::min<int64_t>((int64_t)passes * S * kMsWavesPerXcd * 8, n) * (100 + slack_pct) / 100.0);   // rounds the slack asks for, over the mean group (before rounding to even)
+    // (the rows are spread EVENLY over the bands the geometry has: a band then holds a few groups of 3 rows instead of leaving the last
+    // band half empty, the mean group is shorter and so is the longest -- config 4: 25 600 groups of 39.1 entries instead of 25 000 of 40.0)
     const int32_t band_groups = kMsWavesPerXcd * 8;
+    const int32_t bands = passes * S;
+    const int32_t band_rows = std::min(band_groups * 4, ((n + bands - 1) / bands + 3) / 4 * 4);
     const int32_t groups_all = bands * band_groups;       // (group slots; the last band may leave some empty)
     std::vector<int32_t> grow((size_t)groups_all * 4, -1);
     std::vector<int32_t> glen(groups_all, 0), gcnt(groups_all, 0);
     std::vector<int32_t> order;
     for (int32_t j = 0; j < bands; ++j) {
-        const int32_t r0 = j * band_rows, r1 = std::min(n, r0 + band_rows);
-        const int32_t ng = (r1 - r0 + 3) / 4;
+        const int32_t r0 = std::min(n, j * band_rows), r1 = std::min(n, r0 + band_rows);
+        const int32_t ng = std::min(band_groups, r1 - r0);        // every group slot of the band gets a seed row while rows last
         order.resize(r1 - r0);
         std::iota(order.begin(), order.end(), r0);
         std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b]; });
@@ -133,8 +136,7 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
     int64_t total = 0;
     int32_t longest = 0;
     for (int32_t g = 0; g < groups_all; ++g) total += glen[g], longest = std::max(longest, glen[g]);
-    const double mean = (double)total / groups;
-    int32_t T = std::max(longest, (int32_t)std::ceil(mean * (100 + slack_pct) / 100.0));
+    int32_t T = std::max(longest, cap);
     T = std::max(T, 1);
     T += T & 1;                                      // (the kernel's loop body spans two rounds when S is odd)
     if (T > kMsMaxRounds) return im;
