@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 GPU sessions (one gpurun call each): bash tools/gpu_r5.sh <stage> ; logs under gpurun_out/r05_<stage>/
+# (lab notebook: the stages are kept as they were run; knobs of the early stages -- spmm_pf2, spmm_pfe, spmm_pfs, spmm_pfa -- no longer exist)
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp GFHIP_EXPERIMENTS=1
 S=$1; O=gpurun_out/r05_$S; mkdir -p $O
 case $S in a|b|c|d|e|f|g) export PROBE_SINGLE=1;; esac   # (the first sessions timed single hops; tools/hop_probe.py now times the chain)
@@ -118,5 +119,13 @@ l)  # row bands -> sets (low rows stored last: still in L2 when the next hop of 
   timeout 600 python -m pytest tests/test_gpu_msweep.py -x -q > $O/pytest_msweep.log 2>&1; tail -2 $O/pytest_msweep.log
   timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=3 v:spmm_algo=0 v:spmm_algo=0+spmm_fuse=0 v:spmm_algo=0+spmm_fuse=1+spmm_bar=0 2>&1 | grep "khop chain" | tee $O/khop.log
   pmc l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- cfg4 3 v:spmm_algo=0 v:spmm_algo=0+spmm_fuse=0 | tee $O/pmc.log
+  ;;
+z)  # the shipped kernel: phase stamps and counters on the final sources (no knobs: the product defaults)
+  timeout 300 python tools/msweep_trace.py 2>&1 | tail -12 | tee $O/trace_default.log
+  timeout 300 python tools/msweep_trace.py spmm_store=3 2>&1 | tail -12 | tee $O/trace_nostore.log
+  pmc l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- cfg4 3 v:spmm_algo=0 | tee $O/pmc.log
+  pmc tcp TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum -- cfg4 3 v:spmm_algo=0 | tee -a $O/pmc.log
+  pmc sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SMEM -- cfg4 3 v:spmm_algo=0 | tee -a $O/pmc.log
+  pmc mfma SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE -- cfg4 3 v:spmm_algo=0 | tee -a $O/pmc.log
   ;;
 esac
