@@ -194,8 +194,8 @@ bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W);
 // nhops hops in one launch: hop h reads Xin (h = 0) or Xtaps + (h - 1) * tapStride floats and writes Xtaps + h * tapStride floats
 int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, hipStream_t st);
 size_t gf_msweep_gate_bytes();
-constexpr int32_t kMsMinNodes = 32768;      // an image is built from here on (below, a batch entry's rows -- N x 128 bytes -- fit the 4 MiB L2 of an XCD)
-constexpr int32_t kMsDefaultMinNodes = 49152;   // the default hop uses it from here on (measured: SELL-8 wins at 33k / 40k, the sweep from 50k on)
+constexpr int32_t kMsMinNodes = 32768;      // GFHIP_EXPERIMENTS=1 processes build an image from here on (below, a batch entry's rows -- N x 128 bytes -- fit the 4 MiB L2 of an XCD)
+constexpr int32_t kMsDefaultMinNodes = 49152;   // the default hop uses it from here on, and every process builds the image from here on (measured: SELL-8 wins at 33k / 40k, the sweep from 50k on)
 int gf_contract_launch(const float* Z, const float* h, const float* bias, float* out, int B, int N, int Nout, int G,
                        int F, int E, int K, int transpose_bank, hipStream_t st, int out_rows = 0, const float* mask = nullptr);
 // column-panel pipeline (gf_panel.hip / gf_contract.hip / gf_gradw.hip)

@@ -423,8 +423,10 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
             }
         if ((rc = upload(colv, &d.sell_col, bytes))) return rc;
     }
-    // MSWEEP image (gf_msweep_image.h): graphs whose gather panel does not fit L2, when the groups balance (no hub rows)
-    if (n >= kMsMinNodes) {
+    // MSWEEP image (gf_msweep_image.h): graphs whose gather panel does not fit L2, when the groups balance (no hub rows).  A product
+    // process builds it only where the default hop uses it (kMsDefaultMinNodes); between kMsMinNodes and there the kernel can only be
+    // asked for through gf_tune (spmm_algo = 5), i.e. in GFHIP_EXPERIMENTS=1 processes -- only those pay for that image.
+    if (n >= (g_experiments ? kMsMinNodes : kMsDefaultMinNodes)) {
         MsweepImage ms = build_msweep_image(n, a.rowptr.data(), a.col.data(), a.val.data(), uni, g_tune.spmm_slack, g_tune.spmm_passes > 0 ? g_tune.spmm_passes : 1);
         d.ms_fill = ms.fill();
         if (ms.passes >= 1 && ms.passes <= 2 && ms.fill() >= 0.6) {

@@ -38,3 +38,45 @@ def test_fullsize_and_db_parity_in_the_product_configuration():
     assert m, tail
     assert int(m.group(1)) >= MIN_PASSED, tail
     assert "skipped" not in tail and "failed" not in tail and "error" not in tail, tail
+
+
+_PLAN_BYTES = r"""
+import ctypes, sys
+import numpy as np, scipy.sparse as sp, torch
+from alegnn_amd import _lib
+from alegnn_amd.gso import SparseGSO
+n = int(sys.argv[1])
+rng = np.random.RandomState(3)
+r = np.repeat(np.arange(n), 4); c = rng.randint(0, n, size=r.size)
+A = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(n, n)); A = ((A + A.T) > 0).astype(np.float64) * 0.125
+gso = SparseGSO([sp.csr_matrix(A)])
+plans = gso.plans(torch.device("cuda:0"))
+nn, nnz, nb = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+_lib.check(_lib.lib().gf_plan_info(plans[0], ctypes.byref(nn), ctypes.byref(nnz), ctypes.byref(nb)))
+print("PLAN", nn.value, nnz.value, nb.value, _lib.lib().gf_spmm_hop_kernel(plans[0], 0, 16, 32))
+"""
+
+
+def _plan_bytes(n, experiments):
+    env = dict(os.environ)
+    env["GFHIP_EXPERIMENTS"] = "1" if experiments else "0"
+    env.pop("GFHIP_LIB", None)
+    env["PYTHONPATH"] = os.path.join(ROOT, "graph-neural-networks_amd") + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", _PLAN_BYTES, str(n)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("PLAN ")][-1].split()
+    return int(line[3]), int(line[4])
+
+
+@pytest.mark.gpu
+def test_product_plans_carry_a_sweep_image_only_where_the_default_hop_uses_it():
+    """ADVICE r4 (images of kernels the product never launches): between kMsMinNodes (32 768) and kMsDefaultMinNodes (49 152) the MFMA
+    sweep can only be asked for through gf_tune, so only GFHIP_EXPERIMENTS=1 processes build its image there; from 49 152 nodes on the
+    default hop is the sweep and every process builds it."""
+    prod, k_prod = _plan_bytes(40000, experiments=False)
+    expt, k_expt = _plan_bytes(40000, experiments=True)
+    assert k_prod == 0 and k_expt == 0            # the default hop of this graph is SELL-8 in both
+    assert prod < expt - (1 << 20), (prod, expt)  # the experiments plan holds two images (forward + transposed) of > 1 MB each
+    prod, k_prod = _plan_bytes(60000, experiments=False)
+    expt, k_expt = _plan_bytes(60000, experiments=True)
+    assert k_prod == 1 and k_expt == 1 and prod == expt, (prod, expt, k_prod, k_expt)

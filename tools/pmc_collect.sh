@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 WL=${1:-cfg4}; KN=${2:-spmm_sell_kernel}; TAG=${3:-r03}
 O=gpurun_out/pmc_$WL; rm -rf $O; mkdir -p $O
 i=0
-for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do   # (the TCC block has 4 counter slots: FETCH_SIZE takes 3, WRITE_SIZE 2)
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc$i -o pmc -- python tools/hop_probe.py $WL 3 > $O/pmc$i.log 2>&1
 done
