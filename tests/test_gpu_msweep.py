@@ -133,8 +133,9 @@ def test_msweep_fused_khop_chain_is_bitwise_the_per_hop_launches(n, deg, B, K, w
 
 
 def test_msweep_chain_replays_from_a_hip_graph(knobs):
-    """The trainer's hipGraph mode captures whole steps: the fused chain (a memset node for its barrier counters + one cooperative launch)
-    must be capturable and replay to the same bits."""
+    """The trainer's hipGraph mode captures whole steps: the fused chain (ONE cooperative launch; its XCD barrier resets itself, so there
+    is no state to zero between replays -- a version with a memset node in front replayed wrong from the second replay on) must be
+    capturable and replay to the same bits."""
     n, B, K = 60000, 16, 4
     A = er(n, 4, seed=21)
     gso = SparseGSO([A])
