@@ -44,6 +44,9 @@ constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at 
 #ifndef GF_MS_STPLAIN   // output rows with plain stores (1, default) or non-temporal ones (0; make variant): plain stores leave the rows in the XCD's
 #define GF_MS_STPLAIN 1 // L2, and the rows stored LAST are the lowest bands -- the ones the next hop of the fused chain gathers first (1.24 -> 1.13 ms at config 4)
 #endif
+#ifndef GF_MS_EXP      // experiments (make msvariant; TIMING ONLY, results wrong): bit 0 = no MFMAs in the loop, bit 1 = plain moves instead of the DPP
+#define GF_MS_EXP 0    // broadcasts, bit 2 = global_load (saddr + 32-bit offset) instead of buffer_load offen (only with spmm_srcmask: gaps are not range-checked),
+#endif                 // bit 3 = two of the four MFMAs
 #define GF_MS_STR2(x) #x
 #define GF_MS_STR(x) GF_MS_STR2(x)
 #define GF_MS_MACROS R"(
@@ -52,6 +55,7 @@ constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at 
 .set MS_ACCV, 112
 .set MS_GATHER_NT, GF_MS_NT_VALUE
 .set MS_STORE_PLAIN, GF_MS_STPLAIN_VALUE
+.set MS_EXP, GF_MS_EXP_VALUE
 .set MS_R0, 24
 .macro MS_SETMAP D
   .set MS_A0, 24 + 4*(\D)
@@ -60,7 +64,8 @@ constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at 
   .set MS_V0, MS_E0 + 8              // value buffers (weighted GSOs)
 .endm
 .macro MS_MFMA s, q, k
-  .if ((\s)*16 + (\q)*4) < 256
+  .if (MS_EXP & 1) || ((MS_EXP & 8) && ((\q) & 1))
+  .elseif ((\s)*16 + (\q)*4) < 256
     v_mfma_f32_4x4x1_16b_f32 a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3], v[MS_A0+(\k)], v[MS_R0+4*(\k)+(\q)], a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3]
   .else
     v_mfma_f32_4x4x1_16b_f32 v[MS_ACCV+(\s)*16+(\q)*4-256:MS_ACCV+(\s)*16+(\q)*4-256+3], v[MS_A0+(\k)], v[MS_R0+4*(\k)+(\q)], v[MS_ACCV+(\s)*16+(\q)*4-256:MS_ACCV+(\s)*16+(\q)*4-256+3]
@@ -93,10 +98,15 @@ constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at 
 // position p for step 4 i + sp % 4.  MS_BCAST1 broadcasts lane (sp / 4) % 4 inside every quad, MS_BCAST2 copies the quad that holds it
 // over the position's other quad (rows of 16 lanes = two positions; banks = quads): two DPP moves, with >= 2 instructions between them.
 .macro MS_BCAST1 dst, src, sp
+  .if MS_EXP & 2
+  v_mov_b32 v[\dst], v[\src]
+  .else
   v_mov_b32_dpp v[\dst], v[\src] quad_perm:[((\sp)/4)%4,((\sp)/4)%4,((\sp)/4)%4,((\sp)/4)%4] row_mask:0xf bank_mask:0xf
+  .endif
 .endm
 .macro MS_BCAST2 dst, sp
-  .if ((\sp)/16) == 0
+  .if MS_EXP & 2
+  .elseif ((\sp)/16) == 0
     v_mov_b32_dpp v[\dst], v[\dst] row_shr:4 row_mask:0xf bank_mask:0xa
   .else
     v_mov_b32_dpp v[\dst], v[\dst] row_shl:4 row_mask:0xf bank_mask:0x5
@@ -104,10 +114,12 @@ constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at 
 .endm
 // gather of step sp into ring slot k and its A operand (the entry / value were broadcast into the temporaries of parity `par`), and --
 // behind the last step of a round -- the reload of that round's buffer with the round two later
-.macro MS_ISSUE sp, k, par, buf, rho, S, UNI, rs, re, rv, vfg, vslot, vevoff, smask, scur
+.macro MS_ISSUE sp, k, par, buf, rho, S, UNI, rs, re, rv, vfg, vslot, vevoff, smask, scur, xptr
   .set MS_TA, MS_T0 + 4*(\par)
   v_and_or_b32 v[MS_TA+2], v[MS_TA], \smask, \vfg
-  .if MS_GATHER_NT
+  .if MS_EXP & 4
+    global_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2], \xptr
+  .elseif MS_GATHER_NT
     buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2], \rs, 0 offen nt
   .else
     buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2], \rs, 0 offen
@@ -149,7 +161,7 @@ constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at 
     .if (\UNI) == 0
       MS_BCAST2 (MS_T0+4*(MS_N&1)+1), MS_N
     .endif
-    MS_ISSUE MS_N, MS_N, (MS_N & 1), 0, 0, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
+    MS_ISSUE MS_N, MS_N, (MS_N & 1), 0, 0, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur, \xptr
     .set MS_N, MS_N+1
   .endr
 MS_LOOP_\uid:
@@ -175,7 +187,7 @@ MS_LOOP_\uid:
       s_load_dword \sdummy, \xptr, \spfc offset:MS_N*0x4000
       s_load_dword \sdummy, \xptr, \spfc offset:MS_N*0x4000+0x40
     .endif
-    MS_ISSUE MS_SP, (MS_N % (\D)), (MS_N & 1), (MS_RHO & 1), MS_RHO, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur
+    MS_ISSUE MS_SP, (MS_N % (\D)), (MS_N & 1), (MS_RHO & 1), MS_RHO, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur, \xptr
     .set MS_N, MS_N+1
   .endr
   s_add_u32 \scur, \scur, 2048
@@ -260,7 +272,8 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                   "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
                   "inside the two rounds of an iteration (12-bit instruction offsets)");
     __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
-    asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN));
+    asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN)
+                 "\n\t.set GF_MS_EXP_VALUE, " GF_MS_STR(GF_MS_EXP));
     asm volatile(GF_MS_MACROS);
     const unsigned lane = threadIdx.x & 63;
     const int xcd = blockIdx.x & 7;
@@ -347,6 +360,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             if (trace && wid == 0 && lane == 0 && slot <= 64) {   // (experiments) phase stamps of the XCD's first wave: entry start, previous
                 unsigned long long* t = trace + ((size_t)xcd * 64 + (slot - 1)) * 8;   // stores drained + entries loaded, loop end, stores issued, barrier passed
                 t[0] = t0; t[1] = tl0; t[2] = tl1; t[3] = t1; t[4] = __builtin_amdgcn_s_memtime();
+                t[5] = __builtin_amdgcn_s_memrealtime();   // (100 MHz: the shader clock under this load = d t[4] / d t[5] x 100 MHz)
             }
         }
       }

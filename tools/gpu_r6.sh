@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-6 GPU sessions (one gpurun call each): bash tools/gpu_r6.sh <stage> ; logs under gpurun_out/r06_<stage>/ (lab notebook: stages are kept as run)
+cd "$(dirname "$0")/.."; export TMPDIR=/tmp GFHIP_EXPERIMENTS=1
+S=$1; O=gpurun_out/r06_$S; mkdir -p $O
+LIBD=$PWD/graph-neural-networks_amd/alegnn_amd
+case $S in
+a)  # where do the 12 ns per gather instruction go?  timing-only variants of the loop (no MFMAs / no DPP / global_load / half the MFMAs), each in
+    # four regimes: as shipped; no prefetch; real sources without stores; sources confined to 1 MB (every gather hits L2) without and with stores
+  R="v:spmm_algo=0+spmm_pfd=16+spmm_store=2+spmm_srcmask=0 v:spmm_pfd=0+spmm_store=2+spmm_srcmask=0 v:spmm_pfd=0+spmm_store=3+spmm_srcmask=0 v:spmm_pfd=0+spmm_store=3+spmm_srcmask=1048448 v:spmm_pfd=0+spmm_store=2+spmm_srcmask=1048448"
+  for lib in "" nomfma nodpp nomfmadpp halfmfma; do
+    if [ -n "$lib" ]; then export GFHIP_LIB=$LIBD/libgfhip_$lib.so; else unset GFHIP_LIB; fi
+    echo "== lib=${lib:-shipped}" | tee -a $O/decompose.log
+    timeout 300 python tools/hop_probe.py cfg4 5 $R 2>&1 | grep "khop chain" | sed 's/bitwise.*//' | tee -a $O/decompose.log
+  done
+  for lib in glob globnomfmadpp; do   # global_load has no range check: only with the sources confined
+    export GFHIP_LIB=$LIBD/libgfhip_$lib.so
+    echo "== lib=$lib" | tee -a $O/decompose.log
+    timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=0+spmm_pfd=0+spmm_store=3+spmm_srcmask=1048448 v:spmm_pfd=0+spmm_store=2+spmm_srcmask=1048448 2>&1 | grep "khop chain" | sed 's/bitwise.*//' | tee -a $O/decompose.log
+  done
+  unset GFHIP_LIB
+  timeout 300 python tools/msweep_trace.py 2>&1 | tail -12 | tee $O/trace_default.log
+  ;;
+esac

@@ -25,6 +25,10 @@ torch.cuda.synchronize()
 buf = np.zeros((8, 64, 8), dtype=np.uint64)
 L.gf_debug_msweep_trace.restype = ctypes.c_int
 assert L.gf_debug_msweep_trace(ctypes.c_void_p(buf.ctypes.data)) == 0
+raw = buf.astype(np.float64)
+n0 = int((raw[0, :, 0] > 0).sum())
+if n0 > 1 and raw[0, n0 - 1, 5] > raw[0, 0, 5]:   # s_memrealtime runs at 100 MHz: the s_memtime tick rate under this load
+    print(f"s_memtime ticks per microsecond (XCD 0, {n0} slots): {(raw[0, n0 - 1, 4] - raw[0, 0, 4]) / (raw[0, n0 - 1, 5] - raw[0, 0, 5]) * 100.0:.1f}")
 t = buf.astype(np.float64) / 2200.0         # s_memtime ticks = shader clocks (~2.2 GHz under this load) -> microseconds
 ok = t[:, :, 0] > 0
 names = ["start->loop (zero, drain, entry loads)", "round loop", "store issue", "barrier"]
