@@ -1,8 +1,14 @@
 // gf_msweep.hip -- spmm_msweep_kernel: the node-major hop (graphML.py:158-161, one `x = torch.matmul(x, S)`) as a SOURCE SWEEP whose
 // scatter-accumulate is an fp32 multi-block MFMA (image, geometry and rationale: gf_msweep_image.h).
 //
-// One workgroup of four waves per CU (one 512-register wave per SIMD), 256 workgroups; workgroup L runs on XCD L % 8 (observed
-// dispatch order: a wrong guess costs speed, never correctness).  XCD x works through batch entries x, x + 8, ...: its 128 waves hold
+// One workgroup of four waves per CU (one 512-register wave per SIMD), 256 workgroups.  A fused chain takes its TEAMS from the hardware,
+// not from the dispatch order: every workgroup reads the XCC it runs on (s_getreg HW_REG_XCC_ID), draws its rank among that XCC's
+// workgroups from a census (agent-scope atomics, once per launch) and, when the census shows 32 workgroups on each of 8 XCCs, works as
+// wave rank * 4 + w of team XCC -- the hand-over between the hops of an entry then runs through ONE physical L2 by construction.  Any
+// other census (or a grid that does not become resident within the time limit) ends the launch without a store, and the repair
+// kernel queued behind it (spmm_msweep_repair_kernel, gated on the launch's flag) computes the chain row by row: slower, same bits,
+// no trap, no host synchronisation.  A single hop (no hand-over) keeps workgroup L on team L % 8: there a wrong guess costs speed only.
+// XCD x works through batch entries x, x + 8, ...: its 128 waves hold
 // the entry's whole output (S sets x 32 rows x 32 features per wave) in accumulator registers, walk the entry's source rows together
 // (T rounds of S steps; a step = one 8-row gather + four v_mfma_f32_4x4x1_16b_f32) and store; the K - 1 hops of an entry run back to
 // back in one launch with an XCD barrier between them (hop h + 1 gathers what hop h stored -- with plain stores, so that the rows
@@ -27,6 +33,7 @@
 // have two MFMAs between them (VALU write -> DPP read: 2), accumulators are read only after the loop (s_nop block in MS_BODY).
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 
 #include "gf_common.h"
 #include "gf_msweep_image.h"
@@ -35,7 +42,17 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMsGateWords = 64;      // per XCD: the arrival counter (word 0) and the generation word (word 16) of its barrier, 256 bytes of their own
-constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at once on different streams (slots rotate; zeroed once, at plan creation)
+constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at once: one slot per stream (zeroed once, at plan creation)
+// behind the 8 team lines of a slot: the census block of its launches (agent-scope atomics only)
+constexpr int kMsCensusWord = 8 * kMsGateWords;
+constexpr int kMsSlotWords = kMsCensusWord + 64;
+enum : int { kCsCount = 0 /* [8] workgroups per XCC */, kCsArrive = 8, kCsGen = 9 /* += 2 per launch; bit 0 = this launch is abandoned */,
+             kCsRepair = 10 /* read by the repair kernel behind the launch */, kCsPoison = 11 /* sticky: a launch on this slot timed out */ };
+enum : unsigned { kMsStatusCensus = 1u /* a census did not show 8 x 32 */, kMsStatusTimeout = 2u /* a grid did not become resident / a barrier did not open */ };
+
+__device__ __forceinline__ unsigned ag_load(unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ag_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Assembler macros (a basic asm statement: no operand substitution, `%` and `|` are the assembler's).  Defined once per module.
 #ifndef GF_MS_NT   // experiments (make variant): gathers with the non-temporal hint
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restrict__ val, const uint32_t* __restrict__ rows,
                         const float* __restrict__ Xin, float* __restrict__ Xtaps, size_t tapStrideBytes, int nhops, int N, int B, int passes,
                         int rounds, unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask, int pf_lead, int stagger,
-                        int nostore, unsigned long long* __restrict__ trace) {
+                        int nostore, unsigned long long* __restrict__ trace, int census, unsigned tmo_ticks) {
     constexpr unsigned kRoundBytes = 1024u;                 // a round of the entry stream: 8 positions x 8 quads x 16 bytes
     constexpr int U = 2;                                    // rounds per loop iteration (the two entry buffers alternate by round parity)
     static_assert((U * S) % D == 0 && D < S && S <= kMsMaxSets && S <= 32,
@@ -272,13 +289,69 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                   "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
                   "inside the two rounds of an iteration (12-bit instruction offsets)");
     __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
+    __shared__ unsigned s_ctl[4];                           // census result {XCC, rank, abandoned}, [3] = a barrier timed out
     asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN)
                  "\n\t.set GF_MS_EXP_VALUE, " GF_MS_STR(GF_MS_EXP));
     asm volatile(GF_MS_MACROS);
     const unsigned lane = threadIdx.x & 63;
-    const int xcd = blockIdx.x & 7;
     const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned wid = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) * (kThreads / 64) + wv));   // wave of this XCD
+    unsigned* cs = gate + kMsCensusWord;
+    int xcd = blockIdx.x & 7;
+    unsigned rank = blockIdx.x >> 3;
+    if (census) {
+        // Census (launches with a hand-over between workgroups: cooperative, so the grid is resident or the launch waits).  Tickets and the
+        // arrival count are agent-scope atomics: coherent whatever XCD a workgroup runs on.  The last of the 256 arrivers reads the eight
+        // counts, takes every word back to zero (a captured launch replays as is) and publishes the verdict in the generation word; the
+        // others poll the generation they read BEFORE arriving.  census = 2 / 3 / 4 (experiments): the last arriver calls the census bad /
+        // workgroup 5 claims the next XCC / workgroup 7 never arrives (the others run into the time limit).
+        if (threadIdx.x == 0) {
+            unsigned xcc, bad = 0u, rk = 0u;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            if (census == 3 && blockIdx.x == 5) xcc = (xcc + 1u) & 7u;
+            if (ag_load(cs + kCsPoison) || (census == 4 && blockIdx.x == 7)) {
+                ag_store(cs + kCsRepair, 1u);
+                bad = 1u;
+            } else {
+                const unsigned g0 = ag_load(cs + kCsGen);
+                rk = ag_add(cs + kCsCount + xcc, 1u);
+                if (ag_add(cs + kCsArrive, 1u) == 255u) {
+                    bad = census == 2 ? 1u : 0u;
+                    for (int i = 0; i < 8; ++i) {
+                        bad |= ag_load(cs + kCsCount + i) != 32u ? 1u : 0u;
+                        ag_store(cs + kCsCount + i, 0u);
+                    }
+                    ag_store(cs + kCsArrive, 0u);
+                    bad |= ag_load(cs + kCsPoison) ? 1u : 0u;
+                    ag_store(cs + kCsRepair, bad);
+                    ag_store(cs + kCsGen, ((g0 & ~1u) + 2u) | bad);
+                } else {
+                    const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
+                    unsigned g = g0;
+                    while ((g >> 1) == (g0 >> 1)) {
+                        __builtin_amdgcn_s_sleep(8);
+                        g = ag_load(cs + kCsGen);
+                        if ((g >> 1) == (g0 >> 1) && __builtin_amdgcn_s_memrealtime() - tb > (unsigned long long)tmo_ticks) {
+                            ag_store(cs + kCsPoison, 1u);   // the slot's words are no longer trustworthy: every later launch on it goes to the repair kernel
+                            ag_store(cs + kCsRepair, 1u);
+                            g = g0 | 1u;
+                            break;
+                        }
+                    }
+                    bad = g & 1u;
+                }
+            }
+            s_ctl[0] = xcc;
+            s_ctl[1] = rk;
+            s_ctl[2] = bad;
+            s_ctl[3] = 0u;
+        }
+        __syncthreads();
+        if (s_ctl[2]) return;                               // abandoned before the first store: the repair kernel behind this launch does the work
+        xcd = __builtin_amdgcn_readfirstlane((int)s_ctl[0]);
+        rank = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ctl[1]);
+    }
+    const unsigned wid = (unsigned)__builtin_amdgcn_readfirstlane((int)(rank * (kThreads / 64) + wv));   // wave of this XCD's team
     const unsigned pos = lane >> 3, fg16 = (lane & 7u) * 16u, slotbit = lane & 3u;
     const unsigned tapBytes = (unsigned)N * 128u;
     const size_t streamWords = (size_t)(rounds + 2) * 256;
@@ -332,9 +405,10 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                 // XCD add 1 to the XCD's arrival counter; the 32nd takes the counter back to 0 and advances the generation word, the others
                 // poll the generation they read BEFORE arriving (it cannot move until all 32, they included, have arrived).  Scalar atomics:
                 // they execute in the XCD's L2 and wait on lgkmcnt, not on the stores' vmcnt.  Between the hops of an entry the barrier
-                // orders this hop's stores (acknowledged by the L2: vmcnt(0)) before the next hop's gathers from the other CUs.  The launch
-                // is cooperative, so all 256 workgroups are resident; a barrier that still does not open within ~2 s (a wrong guess about the
-                // workgroup -> XCD placement) ends the kernel with a trap: a launch failure, never a wrong result.
+                // orders this hop's stores (acknowledged by the L2: vmcnt(0)) before the next hop's gathers from the other CUs of the team --
+                // the team IS the set of workgroups on one XCC (census above), so counters and rows live in the one L2 they all use.  The
+                // census has seen all 256 workgroups resident; a barrier that still does not open within the time limit (a team mate died)
+                // abandons the launch the same way a bad census does.
                 if (dependent) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (wv == 0) {
@@ -346,16 +420,22 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                         asm volatile("s_atomic_sub %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(m32) : "s"(ctr) : "memory");
                         asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(one) : "s"(ctr + 16) : "memory");
                     } else {
-                        int spin = 0;
-                        for (g = g0; g == g0 && spin < 4000000; ++spin) {
-                            __builtin_amdgcn_s_sleep(16);
+                        const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
+                        for (g = g0; g == g0;) {
+                            __builtin_amdgcn_s_sleep(2);
                             g = 0u;
                             asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(g) : "s"(ctr + 16) : "memory");
+                            if (g == g0 && __builtin_amdgcn_s_memrealtime() - tb > (unsigned long long)tmo_ticks) break;
                         }
-                        if (g == g0) __builtin_trap();
+                        if (g == g0 && lane == 0) {         // a team mate is gone: abandon the launch (the repair kernel redoes the whole chain)
+                            ag_store(cs + kCsPoison, 1u);
+                            ag_store(cs + kCsRepair, 1u);
+                            s_ctl[3] = 1u;
+                        }
                     }
                 }
-                __builtin_amdgcn_s_barrier();
+                __syncthreads();
+                if (s_ctl[3]) return;
             }
             if (trace && wid == 0 && lane == 0 && slot <= 64) {   // (experiments) phase stamps of the XCD's first wave: entry start, previous
                 unsigned long long* t = trace + ((size_t)xcd * 64 + (slot - 1)) * 8;   // stores drained + entries loaded, loop end, stores issued, barrier passed
@@ -366,19 +446,120 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
       }
 }
 
+// The chain, row by row, for launches the sweep abandoned (bad census, time limit): gated on the launch's flag -- when the sweep ran, every
+// workgroup leaves at once (~2 us per chain).  Workgroup = one batch entry at a time, through all its hops (a hop of an entry needs only
+// that entry's previous tap: the hand-over stays inside the workgroup -- __syncthreads + an agent-scope fence -- and needs no co-residency).
+// Per row: the stored CSR's entries in ascending column order, one fmaf per entry (uniform GSOs: sum, then scale once) = the sums of
+// spmm_msweep_kernel and spmm_sell_kernel, bit for bit.
+__global__ __launch_bounds__(512) void spmm_msweep_repair_kernel(unsigned* __restrict__ cs, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                 const float* __restrict__ val, const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
+                                                                 float* __restrict__ Xtaps, size_t tapStride, int nhops, int N, int B, int uniform, float uval,
+                                                                 unsigned* __restrict__ status) {
+    if (ag_load(cs + kCsRepair) == 0u) return;
+    const int li = threadIdx.x & 7, grp = threadIdx.x >> 3, ngrp = blockDim.x >> 3;
+    for (int b = blockIdx.x; b < B; b += gridDim.x)
+        for (int hop = 0; hop < nhops; ++hop) {
+            const float* src = (hop == 0 ? Xin : Xtaps + (size_t)(hop - 1) * tapStride) + (size_t)b * N * 32;
+            float* dst = Xtaps + (size_t)hop * tapStride + (size_t)b * N * 32;
+            for (int p = grp; p < N; p += ngrp) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = rowptr[p]; q < rowptr[p + 1]; ++q) {
+                    const float4 x = *reinterpret_cast<const float4*>(src + (size_t)col[q] * 32 + li * 4);
+                    const float v = uniform ? 1.f : val[q];
+                    acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
+                }
+                if (uniform) { acc.x *= uval; acc.y *= uval; acc.z *= uval; acc.w *= uval; }
+                *reinterpret_cast<float4*>(dst + (size_t)rowid[p] * 32 + li * 4) = acc;
+            }
+            __syncthreads();
+            __threadfence();
+            __syncthreads();
+        }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && status)   // host-visible (pinned) word: the library reads it at its next call and stops fusing
+        __hip_atomic_fetch_or(status, ag_load(cs + kCsPoison) ? kMsStatusTimeout : kMsStatusCensus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 unsigned long long* g_trace = nullptr;
 constexpr size_t kTraceBytes = 8 * 64 * 8 * sizeof(unsigned long long);
 
-int cu_count() {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n;
-    }();
-    return cus;
+int cu_count() {   // of the CURRENT device (a process may drive several)
+    static std::mutex mu;
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cus[dev] = n > 0 ? n : -1;
+    }
+    return cus[dev];
 }
 
+// One gate slot per stream: two launches of one stream never overlap, and launches on different streams never share barrier words (the
+// first 15 streams a process uses get a slot of their own, the rest share the last one).
+int slot_of(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t seen[kMsGateSlots];
+    static int nseen = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i] == st) return i;
+    if (nseen < kMsGateSlots - 1) {
+        seen[nseen] = st;
+        return nseen++;
+    }
+    return kMsGateSlots - 1;
+}
+
+// Host-visible status of the fused chains of this process: a pinned word the repair kernel ORs its reason into.  Allocated at plan
+// creation (gf_msweep_status_word), never during a launch (a launch may be under stream capture).
+std::atomic<unsigned*> g_status{nullptr};
+std::atomic<int> g_fuse_off{0};   // 1 = a repair was seen (or GFHIP_MSWEEP_FUSE=0): gf_khop runs one launch per hop from here on
+
 }  // namespace
+
+unsigned* gf_msweep_status_word() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    unsigned* w = g_status.load();
+    if (!w) {
+        if (hipHostMalloc((void**)&w, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        *w = 0u;
+        g_status.store(w);
+    }
+    return w;
+}
+
+// 1 while gf_khop may fuse the K - 1 hops into one launch.  Off: GFHIP_MSWEEP_FUSE=0 in the environment, or -- from the first call after
+// the fact -- a launch of this process had to be repaired (reported once on stderr; gf_msweep_status tells which).
+bool gf_msweep_fusion_allowed() {
+    static const int env_off = [] { const char* e = getenv("GFHIP_MSWEEP_FUSE"); return e && atoi(e) == 0 ? 1 : 0; }();
+    if (env_off || g_fuse_off.load()) return false;
+    const unsigned* w = g_status.load();
+    const unsigned st = w ? *reinterpret_cast<const volatile unsigned*>(w) : 0u;
+    if (st) {
+        if (!g_fuse_off.exchange(1))
+            fprintf(stderr, "gfhip: a fused K-hop chain was abandoned (%s%s) and recomputed by the repair kernel; results are unaffected, "
+                            "the chain runs one launch per hop from here on\n",
+                    (st & kMsStatusCensus) ? "workgroups not spread 32 per XCD" : "", (st & kMsStatusTimeout) ? " grid not resident within the time limit" : "");
+        return false;
+    }
+    return true;
+}
+
+extern "C" int gf_msweep_status(uint32_t* flags, int32_t* fusion_on) {
+    const unsigned* w = g_status.load();
+    if (flags) *flags = w ? *reinterpret_cast<const volatile unsigned*>(w) : 0u;
+    if (fusion_on) *fusion_on = gf_msweep_fusion_allowed() ? 1 : 0;
+    return GF_OK;
+}
+
+void gf_msweep_status_reset() {   // experiments (gf_tune("spmm_status_reset", 1)): tests of the repair path start from a clean process state
+    unsigned* w = g_status.load();
+    if (w) *reinterpret_cast<volatile unsigned*>(w) = 0u;
+    g_fuse_off.store(0);
+}
 
 bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W) {
     // 128-byte rows, an image, one workgroup per CU on a 256-CU device (8 XCDs x 32 CUs x 4 SIMDs = the 128 waves per XCD of the
@@ -388,8 +569,7 @@ bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W) {
 }
 
 int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, hipStream_t st) {
-    static std::atomic<unsigned> next_slot{0};
-    unsigned* gate = m.ms_gate + (size_t)(next_slot.fetch_add(1) % kMsGateSlots) * 8 * kMsGateWords;
+    unsigned* gate = m.ms_gate + (size_t)slot_of(st) * kMsSlotWords;
     const int use_barrier = g_tune.spmm_bar;
     dim3 grid(256), block(kThreads);
     const unsigned src_mask = g_tune.spmm_srcmask ? (unsigned)g_tune.spmm_srcmask : 0xffffffffu;   // experiments (timing only): confine the gathers to a window
@@ -402,26 +582,28 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     const bool pf = g_tune.spmm_pfd > 0;
     const bool deep = g_tune.spmm_depth != 5;   // ring of 10 gathers; 5: experiments
     // A fused chain depends on its XCD barriers (hop h + 1 gathers what hop h stored): it is launched COOPERATIVELY -- the runtime starts the
-    // grid only when all 256 workgroups can be resident together (another stream's kernel on some CUs delays the launch instead of leaving
-    // workgroups spinning at a barrier that cannot open).  A single hop has no such dependence and takes the plain launch.
+    // grid only when all 256 workgroups can be resident together -- and opens with the census (kernel); the repair kernel behind it runs
+    // only if the sweep abandoned the launch.  A single hop has no such dependence and takes the plain launch.
+    const bool chained = nhops > 1 || use_barrier;
     const uint32_t* a_ent = m.ms_ent;
     const float* a_val = m.ms_val;
     const uint32_t* a_rows = m.ms_rows;
     size_t a_stride = (size_t)tapStride * 4;
     int a_nhops = nhops, a_N = N, a_B = B, a_passes = m.ms_passes, a_rounds = m.ms_rounds, a_bar = use_barrier, a_pfd = g_tune.spmm_pfd,
-        a_stag = g_tune.spmm_stag, a_nostore = g_tune.spmm_store == 3;
+        a_stag = g_tune.spmm_stag, a_nostore = g_tune.spmm_store == 3, a_census = chained ? 1 + (g_tune.spmm_census > 0 ? g_tune.spmm_census : 0) : 0;
     float a_uval = m.sell_uval;
     unsigned a_mask = src_mask;
+    unsigned a_tmo = (unsigned)(g_tune.spmm_tmo_ms > 0 ? g_tune.spmm_tmo_ms : 2000) * 100000u;   // s_memrealtime ticks (100 MHz)
     void* args[] = {&a_ent, &a_val, &a_rows, &Xin, &Xtaps, &a_stride, &a_nhops, &a_N, &a_B, &a_passes, &a_rounds, &gate, &a_bar, &a_uval, &a_mask,
-                    &a_pfd, &a_stag, &a_nostore, &trace};
+                    &a_pfd, &a_stag, &a_nostore, &trace, &a_census, &a_tmo};
     hipError_t lerr = hipSuccess;
 #define GF_MS(SV, UV, PV, DV)                                                                                                          \
     do {                                                                                                                               \
-        if (nhops > 1 || use_barrier)                                                                                                  \
+        if (chained)                                                                                                                   \
             lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV>, grid, block, args, 0, st);              \
         else                                                                                                                           \
             hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV>), grid, block, 0, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
-                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_stag, a_nostore, trace);                      \
+                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_stag, a_nostore, trace, a_census, a_tmo);     \
     } while (0)
 #define GF_MS_P(SV, UV, DV)                            \
     do {                                              \
@@ -453,6 +635,11 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
 #undef GF_MS
     GF_HIP(lerr);
     GF_LAUNCH_CHECK("spmm_msweep_kernel");
+    if (chained && !a_nostore && src_mask == 0xffffffffu) {
+        hipLaunchKernelGGL(spmm_msweep_repair_kernel, dim3((unsigned)(B < 512 ? B : 512)), dim3(512), 0, st, gate + kMsCensusWord, m.rowptr, m.col, m.val, m.rowid,
+                           Xin, Xtaps, (size_t)tapStride, nhops, N, B, m.ms_uniform, m.sell_uval, g_status.load());
+        GF_LAUNCH_CHECK("spmm_msweep_repair_kernel");
+    }
     return GF_OK;
 }
 
@@ -463,4 +650,4 @@ extern "C" int gf_debug_msweep_trace(unsigned long long* out) {   // [8][64][8];
     return GF_OK;
 }
 
-size_t gf_msweep_gate_bytes() { return (size_t)kMsGateSlots * 8 * kMsGateWords * sizeof(unsigned); }
+size_t gf_msweep_gate_bytes() { return (size_t)kMsGateSlots * kMsSlotWords * sizeof(unsigned); }

@@ -36,7 +36,7 @@
 #include <queue>
 #include <vector>
 
-constexpr int32_t kMsDepth = 5;                      // gather steps in flight per wave (ring of kMsDepth x 4 registers)
+constexpr int32_t kMsDepth = 5;                      // granule of the geometry: sets per wave are a multiple of it (the kernel keeps 5 or 10 gathers in flight per wave)
 constexpr int32_t kMsWavesPerXcd = 128;              // 32 CUs x 4 SIMDs x one 512-register wave
 constexpr int32_t kMsMaxSets = 25;                   // accumulator sets per wave: 25 x 16 = 400 registers
 constexpr uint32_t kMsPad = 0xffffff80u;             // entry of a gap / row offset of a slot without a row

@@ -68,6 +68,9 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_depth")) g_tune.spmm_depth = value;
     else if (!strcmp(key, "spmm_fuse")) g_tune.spmm_fuse = value;
     else if (!strcmp(key, "spmm_trace")) g_tune.spmm_trace = value;
+    else if (!strcmp(key, "spmm_census")) g_tune.spmm_census = value;
+    else if (!strcmp(key, "spmm_tmo_ms")) g_tune.spmm_tmo_ms = value;
+    else if (!strcmp(key, "spmm_status_reset")) gf_msweep_status_reset();
     else if (!strcmp(key, "spmm_passes")) g_tune.spmm_passes = value;
     else if (!strcmp(key, "spmm_stag")) g_tune.spmm_stag = value;
     else if (!strcmp(key, "spmm_srcmask")) g_tune.spmm_srcmask = value;
@@ -439,6 +442,7 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
             if ((rc = upload(ms.rows, &d.ms_rows, bytes))) return rc;
             GF_HIP(hipMalloc((void**)&d.ms_gate, gf_msweep_gate_bytes()));
             GF_HIP(hipMemset(d.ms_gate, 0, gf_msweep_gate_bytes()));
+            (void)gf_msweep_status_word();   // (pinned word for the repair kernel's report: allocated here, never under a launch)
             bytes += (int64_t)gf_msweep_gate_bytes();
         }
     }

@@ -565,6 +565,7 @@ extern "C" int gf_spmm_hop_kernel(const gf_plan* plan, int32_t op, int32_t B, in
 extern "C" int gf_khop(const gf_plan* const* plans, int32_t E, int32_t op, float* Z, int32_t B, int32_t W, int32_t K,
                        void* stream) {
     GF_REQUIRE_ARG(plans && Z, "gf_khop: NULL argument");
+    GF_REQUIRE_ARG(op == GF_OP_FWD || op == GF_OP_BWD, "gf_khop: op = %d", op);
     GF_REQUIRE_SHAPE(E > 0 && K > 0 && B > 0 && W > 0, "gf_khop: bad shape E=%d K=%d B=%d W=%d", E, K, B, W);
     for (int e = 0; e < E; ++e) {
         GF_REQUIRE_ARG(plans[e] != nullptr, "gf_khop: plan %d is NULL", e);
@@ -575,7 +576,7 @@ extern "C" int gf_khop(const gf_plan* const* plans, int32_t E, int32_t op, float
     for (int e = 0; e < E; ++e) {
         // the MFMA sweep runs the K - 1 hops of an edge feature in ONE launch, batch entry by batch entry (gf_msweep.hip)
         const gf_csr_dev& m = plans[e]->mat[op];
-        if (K > 2 && g_tune.spmm_fuse && gf_hop_uses_msweep(plans[e], op, B, W)) {
+        if (K > 2 && g_tune.spmm_fuse && gf_hop_uses_msweep(plans[e], op, B, W) && gf_msweep_fusion_allowed()) {
             const int rc = gf_msweep_launch(m, Z, Z + (int64_t)(1 + e * (K - 1)) * tap, tap, K - 1, plans[e]->n, B, gf_stream(stream));
             if (rc != GF_OK) return rc;
             continue;

@@ -27,7 +27,7 @@ def tune(**kw):
 @pytest.fixture
 def knobs():
     yield tune
-    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=16)
+    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=16, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1)
 
 
 def hop(plans, op, Xt, algo, **kw):
@@ -181,3 +181,87 @@ def test_msweep_is_refused_where_it_does_not_apply(knobs):
     rcs.append(int(L.gf_spmm_hop(small[0], 0, X.data_ptr(), Y.data_ptr(), 8, 32, stream())))
     torch.cuda.synchronize()
     assert all(rc != 0 for rc in rcs), rcs
+
+
+def chain_status():
+    import ctypes
+    f, on = ctypes.c_uint32(0), ctypes.c_int32(0)
+    _lib.check(_lib.lib().gf_msweep_status(ctypes.byref(f), ctypes.byref(on)))
+    return int(f.value), int(on.value)
+
+
+def khop_chain(plans, x0, K, op=0, **kw):
+    tune(**kw)
+    B, n, W = x0.shape
+    Z = torch.full((K, B, n, W), float("nan"), device=DEV)
+    Z[0].copy_(x0)
+    _lib.check(_lib.lib().gf_khop(plans, 1, op, Z.data_ptr(), B, W, K, stream()))
+    torch.cuda.synchronize()
+    return Z
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_fused_chain_with_a_bad_census_is_repaired_not_trapped(mode, weighted, knobs):
+    """The fused chain takes its teams from the hardware (XCC id + a census of the launch's workgroups).  A census that does not show 32
+    workgroups on each of 8 XCCs -- forced here: the last arriver calls it bad (1), or one workgroup claims the neighbouring XCC so that
+    the counts come out 33 / 31 (2) -- must abandon the launch before its first store and leave the work to the repair kernel behind it:
+    no trap, the same bits as SELL-8, the reason reported through gf_msweep_status, and the host stops fusing once it has seen it."""
+    n, B, K = 60000, 16, 4
+    A = er(n, 4, seed=31 + mode, weighted=weighted)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    x0 = torch.randn(B, n, 32, device=DEV)
+    for op in (0, 1):
+        ref = khop_chain(plans, x0, K, op, spmm_algo=3)
+        tune(spmm_status_reset=1)
+        assert chain_status() == (0, 1)
+        ok = khop_chain(plans, x0, K, op, spmm_algo=0, spmm_fuse=1, spmm_census=0)
+        assert torch.equal(ok, ref) and chain_status() == (0, 1)
+        got = khop_chain(plans, x0, K, op, spmm_algo=0, spmm_fuse=1, spmm_census=mode)
+        assert torch.equal(got, ref), (op, mode, int((got != ref).sum()))
+        assert chain_status() == (1, 0)                     # census failure seen; fusion now off in this process
+        again = khop_chain(plans, x0, K, op, spmm_census=0)   # ... so this call runs one launch per hop (still the sweep kernel)
+        assert torch.equal(again, ref)
+        tune(spmm_status_reset=1)
+        back = khop_chain(plans, x0, K, op, spmm_census=0)    # and after the reset the same slot fuses again (the census words reset themselves)
+        assert torch.equal(back, ref) and chain_status() == (0, 1)
+
+
+def test_fused_chain_that_never_becomes_resident_runs_into_its_time_limit_and_is_repaired(knobs):
+    """One workgroup of the cooperative grid never arrives at the census (forced): the others give up after the time limit (30 ms here,
+    2 s in the product), poison the launch slot and leave; the repair kernel computes the chain.  Later launches on the poisoned slot are
+    abandoned at once (and repaired) until the host has seen the report and stopped fusing."""
+    n, B, K = 52000, 9, 3
+    A = er(n, 5, seed=77)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    x0 = torch.randn(B, n, 32, device=DEV)
+    ref = khop_chain(plans, x0, K, spmm_algo=3)
+    tune(spmm_status_reset=1)
+    got = khop_chain(plans, x0, K, spmm_algo=0, spmm_fuse=1, spmm_census=3, spmm_tmo_ms=30)
+    assert torch.equal(got, ref), int((got != ref).sum())
+    assert chain_status() == (2, 0)
+    tune(spmm_status_reset=1)                               # the host forgets, the slot does not: still repaired, still the same bits
+    got = khop_chain(plans, x0, K, spmm_census=0, spmm_tmo_ms=0)
+    assert torch.equal(got, ref) and chain_status()[0] == 2
+
+
+def test_fused_chain_beside_kernels_that_hold_compute_units(knobs):
+    """The cooperative launch needs every CU; here other streams hold a few of them for ~20 ms each while the chain is launched.  The grid
+    then becomes resident late (well inside the time limit): same bits, nothing to repair."""
+    n, B, K = 60000, 16, 4
+    A = er(n, 4, seed=5)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    x0 = torch.randn(B, n, 32, device=DEV)
+    ref = khop_chain(plans, x0, K, spmm_algo=3)
+    tune(spmm_algo=0, spmm_fuse=1, spmm_status_reset=1)
+    side = [torch.cuda.Stream(device=DEV) for _ in range(8)]
+    for rep in range(3):
+        for s_ in side:
+            with torch.cuda.stream(s_):
+                torch.cuda._sleep(40_000_000)               # one spinning wave per stream
+        got = khop_chain(plans, x0, K)
+        assert torch.equal(got, ref), (rep, int((got != ref).sum()))
+    assert chain_status() == (0, 1)

@@ -795,3 +795,29 @@ def test_asm_stores_never_read_mfma_results():
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_contract_isa.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_msweep_isa_register_contract():
+    """spmm_msweep_kernel allocates its registers by hand (v24-v255, a0-a255 belong to the asm body and keep state between the passes of a
+    launch): no instantiation may spill or use scratch, every one gets the whole register file, and no compiler-emitted instruction
+    may name a register of the body (tools/check_msweep_isa.py compiles the file to ISA and scans it)."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_msweep_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 violations" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_fused_chain_can_be_switched_off_in_the_environment():
+    """GFHIP_MSWEEP_FUSE=0 is the product-mode opt-out of the one-launch chain (gf_khop then runs one launch per hop): gf_msweep_status reports
+    fusion_on = 0 in such a process and 1 otherwise; no knob (gf_tune) is involved."""
+    import subprocess
+    code = ("import sys; sys.path[:0] = [%r, %r]; import ctypes; from alegnn_amd import _lib; L = _lib.lib(); "
+            "f = ctypes.c_uint32(7); on = ctypes.c_int32(7); assert L.gf_msweep_status(ctypes.byref(f), ctypes.byref(on)) == 0; print(f.value, on.value)"
+            % (ROOT, os.path.join(ROOT, "graph-neural-networks_amd")))
+    for env_val, want in (("0", "0 0"), ("1", "0 1"), (None, "0 1")):
+        env = {k: v for k, v in os.environ.items() if k not in ("GFHIP_MSWEEP_FUSE", "GFHIP_EXPERIMENTS")}
+        if env_val is not None:
+            env["GFHIP_MSWEEP_FUSE"] = env_val
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and r.stdout.strip() == want, (env_val, r.stdout, r.stderr[-2000:])
