@@ -475,8 +475,10 @@ __global__ __launch_bounds__(512) void spmm_msweep_repair_kernel(unsigned* __res
             __threadfence();
             __syncthreads();
         }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && status)   // host-visible (pinned) word: the library reads it at its next call and stops fusing
-        __hip_atomic_fetch_or(status, ag_load(cs + kCsPoison) ? kMsStatusTimeout : kMsStatusCensus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && status) {   // host-visible (pinned) word: the library reads it at its next call and stops fusing
+        const unsigned old = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (plain load + store: no PCIe atomics needed; one writer per launch)
+        __hip_atomic_store(status, old | (ag_load(cs + kCsPoison) ? kMsStatusTimeout : kMsStatusCensus), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 unsigned long long* g_trace = nullptr;

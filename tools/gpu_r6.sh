@@ -20,4 +20,9 @@ a)  # where do the 12 ns per gather instruction go?  timing-only variants of the
   unset GFHIP_LIB
   timeout 300 python tools/msweep_trace.py 2>&1 | tail -12 | tee $O/trace_default.log
   ;;
+b)  # the census / repair protocol: tests, and what the census costs on the default chain; ring depth 5 vs 10 on the shipped loop
+  timeout 1200 python -m pytest tests/test_gpu_msweep.py -x -q 2>&1 | tail -15 | tee $O/pytest_msweep.log
+  timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0+spmm_depth=0 v:spmm_depth=5 v:spmm_depth=0 v:spmm_depth=5 v:spmm_depth=0+spmm_fuse=0 v:spmm_fuse=1 2>&1 | grep "khop chain" | tee $O/khop.log
+  timeout 300 python tools/msweep_trace.py 2>&1 | tail -12 | tee $O/trace_default.log
+  ;;
 esac
