@@ -151,6 +151,7 @@ struct gf_tuning {
     int spmm_pfd = 16;          // MFMA sweep: scalar prefetch of the source rows this many loop iterations ahead (0 = off; measured best: 12-16 of the 21
                                 // iterations of config 4 -- the prefetch then runs during the first 40 % of an entry, while the previous stores drain)
     int spmm_passes = 2;        // MFMA sweep image: passes (sweeps of the sources) allowed per batch entry -- 1: N <= 102 400, 2: up to 204 800 (set BEFORE gf_plan_create)
+    int spmm_ring = 0;          // MFMA sweep: 1 = the gathers in flight land in LDS (LDS-DMA; a whole round = S gathers per wave in flight), 0 = VGPR ring of spmm_depth
     int spmm_census = 0;        // MFMA sweep, experiments (tests of the abandon-and-repair path): 1 = the census is called bad, 2 = one workgroup claims the
                                 // next XCC (a 33 / 31 census), 3 = one workgroup never arrives (the others run into the time limit: the slot is poisoned)
     int spmm_tmo_ms = 0;        // MFMA sweep, experiments: time limit of the census / the barriers in ms (0 = 2000)

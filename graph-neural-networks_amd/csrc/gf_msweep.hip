@@ -154,6 +154,48 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
     .endif
   .endif
 .endm
+// store phase: slot i of position p of set s = the row whose byte offset is word 4p + i of the set's line in the LDS row table
+// (staging: v[MS_R0 .. MS_R0+19] = four output quads + their addresses, row-table lines in v[MS_E0 .. MS_E0+7])
+.macro MS_STORE S, UNI, ro, vfg, vrow, suval
+  ds_read_b128 v[MS_E0:MS_E0+3], \vrow
+  .set MS_S, 0
+  .rept \S
+    .if MS_S + 1 < \S
+      ds_read_b128 v[MS_E0+4*((MS_S+1)&1):MS_E0+4*((MS_S+1)&1)+3], \vrow offset:(MS_S+1)*128
+      s_waitcnt lgkmcnt(1)
+    .else
+      s_waitcnt lgkmcnt(0)
+    .endif
+    .set MS_I, 0
+    .rept 4
+      .set MS_Q, 0
+      .rept 4
+        .set MS_RR, MS_S*16 + MS_Q*4 + MS_I
+        .if MS_RR < 256
+          v_accvgpr_read_b32 v[MS_R0+4*MS_I+MS_Q], a[MS_RR]
+          .if \UNI
+            v_mul_f32 v[MS_R0+4*MS_I+MS_Q], \suval, v[MS_R0+4*MS_I+MS_Q]
+          .endif
+        .else
+          .if \UNI
+            v_mul_f32 v[MS_R0+4*MS_I+MS_Q], \suval, v[MS_ACCV+MS_RR-256]
+          .else
+            v_mov_b32 v[MS_R0+4*MS_I+MS_Q], v[MS_ACCV+MS_RR-256]
+          .endif
+        .endif
+        .set MS_Q, MS_Q+1
+      .endr
+      v_add_u32 v[MS_R0+16+MS_I], v[MS_E0+4*(MS_S&1)+MS_I], \vfg
+      .if MS_STORE_PLAIN
+        buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen
+      .else
+        buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen nt
+      .endif
+      .set MS_I, MS_I+1
+    .endr
+    .set MS_S, MS_S+1
+  .endr
+.endm
 // S sets, ring depth D, two rounds per loop iteration (the entry buffers alternate by round parity; 2 S steps must be a multiple of D: ring
 // slots are static); scur = byte offset of the iteration's first round in the entry stream, sit = iterations left
 .macro MS_BODY S, UNI, RB, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, stl0, stl1, uid
@@ -221,45 +263,128 @@ MS_LOOP_\uid:
   s_nop 7
   s_nop 7
   s_nop 7
-  // store: slot i of position p of set s = the row whose byte offset is word 4p + i of the set's line in the LDS row table
-  ds_read_b128 v[MS_E0:MS_E0+3], \vrow
-  .set MS_S, 0
-  .rept \S
-    .if MS_S + 1 < \S
-      ds_read_b128 v[MS_E0+4*((MS_S+1)&1):MS_E0+4*((MS_S+1)&1)+3], \vrow offset:(MS_S+1)*128
-      s_waitcnt lgkmcnt(1)
-    .else
-      s_waitcnt lgkmcnt(0)
+  MS_STORE \S, \UNI, \ro, \vfg, \vrow, \suval
+.endm
+// ---- LDS ring (round 6) ----------------------------------------------------------------------------------------------------------------
+// The gathers of a wave land in LDS (buffer_load ... lds: LDS-DMA, M0 = slot base, lane l's 16 bytes at base + 16 l) instead of a VGPR ring:
+// a slot costs 1 KB of LDS, not four registers, so a wave keeps a whole ROUND (S = 25 gathers) in flight instead of 10 -- a first touch then
+// holds back the wave's in-order returns for a 25th of its window, and the vector cache's miss capacity, not the wave's window, sets the
+// number of misses in flight.  Step n consumes slot n % S (ds_read_b128 into one of two staging quads, issued a step ahead), runs its four
+// MFMAs and re-issues the slot with the same step of the NEXT round.  No scalar prefetch (lgkmcnt counts the ds_reads).
+//   v24 .. v31  staging quads (store phase: v24 .. v43 as above)      v32 .. v39  temporaries {entry, value, offset, mask} x step parity
+//   v44 .. v68  A operands of the S gathers in flight                 v70 .. v77 / v78 .. v85  entry / value buffers by round parity
+.macro ML_SETMAP
+  .set MS_A0, 44
+  .set MS_T0, 32
+  .set MS_E0, 70
+  .set MS_V0, 78
+.endm
+.macro ML_MFMA s, q, par
+  .if ((\s)*16 + (\q)*4) < 256
+    v_mfma_f32_4x4x1_16b_f32 a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3], v[MS_A0+(\s)], v[MS_R0+4*(\par)+(\q)], a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3]
+  .else
+    v_mfma_f32_4x4x1_16b_f32 v[MS_ACCV+(\s)*16+(\q)*4-256:MS_ACCV+(\s)*16+(\q)*4-256+3], v[MS_A0+(\s)], v[MS_R0+4*(\par)+(\q)], v[MS_ACCV+(\s)*16+(\q)*4-256:MS_ACCV+(\s)*16+(\q)*4-256+3]
+  .endif
+.endm
+// gather of step sp of the round whose entries sit in buffer `buf` into LDS slot sp, its A operand, and -- behind a round's last step -- the
+// reload of that buffer with the round two later (stream offset scur + rho3 KB)
+.macro ML_ISSUE sp, par, buf, rho3, S, UNI, rs, re, rv, vfg, vslot, vevoff, smask, scur, sring
+  .set MS_TA, MS_T0 + 4*(\par)
+  s_add_u32 m0, \sring, (\sp)*1024
+  v_and_or_b32 v[MS_TA+2], v[MS_TA], \smask, \vfg
+  v_bfe_i32 v[MS_TA+3], v[MS_TA], \vslot, 1
+  buffer_load_dwordx4 v[MS_TA+2], \rs, 0 offen lds
+  .if \UNI
+    v_and_b32 v[MS_A0+(\sp)], 1.0, v[MS_TA+3]
+  .else
+    v_and_b32 v[MS_A0+(\sp)], v[MS_TA+1], v[MS_TA+3]
+  .endif
+  .if (\sp) == (\S)-1
+    buffer_load_dwordx4 v[MS_E0+4*(\buf):MS_E0+4*(\buf)+3], \vevoff, \re, \scur offen offset:(\rho3)*1024
+    .if (\UNI) == 0
+      buffer_load_dwordx4 v[MS_V0+4*(\buf):MS_V0+4*(\buf)+3], \vevoff, \rv, \scur offen offset:(\rho3)*1024
     .endif
-    .set MS_I, 0
-    .rept 4
-      .set MS_Q, 0
-      .rept 4
-        .set MS_RR, MS_S*16 + MS_Q*4 + MS_I
-        .if MS_RR < 256
-          v_accvgpr_read_b32 v[MS_R0+4*MS_I+MS_Q], a[MS_RR]
-          .if \UNI
-            v_mul_f32 v[MS_R0+4*MS_I+MS_Q], \suval, v[MS_R0+4*MS_I+MS_Q]
-          .endif
-        .else
-          .if \UNI
-            v_mul_f32 v[MS_R0+4*MS_I+MS_Q], \suval, v[MS_ACCV+MS_RR-256]
-          .else
-            v_mov_b32 v[MS_R0+4*MS_I+MS_Q], v[MS_ACCV+MS_RR-256]
-          .endif
-        .endif
-        .set MS_Q, MS_Q+1
-      .endr
-      v_add_u32 v[MS_R0+16+MS_I], v[MS_E0+4*(MS_S&1)+MS_I], \vfg
-      .if MS_STORE_PLAIN
-        buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen
-      .else
-        buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen nt
-      .endif
-      .set MS_I, MS_I+1
-    .endr
-    .set MS_S, MS_S+1
+  .endif
+.endm
+// MS_CNT = entry-buffer reloads among the S - 2 steps before step n (one per round, behind the gather of step S - 1)
+.macro ML_RLCOUNT n, S
+  .set MS_CNT, 0
+  .set MS_DD, 1
+  .rept (\S)-2
+    .if (((\n)+2*(\S)-MS_DD) % (\S)) == (\S)-1
+      .set MS_CNT, MS_CNT+1
+    .endif
+    .set MS_DD, MS_DD+1
   .endr
+.endm
+.macro MS_LBODY S, UNI, ZERO, rs, ro, re, rv, vfg, vslot, vevoff, vrow, vlds, smask, suval, sring, scur, sit, stl0, stl1, uid
+  ML_SETMAP
+  buffer_load_dwordx4 v[MS_E0:MS_E0+3], \vevoff, \re, 0 offen
+  buffer_load_dwordx4 v[MS_E0+4:MS_E0+7], \vevoff, \re, 0 offen offset:1024
+  .if (\UNI) == 0
+    buffer_load_dwordx4 v[MS_V0:MS_V0+3], \vevoff, \rv, 0 offen
+    buffer_load_dwordx4 v[MS_V0+4:MS_V0+7], \vevoff, \rv, 0 offen offset:1024
+  .endif
+  .if \ZERO
+    MS_ZERO \S
+  .endif
+  s_waitcnt vmcnt(0) lgkmcnt(0)
+  s_memtime \stl0
+  // round 0: S gathers out (buffer 0), then buffer 0 <- round 2
+  .set MS_N, 0
+  .rept \S
+    MS_BCAST1 (MS_T0+4*(MS_N&1)), (MS_E0+(MS_N%4)), MS_N
+    .if (\UNI) == 0
+      MS_BCAST1 (MS_T0+4*(MS_N&1)+1), (MS_V0+(MS_N%4)), MS_N
+    .endif
+    s_nop 1
+    MS_BCAST2 (MS_T0+4*(MS_N&1)), MS_N
+    .if (\UNI) == 0
+      MS_BCAST2 (MS_T0+4*(MS_N&1)+1), MS_N
+    .endif
+    s_nop 0
+    ML_ISSUE MS_N, (MS_N&1), 0, 2, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur, \sring
+    .set MS_N, MS_N+1
+  .endr
+  s_waitcnt vmcnt((\S) - 1 + (2-(\UNI)))
+  ds_read_b128 v[MS_R0:MS_R0+3], \vlds
+ML_LOOP_\uid:
+  .set MS_N, 0
+  .rept 2*(\S)
+    .set MS_SP, MS_N % (\S)
+    .set MS_RHO, MS_N / (\S)
+    ML_RLCOUNT MS_N, \S
+    s_waitcnt vmcnt((\S) - 2 + MS_CNT*(2-(\UNI)))
+    ds_read_b128 v[MS_R0+4*((MS_N+1)&1):MS_R0+4*((MS_N+1)&1)+3], \vlds offset:((MS_N+1)%(\S))*1024
+    MS_BCAST1 (MS_T0+4*(MS_N&1)), (MS_E0+4*((MS_RHO+1)&1)+(MS_SP%4)), MS_SP
+    .if (\UNI) == 0
+      MS_BCAST1 (MS_T0+4*(MS_N&1)+1), (MS_V0+4*((MS_RHO+1)&1)+(MS_SP%4)), MS_SP
+    .endif
+    s_waitcnt lgkmcnt(1)
+    ML_MFMA MS_SP, 0, (MS_N&1)
+    ML_MFMA MS_SP, 1, (MS_N&1)
+    MS_BCAST2 (MS_T0+4*(MS_N&1)), MS_SP
+    .if (\UNI) == 0
+      MS_BCAST2 (MS_T0+4*(MS_N&1)+1), MS_SP
+    .endif
+    ML_MFMA MS_SP, 2, (MS_N&1)
+    ML_MFMA MS_SP, 3, (MS_N&1)
+    ML_ISSUE MS_SP, (MS_N&1), ((MS_RHO+1)&1), 3, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur, \sring
+    .if MS_SP == (\S)-1
+      s_add_u32 \scur, \scur, 1024           // scur = stream offset of the round being consumed (12-bit instruction offsets: <= 3 KB ahead)
+    .endif
+    .set MS_N, MS_N+1
+  .endr
+  s_sub_u32 \sit, \sit, 1
+  s_cmp_lg_u32 \sit, 0
+  s_cbranch_scc1 ML_LOOP_\uid
+  s_memtime \stl1
+  // the S gathers in flight belong to round T (gaps); they, the last staging read and the last entry reloads must land before their registers / slots are reused
+  s_waitcnt vmcnt(0) lgkmcnt(0)
+  s_nop 7
+  s_nop 7
+  s_nop 7
+  MS_STORE \S, \UNI, \ro, \vfg, \vrow, \suval
 .endm
 .endif
 )"
@@ -276,7 +401,7 @@ MS_LOOP_\uid:
         GF_MS_A8(19), GF_MS_A8(20), GF_MS_A8(21), GF_MS_A8(22), GF_MS_A8(23), GF_MS_A8(24), "a250", "a251", "a252", "a253",        \
         "a254", "a255"
 
-template <int S, int UNI, int PF, int D>
+template <int S, int UNI, int PF, int D, int RING>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restrict__ val, const uint32_t* __restrict__ rows,
                         const float* __restrict__ Xin, float* __restrict__ Xtaps, size_t tapStrideBytes, int nhops, int N, int B, int passes,
@@ -284,12 +409,15 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                         int nostore, unsigned long long* __restrict__ trace, int census, unsigned tmo_ticks) {
     constexpr unsigned kRoundBytes = 1024u;                 // a round of the entry stream: 8 positions x 8 quads x 16 bytes
     constexpr int U = 2;                                    // rounds per loop iteration (the two entry buffers alternate by round parity)
-    static_assert((U * S) % D == 0 && D < S && S <= kMsMaxSets && S <= 32,
+    static_assert(RING == 0 || (PF == 0 && D == S), "the LDS ring holds one round; no scalar prefetch beside its ds_reads");
+    static_assert(RING == 1 || ((U * S) % D == 0 && D < S), "VGPR ring");
+    static_assert(S <= kMsMaxSets && S <= 32,
                   "ring slots are static: 2 S steps are a multiple of the depth; a round's buffer is reloaded (for the round two later) behind "
                   "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
                   "inside the two rounds of an iteration (12-bit instruction offsets)");
     __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
     __shared__ unsigned s_ctl[4];                           // census result {XCC, rank, abandoned}, [3] = a barrier timed out
+    extern __shared__ __attribute__((aligned(16))) char s_ring[];   // RING: per wave S slots of 1 KB, the gathers in flight (LDS-DMA)
     asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN)
                  "\n\t.set GF_MS_EXP_VALUE, " GF_MS_STR(GF_MS_EXP));
     asm volatile(GF_MS_MACROS);
@@ -357,6 +485,8 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     const size_t streamWords = (size_t)(rounds + 2) * 256;
     const unsigned evoff = lane * 16u;                      // this lane's 16 bytes of a round of the entry stream (lane 8 p + i: quad i of position p)
     const unsigned rowlds = (unsigned)(size_t)(&s_rows[wv][0]) + pos * 16u;   // (an LDS address is the low half of the generic pointer)
+    const unsigned ringbase = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)s_ring + wv * (unsigned)(S * 1024)));
+    const unsigned ringlane = ringbase + lane * 16u;
     const unsigned smask = 0xffffff80u & src_mask;
     const unsigned chunkBytes = (unsigned)((N + rounds - 1) / rounds) * 128u;   // source rows per round
     unsigned* ctr = gate + (size_t)xcd * kMsGateWords;
@@ -391,11 +521,20 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             const char* xptr = src + (size_t)b * tapBytes;
             unsigned long long tl0, tl1;
             const unsigned long long t0 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-            asm volatile("MS_BODY %21, %22, %23, %24, %25, %26, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
-                         : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy), "=&s"(tl0), "=&s"(tl1)
-                         : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fg16), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
-                           "s"(xptr), "s"(smaxpf), "s"(U * chunkBytes), "s"(0), "n"(S), "n"(UNI), "n"(kRoundBytes), "n"(PF), "n"(D), "n"(U)
-                         : GF_MS_CLOBBERS);
+            if constexpr (RING) {
+                (void)spfr; (void)spfc; (void)sdummy; (void)xptr; (void)smaxpf;
+                asm volatile("MS_LBODY %16, %17, 1, %4, %5, %6, %7, %8, %9, %10, %11, %12, %13, %14, %15, %0, %1, %2, %3, %="
+                             : "+s"(scur), "+s"(sit), "=&s"(tl0), "=&s"(tl1)
+                             : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fg16), "v"(slotbit), "v"(evoff), "v"(rowlds), "v"(ringlane), "s"(smask), "s"(uval),
+                               "s"(ringbase), "n"(S), "n"(UNI)
+                             : GF_MS_CLOBBERS);   // (also writes m0: the compiler holds nothing there -- tools/check_msweep_isa.py)
+            } else {
+                asm volatile("MS_BODY %21, %22, %23, %24, %25, %26, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
+                             : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy), "=&s"(tl0), "=&s"(tl1)
+                             : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fg16), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
+                               "s"(xptr), "s"(smaxpf), "s"(U * chunkBytes), "s"(0), "n"(S), "n"(UNI), "n"(kRoundBytes), "n"(PF), "n"(D), "n"(U)
+                             : GF_MS_CLOBBERS);
+            }
             const unsigned long long t1 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
             const bool dependent = nhops > 1 && pass == passes - 1 && hop + 1 < nhops;   // the next hop gathers what this one stores
@@ -583,6 +722,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     }
     const bool pf = g_tune.spmm_pfd > 0;
     const bool deep = g_tune.spmm_depth != 5;   // ring of 10 gathers; 5: experiments
+    const bool ring = g_tune.spmm_ring != 0;    // the gathers in flight live in LDS (a whole round per wave) instead of a VGPR ring
     // A fused chain depends on its XCD barriers (hop h + 1 gathers what hop h stored): it is launched COOPERATIVELY -- the runtime starts the
     // grid only when all 256 workgroups can be resident together -- and opens with the census (kernel); the repair kernel behind it runs
     // only if the sweep abandoned the launch.  A single hop has no such dependence and takes the plain launch.
@@ -599,34 +739,38 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     void* args[] = {&a_ent, &a_val, &a_rows, &Xin, &Xtaps, &a_stride, &a_nhops, &a_N, &a_B, &a_passes, &a_rounds, &gate, &a_bar, &a_uval, &a_mask,
                     &a_pfd, &a_stag, &a_nostore, &trace, &a_census, &a_tmo};
     hipError_t lerr = hipSuccess;
-#define GF_MS(SV, UV, PV, DV)                                                                                                          \
+#define GF_MS(SV, UV, PV, DV, RV)                                                                                                      \
     do {                                                                                                                               \
+        const size_t lds_ = (RV) ? (size_t)4 * (SV) * 1024 : 0;                                                                        \
+        if (lds_ > 48 * 1024) lerr = gf_grant_lds((const void*)spmm_msweep_kernel<SV, UV, PV, DV, RV>, lds_ + 16 * 1024);              \
+        if (lerr != hipSuccess) break;                                                                                                 \
         if (chained)                                                                                                                   \
-            lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV>, grid, block, args, 0, st);              \
+            lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV, RV>, grid, block, args, (unsigned)lds_, st); \
         else                                                                                                                           \
-            hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV>), grid, block, 0, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
+            hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV, RV>), grid, block, lds_, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
                                a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_stag, a_nostore, trace, a_census, a_tmo);     \
     } while (0)
 #define GF_MS_P(SV, UV, DV)                            \
     do {                                              \
-        if (pf) GF_MS(SV, UV, 1, DV);                 \
-        else GF_MS(SV, UV, 0, DV);                    \
+        if (pf) GF_MS(SV, UV, 1, DV, 0);              \
+        else GF_MS(SV, UV, 0, DV, 0);                 \
     } while (0)
 #define GF_MS_D(SV, UV)                               \
     do {                                              \
-        if (deep) GF_MS_P(SV, UV, 10);                \
+        if (ring) GF_MS(SV, UV, 0, SV, 1);            \
+        else if (deep) GF_MS_P(SV, UV, 10);           \
         else GF_MS_P(SV, UV, 5);                      \
     } while (0)
     if (m.ms_uniform) {
         switch (m.ms_sets) {
-            case 10: GF_MS_P(10, 1, 5); break;
+            case 10: if (ring) GF_MS(10, 1, 0, 10, 1); else GF_MS_P(10, 1, 5); break;
             case 15: GF_MS_D(15, 1); break;
             case 20: GF_MS_D(20, 1); break;
             default: GF_MS_D(25, 1); break;
         }
     } else {
         switch (m.ms_sets) {
-            case 10: GF_MS_P(10, 0, 5); break;
+            case 10: if (ring) GF_MS(10, 0, 0, 10, 1); else GF_MS_P(10, 0, 5); break;
             case 15: GF_MS_D(15, 0); break;
             case 20: GF_MS_D(20, 0); break;
             default: GF_MS_D(25, 0); break;

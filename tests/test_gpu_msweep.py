@@ -27,7 +27,7 @@ def tune(**kw):
 @pytest.fixture
 def knobs():
     yield tune
-    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=16, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1)
+    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=16, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1, spmm_ring=0)
 
 
 def hop(plans, op, Xt, algo, **kw):
@@ -265,3 +265,29 @@ def test_fused_chain_beside_kernels_that_hold_compute_units(knobs):
         got = khop_chain(plans, x0, K)
         assert torch.equal(got, ref), (rep, int((got != ref).sum()))
     assert chain_status() == (0, 1)
+
+
+@pytest.mark.parametrize("n,deg,B,K,directed,weighted", [
+    (100000, 5, 24, 5, False, False),     # config 4's shape: 25 sets per wave = 25 gathers in flight per wave
+    (100000, 5, 9, 3, False, True),       # weighted: value buffers
+    (40000, 5, 17, 3, True, False),       # 10 sets
+    (60000, 4, 16, 4, False, False),      # 15 sets
+    (81000, 3, 8, 3, False, True),        # 20 sets, weighted
+    (130000, 3, 9, 3, False, False),      # two passes per batch entry
+])
+def test_msweep_lds_ring_is_bitwise_sell(n, deg, B, K, directed, weighted, knobs):
+    """spmm_ring = 1: the gathers in flight land in LDS (LDS-DMA) instead of a VGPR ring -- a whole round per wave in flight.  Same image, same
+    accumulators, same order of additions: single hops and the fused chain must reproduce SELL-8 bit for bit, both orientations."""
+    A = er(n, deg, seed=n + B + K, directed=directed, weighted=weighted)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    x0 = torch.randn(B, n, 32, device=DEV)
+    for op in (0, 1):
+        ref1 = hop(plans, op, x0, 3)
+        for rep in range(2):
+            got1 = hop(plans, op, x0, 5, spmm_ring=1, spmm_bar=rep)
+            assert torch.equal(got1, ref1), (op, rep, int((got1 != ref1).sum()), float((got1 - ref1).abs().max()))
+        ref = khop_chain(plans, x0, K, op, spmm_algo=3)
+        for rep in range(2):
+            got = khop_chain(plans, x0, K, op, spmm_algo=5, spmm_ring=1, spmm_fuse=1, spmm_bar=0)
+            assert torch.equal(got, ref), (op, rep, int((got != ref).sum()))

@@ -25,4 +25,10 @@ b)  # the census / repair protocol: tests, and what the census costs on the defa
   timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0+spmm_depth=0 v:spmm_depth=5 v:spmm_depth=0 v:spmm_depth=5 v:spmm_depth=0+spmm_fuse=0 v:spmm_fuse=1 2>&1 | grep "khop chain" | tee $O/khop.log
   timeout 300 python tools/msweep_trace.py 2>&1 | tail -12 | tee $O/trace_default.log
   ;;
+c)  # LDS ring (a whole round of gathers in flight per wave): parity, then time against the VGPR ring in the regimes of stage a
+  timeout 900 python -m pytest tests/test_gpu_msweep.py -x -q -k "lds_ring" 2>&1 | tail -15 | tee $O/pytest_ring.log
+  R="v:spmm_algo=0+spmm_ring=0+spmm_pfd=16+spmm_store=2+spmm_srcmask=0 v:spmm_ring=1 v:spmm_ring=0 v:spmm_ring=1 v:spmm_ring=1+spmm_store=3 v:spmm_ring=1+spmm_store=3+spmm_srcmask=1048448 v:spmm_ring=1+spmm_store=2+spmm_srcmask=1048448 v:spmm_ring=0+spmm_srcmask=0+spmm_fuse=0 v:spmm_ring=1+spmm_fuse=0"
+  timeout 300 python tools/hop_probe.py cfg4 10 $R 2>&1 | grep "khop chain" | tee $O/khop.log
+  timeout 300 python tools/msweep_trace.py spmm_ring=1 2>&1 | tail -12 | tee $O/trace_ring.log
+  ;;
 esac
