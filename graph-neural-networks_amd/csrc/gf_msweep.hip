@@ -415,9 +415,12 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                   "ring slots are static: 2 S steps are a multiple of the depth; a round's buffer is reloaded (for the round two later) behind "
                   "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
                   "inside the two rounds of an iteration (12-bit instruction offsets)");
-    __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
-    __shared__ unsigned s_ctl[4];                           // census result {XCC, rank, abandoned}, [3] = a barrier timed out
-    extern __shared__ __attribute__((aligned(16))) char s_ring[];   // RING: per wave S slots of 1 KB, the gathers in flight (LDS-DMA)
+    // LDS, all of it dynamic (a kernel that asks for more than 64 KB may not have static LDS on top: the grant is for the whole 160 KB):
+    //   RING: per wave S slots of 1 KB, the gathers in flight (LDS-DMA) | per wave the output byte offsets of (set, position, slot) | control words
+    extern __shared__ __attribute__((aligned(16))) char s_lds[];
+    char* const s_ring = s_lds;
+    unsigned (*const s_rows)[S * 32] = reinterpret_cast<unsigned (*)[S * 32]>(s_lds + (RING ? 4 * S * 1024 : 0));
+    unsigned* const s_ctl = reinterpret_cast<unsigned*>(s_lds + (RING ? 4 * S * 1024 : 0) + 4 * S * 128);   // census result {XCC, rank, abandoned}, [3] = a barrier timed out
     asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN)
                  "\n\t.set GF_MS_EXP_VALUE, " GF_MS_STR(GF_MS_EXP));
     asm volatile(GF_MS_MACROS);
@@ -741,8 +744,8 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     hipError_t lerr = hipSuccess;
 #define GF_MS(SV, UV, PV, DV, RV)                                                                                                      \
     do {                                                                                                                               \
-        const size_t lds_ = (RV) ? (size_t)4 * (SV) * 1024 : 0;                                                                        \
-        if (lds_ > 48 * 1024) lerr = gf_grant_lds((const void*)spmm_msweep_kernel<SV, UV, PV, DV, RV>, lds_ + 16 * 1024);              \
+        const size_t lds_ = ((RV) ? (size_t)4 * (SV) * 1024 : 0) + (size_t)4 * (SV) * 128 + 16;                                        \
+        if (lds_ > 64 * 1024) lerr = gf_grant_lds((const void*)spmm_msweep_kernel<SV, UV, PV, DV, RV>, lds_);                          \
         if (lerr != hipSuccess) break;                                                                                                 \
         if (chained)                                                                                                                   \
             lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV, RV>, grid, block, args, (unsigned)lds_, st); \
