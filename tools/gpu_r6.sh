@@ -31,4 +31,12 @@ c)  # LDS ring (a whole round of gathers in flight per wave): parity, then time 
   timeout 300 python tools/hop_probe.py cfg4 10 $R 2>&1 | grep "khop chain" | tee $O/khop.log
   timeout 300 python tools/msweep_trace.py spmm_ring=1 2>&1 | tail -12 | tee $O/trace_ring.log
   ;;
+d)  # near scalar prefetch at a controlled rate: one row every k-th step (k = 1 shipped, 2, 3, 4), lead 1 .. 16 iterations
+  for lib in "" pfk2 pfk3 pfk4; do
+    if [ -n "$lib" ]; then export GFHIP_LIB=$LIBD/libgfhip_$lib.so; else unset GFHIP_LIB; fi
+    echo "== lib=${lib:-shipped}" | tee -a $O/khop.log
+    V="v:spmm_algo=0+spmm_pfd=16"; for l in 1 2 3 4 6 8 12 16 0; do V="$V v:spmm_pfd=$l"; done
+    timeout 300 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "khop chain" | sed 's/bitwise.*//' | tee -a $O/khop.log
+  done
+  ;;
 esac
