@@ -151,14 +151,12 @@ struct gf_tuning {
     int spmm_pfd = 16;          // MFMA sweep: scalar prefetch of the source rows this many loop iterations ahead (0 = off; measured best: 12-16 of the 21
                                 // iterations of config 4 -- the prefetch then runs during the first 40 % of an entry, while the previous stores drain)
     int spmm_passes = 2;        // MFMA sweep image: passes (sweeps of the sources) allowed per batch entry -- 1: N <= 102 400, 2: up to 204 800 (set BEFORE gf_plan_create)
-    int spmm_ring = 0;          // MFMA sweep: 1 = the gathers in flight land in LDS (LDS-DMA; a whole round = S gathers per wave in flight), 0 = VGPR ring of spmm_depth
     int spmm_census = 0;        // MFMA sweep, experiments (tests of the abandon-and-repair path): 1 = the census is called bad, 2 = one workgroup claims the
                                 // next XCC (a 33 / 31 census), 3 = one workgroup never arrives (the others run into the time limit: the slot is poisoned)
     int spmm_tmo_ms = 0;        // MFMA sweep, experiments: time limit of the census / the barriers in ms (0 = 2000)
     int spmm_trace = 0;         // MFMA sweep, experiments: record phase time stamps (gf_debug_msweep_trace)
     int spmm_fuse = 1;          // MFMA sweep: the K - 1 hops of gf_khop in one launch, entry by entry (0 = one launch per hop)
     int spmm_depth = 0;         // MFMA sweep: gathers in flight per wave, 0 = default (10 from 15 sets per wave on, 5 at 10 sets), 5
-    int spmm_stag = 0;          // MFMA sweep, experiments: XCD x starts x * spmm_stag * ~3.4 us late
     int spmm_srcmask = 0;       // MFMA sweep, timing experiments only (results wrong): AND mask on the gathered source offsets (confines them to a window)
     int spmm_slack = 5;         // MFMA sweep image: rounds beyond the mean group length, in percent (set BEFORE gf_plan_create)
     int spmm_xcd = 1;           // 1 = XCD-aware tile order
@@ -196,7 +194,7 @@ extern gf_tuning g_tune;
 // internal launchers shared between translation units
 bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W);
 // nhops hops in one launch: hop h reads Xin (h = 0) or Xtaps + (h - 1) * tapStride floats and writes Xtaps + h * tapStride floats
-int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, hipStream_t st);
+int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st);
 size_t gf_msweep_gate_bytes();
 unsigned* gf_msweep_status_word();          // pinned host word the repair kernel reports into (allocated on first use: call at plan creation)
 bool gf_msweep_fusion_allowed();            // false once a launch had to be repaired, or with GFHIP_MSWEEP_FUSE=0

@@ -41,7 +41,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMsGateWords = 64;      // per XCD: the arrival counter (word 0) and the generation word (word 16) of its barrier, 256 bytes of their own
+constexpr int kMsGateWords = 64;      // per XCD: the arrival counter (word 0) of its barrier, 256 bytes of its own
 constexpr int kMsGateSlots = 16;      // launches whose barriers may be live at once: one slot per stream (zeroed once, at plan creation)
 // behind the 8 team lines of a slot: the census block of its launches (agent-scope atomics only)
 constexpr int kMsCensusWord = 8 * kMsGateWords;
@@ -62,8 +62,8 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 #define GF_MS_STPLAIN 1 // L2, and the rows stored LAST are the lowest bands -- the ones the next hop of the fused chain gathers first (1.24 -> 1.13 ms at config 4)
 #endif
 #ifndef GF_MS_EXP      // experiments (make msvariant; TIMING ONLY, results wrong): bit 0 = no MFMAs in the loop, bit 1 = plain moves instead of the DPP
-#define GF_MS_EXP 0    // broadcasts, bit 2 = global_load (saddr + 32-bit offset) instead of buffer_load offen (only with spmm_srcmask: gaps are not range-checked),
-#endif                 // bit 3 = two of the four MFMAs
+#define GF_MS_EXP 0    // broadcasts (both change the addresses: not a valid timing), bit 3 = two of the four MFMAs (round 6's global_load variant, bit 2: same time as buffer_load)
+#endif
 #ifndef GF_MS_PFK      // scalar prefetch: one source row (two s_loads) every GF_MS_PFK-th step of a wave
 #define GF_MS_PFK 1
 #endif
@@ -137,10 +137,18 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 // behind the last step of a round -- the reload of that round's buffer with the round two later
 .macro MS_ISSUE sp, k, par, buf, rho, S, UNI, rs, re, rv, vfg, vslot, vevoff, smask, scur, xptr
   .set MS_TA, MS_T0 + 4*(\par)
+  .if MS_IDX                                   // wide rows (W = 64 / 96 / 128): address = row index x stride (buffer resource) + constant column offset in v[MS_TA+3]
+    v_lshrrev_b32 v[MS_TA+2], 7, v[MS_TA]
+    buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2:MS_TA+3], \rs, 0 idxen offen
+    v_bfe_i32 v[MS_A0+(\k)], v[MS_TA], \vslot, 1
+    .if \UNI
+      v_and_b32 v[MS_A0+(\k)], 1.0, v[MS_A0+(\k)]
+    .else
+      v_and_b32 v[MS_A0+(\k)], v[MS_TA+1], v[MS_A0+(\k)]
+    .endif
+  .else
   v_and_or_b32 v[MS_TA+2], v[MS_TA], \smask, \vfg
-  .if MS_EXP & 4
-    global_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2], \xptr
-  .elseif MS_GATHER_NT
+  .if MS_GATHER_NT
     buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2], \rs, 0 offen nt
   .else
     buffer_load_dwordx4 v[MS_R0+4*(\k):MS_R0+4*(\k)+3], v[MS_TA+2], \rs, 0 offen
@@ -150,6 +158,7 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
     v_and_b32 v[MS_A0+(\k)], 1.0, v[MS_TA+3]
   .else
     v_and_b32 v[MS_A0+(\k)], v[MS_TA+1], v[MS_TA+3]
+  .endif
   .endif
   .if (\sp) == (\S)-1
     buffer_load_dwordx4 v[MS_E0+4*(\buf):MS_E0+4*(\buf)+3], \vevoff, \re, \scur offen offset:((\rho)+2)*1024
@@ -161,6 +170,12 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 // store phase: slot i of position p of set s = the row whose byte offset is word 4p + i of the set's line in the LDS row table
 // (staging: v[MS_R0 .. MS_R0+19] = four output quads + their addresses, row-table lines in v[MS_E0 .. MS_E0+7])
 .macro MS_STORE S, UNI, ro, vfg, vrow, suval
+  .if MS_IDX                                   // (wide rows: store address = {row index, column offset} pairs in the dead A-operand registers)
+    v_mov_b32 v[MS_A0+1], \vfg
+    v_mov_b32 v[MS_A0+3], \vfg
+    v_mov_b32 v[MS_A0+5], \vfg
+    v_mov_b32 v[MS_A0+7], \vfg
+  .endif
   ds_read_b128 v[MS_E0:MS_E0+3], \vrow
   .set MS_S, 0
   .rept \S
@@ -175,8 +190,9 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
       .set MS_Q, 0
       .rept 4
         .set MS_RR, MS_S*16 + MS_Q*4 + MS_I
-        .if MS_RR < 256
+        .if MS_RR < 256                          // (read, then zero: the next (entry, hop) finds its accumulators cleared)
           v_accvgpr_read_b32 v[MS_R0+4*MS_I+MS_Q], a[MS_RR]
+          v_accvgpr_write_b32 a[MS_RR], 0
           .if \UNI
             v_mul_f32 v[MS_R0+4*MS_I+MS_Q], \suval, v[MS_R0+4*MS_I+MS_Q]
           .endif
@@ -186,14 +202,20 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
           .else
             v_mov_b32 v[MS_R0+4*MS_I+MS_Q], v[MS_ACCV+MS_RR-256]
           .endif
+          v_mov_b32 v[MS_ACCV+MS_RR-256], 0
         .endif
         .set MS_Q, MS_Q+1
       .endr
+      .if MS_IDX
+        v_lshrrev_b32 v[MS_A0+2*MS_I], 7, v[MS_E0+4*(MS_S&1)+MS_I]
+        buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_A0+2*MS_I:MS_A0+2*MS_I+1], \ro, 0 idxen offen
+      .else
       v_add_u32 v[MS_R0+16+MS_I], v[MS_E0+4*(MS_S&1)+MS_I], \vfg
       .if MS_STORE_PLAIN
         buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen
       .else
         buffer_store_dwordx4 v[MS_R0+4*MS_I:MS_R0+4*MS_I+3], v[MS_R0+16+MS_I], \ro, 0 offen nt
+      .endif
       .endif
       .set MS_I, MS_I+1
     .endr
@@ -202,15 +224,21 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 .endm
 // S sets, ring depth D, two rounds per loop iteration (the entry buffers alternate by round parity; 2 S steps must be a multiple of D: ring
 // slots are static); scur = byte offset of the iteration's first round in the entry stream, sit = iterations left
-.macro MS_BODY S, UNI, RB, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, stl0, stl1, uid
+.macro MS_BODY S, UNI, IDX, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, stl0, stl1, uid
   MS_SETMAP \D
+  .set MS_IDX, \IDX
+  s_nop 4                                      // (an SGPR operand the compiler has just written with a VALU instruction -- v_readfirstlane / v_readlane -- needs five wait states before
+                                               //  a VMEM instruction reads it, and the hazard recogniser does not look into this block)
   buffer_load_dwordx4 v[MS_E0:MS_E0+3], \vevoff, \re, 0 offen
   buffer_load_dwordx4 v[MS_E0+4:MS_E0+7], \vevoff, \re, 0 offen offset:1024
   .if (\UNI) == 0
     buffer_load_dwordx4 v[MS_V0:MS_V0+3], \vevoff, \rv, 0 offen
     buffer_load_dwordx4 v[MS_V0+4:MS_V0+7], \vevoff, \rv, 0 offen offset:1024
   .endif
-  MS_ZERO \S
+  .if MS_IDX
+    v_mov_b32 v[MS_T0+3], \vfg
+    v_mov_b32 v[MS_T0+7], \vfg
+  .endif
   s_waitcnt vmcnt(0)
   s_memtime \stl0
   .set MS_N, 0
@@ -269,127 +297,6 @@ MS_LOOP_\uid:
   s_nop 7
   MS_STORE \S, \UNI, \ro, \vfg, \vrow, \suval
 .endm
-// ---- LDS ring (round 6) ----------------------------------------------------------------------------------------------------------------
-// The gathers of a wave land in LDS (buffer_load ... lds: LDS-DMA, M0 = slot base, lane l's 16 bytes at base + 16 l) instead of a VGPR ring:
-// a slot costs 1 KB of LDS, not four registers, so a wave keeps a whole ROUND (S = 25 gathers) in flight instead of 10 -- a first touch then
-// holds back the wave's in-order returns for a 25th of its window, and the vector cache's miss capacity, not the wave's window, sets the
-// number of misses in flight.  Step n consumes slot n % S (ds_read_b128 into one of two staging quads, issued a step ahead), runs its four
-// MFMAs and re-issues the slot with the same step of the NEXT round.  No scalar prefetch (lgkmcnt counts the ds_reads).
-//   v24 .. v31  staging quads (store phase: v24 .. v43 as above)      v32 .. v39  temporaries {entry, value, offset, mask} x step parity
-//   v44 .. v68  A operands of the S gathers in flight                 v70 .. v77 / v78 .. v85  entry / value buffers by round parity
-.macro ML_SETMAP
-  .set MS_A0, 44
-  .set MS_T0, 32
-  .set MS_E0, 70
-  .set MS_V0, 78
-.endm
-.macro ML_MFMA s, q, par
-  .if ((\s)*16 + (\q)*4) < 256
-    v_mfma_f32_4x4x1_16b_f32 a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3], v[MS_A0+(\s)], v[MS_R0+4*(\par)+(\q)], a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3]
-  .else
-    v_mfma_f32_4x4x1_16b_f32 v[MS_ACCV+(\s)*16+(\q)*4-256:MS_ACCV+(\s)*16+(\q)*4-256+3], v[MS_A0+(\s)], v[MS_R0+4*(\par)+(\q)], v[MS_ACCV+(\s)*16+(\q)*4-256:MS_ACCV+(\s)*16+(\q)*4-256+3]
-  .endif
-.endm
-// gather of step sp of the round whose entries sit in buffer `buf` into LDS slot sp, its A operand, and -- behind a round's last step -- the
-// reload of that buffer with the round two later (stream offset scur + rho3 KB)
-.macro ML_ISSUE sp, par, buf, rho3, S, UNI, rs, re, rv, vfg, vslot, vevoff, smask, scur, sring
-  .set MS_TA, MS_T0 + 4*(\par)
-  s_add_u32 m0, \sring, (\sp)*1024
-  v_and_or_b32 v[MS_TA+2], v[MS_TA], \smask, \vfg
-  v_bfe_i32 v[MS_TA+3], v[MS_TA], \vslot, 1
-  buffer_load_dwordx4 v[MS_TA+2], \rs, 0 offen lds
-  .if \UNI
-    v_and_b32 v[MS_A0+(\sp)], 1.0, v[MS_TA+3]
-  .else
-    v_and_b32 v[MS_A0+(\sp)], v[MS_TA+1], v[MS_TA+3]
-  .endif
-  .if (\sp) == (\S)-1
-    buffer_load_dwordx4 v[MS_E0+4*(\buf):MS_E0+4*(\buf)+3], \vevoff, \re, \scur offen offset:(\rho3)*1024
-    .if (\UNI) == 0
-      buffer_load_dwordx4 v[MS_V0+4*(\buf):MS_V0+4*(\buf)+3], \vevoff, \rv, \scur offen offset:(\rho3)*1024
-    .endif
-  .endif
-.endm
-// MS_CNT = entry-buffer reloads among the S - 2 steps before step n (one per round, behind the gather of step S - 1)
-.macro ML_RLCOUNT n, S
-  .set MS_CNT, 0
-  .set MS_DD, 1
-  .rept (\S)-2
-    .if (((\n)+2*(\S)-MS_DD) % (\S)) == (\S)-1
-      .set MS_CNT, MS_CNT+1
-    .endif
-    .set MS_DD, MS_DD+1
-  .endr
-.endm
-.macro MS_LBODY S, UNI, ZERO, rs, ro, re, rv, vfg, vslot, vevoff, vrow, vlds, smask, suval, sring, scur, sit, stl0, stl1, uid
-  ML_SETMAP
-  buffer_load_dwordx4 v[MS_E0:MS_E0+3], \vevoff, \re, 0 offen
-  buffer_load_dwordx4 v[MS_E0+4:MS_E0+7], \vevoff, \re, 0 offen offset:1024
-  .if (\UNI) == 0
-    buffer_load_dwordx4 v[MS_V0:MS_V0+3], \vevoff, \rv, 0 offen
-    buffer_load_dwordx4 v[MS_V0+4:MS_V0+7], \vevoff, \rv, 0 offen offset:1024
-  .endif
-  .if \ZERO
-    MS_ZERO \S
-  .endif
-  s_waitcnt vmcnt(0) lgkmcnt(0)
-  s_memtime \stl0
-  // round 0: S gathers out (buffer 0), then buffer 0 <- round 2
-  .set MS_N, 0
-  .rept \S
-    MS_BCAST1 (MS_T0+4*(MS_N&1)), (MS_E0+(MS_N%4)), MS_N
-    .if (\UNI) == 0
-      MS_BCAST1 (MS_T0+4*(MS_N&1)+1), (MS_V0+(MS_N%4)), MS_N
-    .endif
-    s_nop 1
-    MS_BCAST2 (MS_T0+4*(MS_N&1)), MS_N
-    .if (\UNI) == 0
-      MS_BCAST2 (MS_T0+4*(MS_N&1)+1), MS_N
-    .endif
-    s_nop 0
-    ML_ISSUE MS_N, (MS_N&1), 0, 2, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur, \sring
-    .set MS_N, MS_N+1
-  .endr
-  s_waitcnt vmcnt((\S) - 1 + (2-(\UNI)))
-  ds_read_b128 v[MS_R0:MS_R0+3], \vlds
-ML_LOOP_\uid:
-  .set MS_N, 0
-  .rept 2*(\S)
-    .set MS_SP, MS_N % (\S)
-    .set MS_RHO, MS_N / (\S)
-    ML_RLCOUNT MS_N, \S
-    s_waitcnt vmcnt((\S) - 2 + MS_CNT*(2-(\UNI)))
-    ds_read_b128 v[MS_R0+4*((MS_N+1)&1):MS_R0+4*((MS_N+1)&1)+3], \vlds offset:((MS_N+1)%(\S))*1024
-    MS_BCAST1 (MS_T0+4*(MS_N&1)), (MS_E0+4*((MS_RHO+1)&1)+(MS_SP%4)), MS_SP
-    .if (\UNI) == 0
-      MS_BCAST1 (MS_T0+4*(MS_N&1)+1), (MS_V0+4*((MS_RHO+1)&1)+(MS_SP%4)), MS_SP
-    .endif
-    s_waitcnt lgkmcnt(1)
-    ML_MFMA MS_SP, 0, (MS_N&1)
-    ML_MFMA MS_SP, 1, (MS_N&1)
-    MS_BCAST2 (MS_T0+4*(MS_N&1)), MS_SP
-    .if (\UNI) == 0
-      MS_BCAST2 (MS_T0+4*(MS_N&1)+1), MS_SP
-    .endif
-    ML_MFMA MS_SP, 2, (MS_N&1)
-    ML_MFMA MS_SP, 3, (MS_N&1)
-    ML_ISSUE MS_SP, (MS_N&1), ((MS_RHO+1)&1), 3, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur, \sring
-    .if MS_SP == (\S)-1
-      s_add_u32 \scur, \scur, 1024           // scur = stream offset of the round being consumed (12-bit instruction offsets: <= 3 KB ahead)
-    .endif
-    .set MS_N, MS_N+1
-  .endr
-  s_sub_u32 \sit, \sit, 1
-  s_cmp_lg_u32 \sit, 0
-  s_cbranch_scc1 ML_LOOP_\uid
-  s_memtime \stl1
-  // the S gathers in flight belong to round T (gaps); they, the last staging read and the last entry reloads must land before their registers / slots are reused
-  s_waitcnt vmcnt(0) lgkmcnt(0)
-  s_nop 7
-  s_nop 7
-  s_nop 7
-  MS_STORE \S, \UNI, \ro, \vfg, \vrow, \suval
-.endm
 .endif
 )"
 
@@ -405,26 +312,20 @@ ML_LOOP_\uid:
         GF_MS_A8(19), GF_MS_A8(20), GF_MS_A8(21), GF_MS_A8(22), GF_MS_A8(23), GF_MS_A8(24), "a250", "a251", "a252", "a253",        \
         "a254", "a255"
 
-template <int S, int UNI, int PF, int D, int RING>
+template <int S, int UNI, int PF, int D, int IDX>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restrict__ val, const uint32_t* __restrict__ rows,
                         const float* __restrict__ Xin, float* __restrict__ Xtaps, size_t tapStrideBytes, int nhops, int N, int B, int passes,
-                        int rounds, unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask, int pf_lead, int stagger,
-                        int nostore, unsigned long long* __restrict__ trace, int census, unsigned tmo_ticks) {
-    constexpr unsigned kRoundBytes = 1024u;                 // a round of the entry stream: 8 positions x 8 quads x 16 bytes
+                        int rounds, unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask, int pf_lead,
+                        int nostore, unsigned long long* __restrict__ trace, int census, unsigned tmo_ticks, int W) {
     constexpr int U = 2;                                    // rounds per loop iteration (the two entry buffers alternate by round parity)
-    static_assert(RING == 0 || (PF == 0 && D == S), "the LDS ring holds one round; no scalar prefetch beside its ds_reads");
-    static_assert(RING == 1 || ((U * S) % D == 0 && D < S), "VGPR ring");
-    static_assert(S <= kMsMaxSets && S <= 32,
+    static_assert(IDX == 0 || PF == 0, "wide rows: no scalar prefetch");
+    static_assert((U * S) % D == 0 && D < S && S <= kMsMaxSets && S <= 32,
                   "ring slots are static: 2 S steps are a multiple of the depth; a round's buffer is reloaded (for the round two later) behind "
                   "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
                   "inside the two rounds of an iteration (12-bit instruction offsets)");
-    // LDS, all of it dynamic (a kernel that asks for more than 64 KB may not have static LDS on top: the grant is for the whole 160 KB):
-    //   RING: per wave S slots of 1 KB, the gathers in flight (LDS-DMA) | per wave the output byte offsets of (set, position, slot) | control words
-    extern __shared__ __attribute__((aligned(16))) char s_lds[];
-    char* const s_ring = s_lds;
-    unsigned (*const s_rows)[S * 32] = reinterpret_cast<unsigned (*)[S * 32]>(s_lds + (RING ? 4 * S * 1024 : 0));
-    unsigned* const s_ctl = reinterpret_cast<unsigned*>(s_lds + (RING ? 4 * S * 1024 : 0) + 4 * S * 128);   // census result {XCC, rank, abandoned}, [3] = a barrier timed out
+    __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
+    __shared__ unsigned s_ctl[4];                           // census result {XCC, rank, abandoned}, [3] = a barrier timed out
     asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN)
                  "\n\t.set GF_MS_EXP_VALUE, " GF_MS_STR(GF_MS_EXP) "\n\t.set GF_MS_PFK_VALUE, " GF_MS_STR(GF_MS_PFK));
     asm volatile(GF_MS_MACROS);
@@ -487,30 +388,36 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
         rank = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ctl[1]);
     }
     const unsigned wid = (unsigned)__builtin_amdgcn_readfirstlane((int)(rank * (kThreads / 64) + wv));   // wave of this XCD's team
+    // accumulators start at zero; every store phase leaves them zero again (the compiler keeps out of v24+ / a0+ between the bodies:
+    // tools/check_msweep_isa.py, a CPU test)
+    asm volatile("MS_ZERO %0" ::"n"(S) : GF_MS_CLOBBERS);
     const unsigned pos = lane >> 3, fg16 = (lane & 7u) * 16u, slotbit = lane & 3u;
     const unsigned tapBytes = (unsigned)N * 128u;
     const size_t streamWords = (size_t)(rounds + 2) * 256;
     const unsigned evoff = lane * 16u;                      // this lane's 16 bytes of a round of the entry stream (lane 8 p + i: quad i of position p)
     const unsigned rowlds = (unsigned)(size_t)(&s_rows[wv][0]) + pos * 16u;   // (an LDS address is the low half of the generic pointer)
-    const unsigned ringbase = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)s_ring + wv * (unsigned)(S * 1024)));
-    const unsigned ringlane = ringbase + lane * 16u;
     const unsigned smask = 0xffffff80u & src_mask;
     const unsigned chunkBytes = (unsigned)((N + rounds - 1) / rounds) * 128u;   // source rows per round
     unsigned* ctr = gate + (size_t)xcd * kMsGateWords;
-    unsigned slot = 0;                                      // (entry, hop, pass) bodies done: the trace slot
     int table_of = -1;
-    // (experiments) XCD x starts x * stagger * ~3.4 us late, so that the XCDs' store phases do not coincide
-    for (int i = 0; i < xcd * stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     // Batch entry b runs through all its hops before the XCD takes the next entry (hop h reads the tap hop h - 1 wrote: Xin for the
     // first, then Xtaps + (h - 1) taps; it writes Xtaps + h taps): the rows a hop gathers first were written by this XCD a moment ago
     // and are still in its L2 (the image stores the lowest row bands last).
-    for (int b = xcd; b < B; b += 8)
+    // Wide rows (IDX: W = 64 / 96 / 128 floats): a batch entry is W / 32 independent SLABS of 32 columns -- the same image, the same
+    // sums; a gather addresses {row, slab column} through a buffer resource whose stride is the row (range check: row < N).  The XCD's
+    // work list is the (entry, slab) pairs x, x + 8, ...
+    const int nslab = IDX ? (W >> 5) : 1;
+    const unsigned rowBytes = IDX ? (unsigned)W * 4u : 128u;
+    const size_t entryBytes = (size_t)N * rowBytes;
+    for (int ve = xcd; ve < B * nslab; ve += 8)
       for (int hop = 0; hop < nhops; ++hop) {
+        const int b = IDX ? ve / nslab : ve;
+        const unsigned fgs = IDX ? fg16 + (unsigned)(ve - b * nslab) * 128u : fg16;
         const char* src = hop == 0 ? reinterpret_cast<const char*>(Xin) : reinterpret_cast<const char*>(Xtaps) + (size_t)(hop - 1) * tapStrideBytes;
         char* dst = reinterpret_cast<char*>(Xtaps) + (size_t)hop * tapStrideBytes;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)b * tapBytes), 0, (int)tapBytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (size_t)b * tapBytes), 0, nostore ? 0 : (int)tapBytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)b * entryBytes), IDX ? (short)rowBytes : (short)0, IDX ? N : (int)tapBytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (size_t)b * entryBytes), IDX ? (short)rowBytes : (short)0, nostore ? 0 : (IDX ? N : (int)tapBytes), 0x00020000);
         for (int pass = 0; pass < passes; ++pass) {
             const size_t pw = (size_t)pass * kMsWavesPerXcd + wid;
             if (table_of != pass) {   // wave-private copy (LDS operations of one wave execute in order: no barrier)
@@ -525,31 +432,27 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             // vector cache's, whose in-order returns would hold the wave's other gathers behind an HBM round trip
             const unsigned smaxpf = tapBytes - (unsigned)(U * S) * 0x4000u - 128u;
             unsigned spfr = (unsigned)pf_lead * (U * chunkBytes) + wid * 128u, spfc = spfr < smaxpf ? spfr : smaxpf, sdummy;
-            const char* xptr = src + (size_t)b * tapBytes;
+            const char* xptr = src + (size_t)b * entryBytes;
             unsigned long long tl0, tl1;
-            const unsigned long long t0 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-            if constexpr (RING) {
-                (void)spfr; (void)spfc; (void)sdummy; (void)xptr; (void)smaxpf;
-                asm volatile("MS_LBODY %16, %17, 1, %4, %5, %6, %7, %8, %9, %10, %11, %12, %13, %14, %15, %0, %1, %2, %3, %="
-                             : "+s"(scur), "+s"(sit), "=&s"(tl0), "=&s"(tl1)
-                             : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fg16), "v"(slotbit), "v"(evoff), "v"(rowlds), "v"(ringlane), "s"(smask), "s"(uval),
-                               "s"(ringbase), "n"(S), "n"(UNI)
-                             : GF_MS_CLOBBERS);   // (also writes m0: the compiler holds nothing there -- tools/check_msweep_isa.py)
-            } else {
-                asm volatile("MS_BODY %21, %22, %23, %24, %25, %26, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
+            if constexpr (PF) {
+                asm volatile("MS_BODY %20, %21, %22, 1, %23, %24, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
                              : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy), "=&s"(tl0), "=&s"(tl1)
-                             : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fg16), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
-                               "s"(xptr), "s"(smaxpf), "s"(U * chunkBytes), "s"(0), "n"(S), "n"(UNI), "n"(kRoundBytes), "n"(PF), "n"(D), "n"(U)
+                             : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fgs), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
+                               "s"(xptr), "s"(smaxpf), "s"(U * chunkBytes), "n"(S), "n"(UNI), "n"(IDX), "n"(D), "n"(U)
+                             : GF_MS_CLOBBERS);
+            } else {   // (no scalar prefetch: its six operands are not materialised)
+                (void)spfr; (void)spfc; (void)sdummy; (void)xptr; (void)smaxpf;
+                asm volatile("MS_BODY %15, %16, %17, 0, %18, %19, %4, %5, %6, %7, %8, %9, %10, %11, %12, %13, %14, %14, %14, %0, %1, %14, %14, %14, %2, %3, %="
+                             : "+s"(scur), "+s"(sit), "=&s"(tl0), "=&s"(tl1)
+                             : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fgs), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
+                               "s"(0), "n"(S), "n"(UNI), "n"(IDX), "n"(D), "n"(U)
                              : GF_MS_CLOBBERS);
             }
             const unsigned long long t1 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
             const bool dependent = nhops > 1 && pass == passes - 1 && hop + 1 < nhops;   // the next hop gathers what this one stores
-            ++slot;
             if (use_barrier || dependent) {
-                // XCD barrier, self-resetting (no state to zero between launches: a captured launch replays as is): the workgroups of an
-                // XCD add 1 to the XCD's arrival counter; the 32nd takes the counter back to 0 and advances the generation word, the others
-                // poll the generation they read BEFORE arriving (it cannot move until all 32, they included, have arrived).  Scalar atomics:
+                // XCD barrier (no state to zero between launches: a captured launch replays as is).  Scalar atomics:
                 // they execute in the XCD's L2 and wait on lgkmcnt, not on the stores' vmcnt.  Between the hops of an entry the barrier
                 // orders this hop's stores (acknowledged by the L2: vmcnt(0)) before the next hop's gathers from the other CUs of the team --
                 // the team IS the set of workgroups on one XCC (census above), so counters and rows live in the one L2 they all use.  The
@@ -558,22 +461,23 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                 if (dependent) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (wv == 0) {
-                    unsigned g0 = 0u, t = 1u, g = 0u;
-                    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(g0) : "s"(ctr + 16) : "memory");
+                    // ONE monotonic counter per team: arrival = fetch-add, the barrier opens when the count reaches the next multiple of 32 (exactly 32
+                    // arrivals per barrier, so launches start on a multiple and nothing has to be reset; the last arriver is through after one L2
+                    // round trip, the others after their next poll).  Wrap-around: compared as a signed difference.
+                    unsigned t = 1u;
                     asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ctr) : "memory");
-                    if (t == 31u) {
-                        unsigned m32 = 32u, one = 1u;
-                        asm volatile("s_atomic_sub %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(m32) : "s"(ctr) : "memory");
-                        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(one) : "s"(ctr + 16) : "memory");
-                    } else {
+                    if ((t & 31u) != 31u) {
+                        const unsigned target = (t & ~31u) + 32u;
                         const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
-                        for (g = g0; g == g0;) {
+                        bool open = false;
+                        while (!open) {
                             __builtin_amdgcn_s_sleep(2);
-                            g = 0u;
-                            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(g) : "s"(ctr + 16) : "memory");
-                            if (g == g0 && __builtin_amdgcn_s_memrealtime() - tb > (unsigned long long)tmo_ticks) break;
+                            unsigned v = 0u;
+                            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(ctr) : "memory");
+                            open = (int)(v - target) >= 0;
+                            if (!open && __builtin_amdgcn_s_memrealtime() - tb > (unsigned long long)tmo_ticks) break;
                         }
-                        if (g == g0 && lane == 0) {         // a team mate is gone: abandon the launch (the repair kernel redoes the whole chain)
+                        if (!open && lane == 0) {           // a team mate is gone: abandon the launch (the repair kernel redoes the whole chain)
                             ag_store(cs + kCsPoison, 1u);
                             ag_store(cs + kCsRepair, 1u);
                             s_ctl[3] = 1u;
@@ -583,9 +487,10 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                 __syncthreads();
                 if (s_ctl[3]) return;
             }
-            if (trace && wid == 0 && lane == 0 && slot <= 64) {   // (experiments) phase stamps of the XCD's first wave: entry start, previous
-                unsigned long long* t = trace + ((size_t)xcd * 64 + (slot - 1)) * 8;   // stores drained + entries loaded, loop end, stores issued, barrier passed
-                t[0] = t0; t[1] = tl0; t[2] = tl1; t[3] = t1; t[4] = __builtin_amdgcn_s_memtime();
+            const int slot = ((ve >> 3) * nhops + hop) * passes + pass;   // (entry, hop, pass) bodies done by this XCD
+            if (trace && wid == 0 && lane == 0 && slot < 64) {    // (experiments) phase stamps of the XCD's first wave: previous stores drained + entries
+                unsigned long long* t = trace + ((size_t)xcd * 64 + slot) * 8;   // loaded (= loop start), loop end, stores issued, barrier passed (= the next body's start)
+                t[0] = 1ull; t[1] = tl0; t[2] = tl1; t[3] = t1; t[4] = __builtin_amdgcn_s_memtime();
                 t[5] = __builtin_amdgcn_s_memrealtime();   // (100 MHz: the shader clock under this load = d t[4] / d t[5] x 100 MHz)
             }
         }
@@ -599,23 +504,24 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
 // spmm_msweep_kernel and spmm_sell_kernel, bit for bit.
 __global__ __launch_bounds__(512) void spmm_msweep_repair_kernel(unsigned* __restrict__ cs, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                  const float* __restrict__ val, const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
-                                                                 float* __restrict__ Xtaps, size_t tapStride, int nhops, int N, int B, int uniform, float uval,
+                                                                 float* __restrict__ Xtaps, size_t tapStride, int nhops, int N, int B, int W, int uniform, float uval,
                                                                  unsigned* __restrict__ status) {
     if (ag_load(cs + kCsRepair) == 0u) return;
-    const int li = threadIdx.x & 7, grp = threadIdx.x >> 3, ngrp = blockDim.x >> 3;
+    const int W4 = W >> 2;                                  // float4 columns per row
     for (int b = blockIdx.x; b < B; b += gridDim.x)
         for (int hop = 0; hop < nhops; ++hop) {
-            const float* src = (hop == 0 ? Xin : Xtaps + (size_t)(hop - 1) * tapStride) + (size_t)b * N * 32;
-            float* dst = Xtaps + (size_t)hop * tapStride + (size_t)b * N * 32;
-            for (int p = grp; p < N; p += ngrp) {
+            const float* src = (hop == 0 ? Xin : Xtaps + (size_t)(hop - 1) * tapStride) + (size_t)b * N * W;
+            float* dst = Xtaps + (size_t)hop * tapStride + (size_t)b * N * W;
+            for (int64_t idx = threadIdx.x; idx < (int64_t)N * W4; idx += blockDim.x) {
+                const int p = (int)(idx / W4), c4 = (int)(idx - (int64_t)p * W4) * 4;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int q = rowptr[p]; q < rowptr[p + 1]; ++q) {
-                    const float4 x = *reinterpret_cast<const float4*>(src + (size_t)col[q] * 32 + li * 4);
+                    const float4 x = *reinterpret_cast<const float4*>(src + (size_t)col[q] * W + c4);
                     const float v = uniform ? 1.f : val[q];
                     acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
                 }
                 if (uniform) { acc.x *= uval; acc.y *= uval; acc.z *= uval; acc.w *= uval; }
-                *reinterpret_cast<float4*>(dst + (size_t)rowid[p] * 32 + li * 4) = acc;
+                *reinterpret_cast<float4*>(dst + (size_t)rowid[p] * W + c4) = acc;
             }
             __syncthreads();
             __threadfence();
@@ -710,13 +616,14 @@ void gf_msweep_status_reset() {   // experiments (gf_tune("spmm_status_reset", 1
 }
 
 bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W) {
-    // 128-byte rows, an image, one workgroup per CU on a 256-CU device (8 XCDs x 32 CUs x 4 SIMDs = the 128 waves per XCD of the
-    // image), 32-bit byte offsets inside a tap, enough batch entries to give every XCD one
-    return W == 32 && m.ms_ent && m.ms_rows && m.ms_sets >= 2 * kMsDepth && (m.ms_uniform || m.ms_val) && cu_count() == 256 && B >= 8 &&
-           (int64_t)N * 128 < (int64_t)kMsPad;
+    // rows of 32 columns, or of 2 / 3 / 4 slabs of 32 (the image is the same: a slab is a 128-byte column block of the row); an image; one
+    // workgroup per CU on a 256-CU device (8 XCDs x 32 CUs x 4 SIMDs = the 128 waves per XCD of the image); 32-bit byte offsets inside a
+    // tap; enough (entry, slab) pairs to give every XCD one
+    return (W == 32 || W == 64 || W == 96 || W == 128) && m.ms_ent && m.ms_rows && m.ms_sets >= 2 * kMsDepth && (m.ms_uniform || m.ms_val) &&
+           cu_count() == 256 && B * (W / 32) >= 8 && (int64_t)N * 128 < (int64_t)kMsPad;
 }
 
-int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, hipStream_t st) {
+int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st) {
     unsigned* gate = m.ms_gate + (size_t)slot_of(st) * kMsSlotWords;
     const int use_barrier = g_tune.spmm_bar;
     dim3 grid(256), block(kThreads);
@@ -727,9 +634,9 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
         GF_HIP(hipMemsetAsync(g_trace, 0, kTraceBytes, st));
         trace = g_trace;
     }
-    const bool pf = g_tune.spmm_pfd > 0;
+    const bool wide = W != 32;                  // slabs of 32 columns: {row, column} addressing, no scalar prefetch
+    const bool pf = g_tune.spmm_pfd > 0 && !wide;
     const bool deep = g_tune.spmm_depth != 5;   // ring of 10 gathers; 5: experiments
-    const bool ring = g_tune.spmm_ring != 0;    // the gathers in flight live in LDS (a whole round per wave) instead of a VGPR ring
     // A fused chain depends on its XCD barriers (hop h + 1 gathers what hop h stored): it is launched COOPERATIVELY -- the runtime starts the
     // grid only when all 256 workgroups can be resident together -- and opens with the census (kernel); the repair kernel behind it runs
     // only if the sweep abandoned the launch.  A single hop has no such dependence and takes the plain launch.
@@ -739,23 +646,21 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     const uint32_t* a_rows = m.ms_rows;
     size_t a_stride = (size_t)tapStride * 4;
     int a_nhops = nhops, a_N = N, a_B = B, a_passes = m.ms_passes, a_rounds = m.ms_rounds, a_bar = use_barrier, a_pfd = g_tune.spmm_pfd,
-        a_stag = g_tune.spmm_stag, a_nostore = g_tune.spmm_store == 3, a_census = chained ? 1 + (g_tune.spmm_census > 0 ? g_tune.spmm_census : 0) : 0;
+        a_nostore = g_tune.spmm_store == 3, a_census = chained ? 1 + (g_tune.spmm_census > 0 ? g_tune.spmm_census : 0) : 0;
     float a_uval = m.sell_uval;
     unsigned a_mask = src_mask;
+    int a_W = W;
     unsigned a_tmo = (unsigned)(g_tune.spmm_tmo_ms > 0 ? g_tune.spmm_tmo_ms : 2000) * 100000u;   // s_memrealtime ticks (100 MHz)
     void* args[] = {&a_ent, &a_val, &a_rows, &Xin, &Xtaps, &a_stride, &a_nhops, &a_N, &a_B, &a_passes, &a_rounds, &gate, &a_bar, &a_uval, &a_mask,
-                    &a_pfd, &a_stag, &a_nostore, &trace, &a_census, &a_tmo};
+                    &a_pfd, &a_nostore, &trace, &a_census, &a_tmo, &a_W};
     hipError_t lerr = hipSuccess;
-#define GF_MS(SV, UV, PV, DV, RV)                                                                                                      \
+#define GF_MS(SV, UV, PV, DV, XV)                                                                                                    \
     do {                                                                                                                               \
-        const size_t lds_ = ((RV) ? (size_t)4 * (SV) * 1024 : 0) + (size_t)4 * (SV) * 128 + 16;                                        \
-        if (lds_ > 64 * 1024) lerr = gf_grant_lds((const void*)spmm_msweep_kernel<SV, UV, PV, DV, RV>, lds_);                          \
-        if (lerr != hipSuccess) break;                                                                                                 \
         if (chained)                                                                                                                   \
-            lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV, RV>, grid, block, args, (unsigned)lds_, st); \
+            lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV, XV>, grid, block, args, 0, st); \
         else                                                                                                                           \
-            hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV, RV>), grid, block, lds_, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
-                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_stag, a_nostore, trace, a_census, a_tmo);     \
+            hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV, XV>), grid, block, 0, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
+                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_nostore, trace, a_census, a_tmo, a_W); \
     } while (0)
 #define GF_MS_P(SV, UV, DV)                            \
     do {                                              \
@@ -764,20 +669,20 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     } while (0)
 #define GF_MS_D(SV, UV)                               \
     do {                                              \
-        if (ring) GF_MS(SV, UV, 0, SV, 1);            \
+        if (wide) GF_MS(SV, UV, 0, 10, 1);            \
         else if (deep) GF_MS_P(SV, UV, 10);           \
         else GF_MS_P(SV, UV, 5);                      \
     } while (0)
     if (m.ms_uniform) {
         switch (m.ms_sets) {
-            case 10: if (ring) GF_MS(10, 1, 0, 10, 1); else GF_MS_P(10, 1, 5); break;
+            case 10: if (wide) GF_MS(10, 1, 0, 5, 1); else GF_MS_P(10, 1, 5); break;
             case 15: GF_MS_D(15, 1); break;
             case 20: GF_MS_D(20, 1); break;
             default: GF_MS_D(25, 1); break;
         }
     } else {
         switch (m.ms_sets) {
-            case 10: if (ring) GF_MS(10, 0, 0, 10, 1); else GF_MS_P(10, 0, 5); break;
+            case 10: if (wide) GF_MS(10, 0, 0, 5, 1); else GF_MS_P(10, 0, 5); break;
             case 15: GF_MS_D(15, 0); break;
             case 20: GF_MS_D(20, 0); break;
             default: GF_MS_D(25, 0); break;
@@ -790,7 +695,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     GF_LAUNCH_CHECK("spmm_msweep_kernel");
     if (chained && !a_nostore && src_mask == 0xffffffffu) {
         hipLaunchKernelGGL(spmm_msweep_repair_kernel, dim3((unsigned)(B < 512 ? B : 512)), dim3(512), 0, st, gate + kMsCensusWord, m.rowptr, m.col, m.val, m.rowid,
-                           Xin, Xtaps, (size_t)tapStride, nhops, N, B, m.ms_uniform, m.sell_uval, g_status.load());
+                           Xin, Xtaps, (size_t)tapStride, nhops, N, B, W, m.ms_uniform, m.sell_uval, g_status.load());
         GF_LAUNCH_CHECK("spmm_msweep_repair_kernel");
     }
     return GF_OK;

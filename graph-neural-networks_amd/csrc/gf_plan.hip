@@ -68,12 +68,10 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_depth")) g_tune.spmm_depth = value;
     else if (!strcmp(key, "spmm_fuse")) g_tune.spmm_fuse = value;
     else if (!strcmp(key, "spmm_trace")) g_tune.spmm_trace = value;
-    else if (!strcmp(key, "spmm_ring")) g_tune.spmm_ring = value;
     else if (!strcmp(key, "spmm_census")) g_tune.spmm_census = value;
     else if (!strcmp(key, "spmm_tmo_ms")) g_tune.spmm_tmo_ms = value;
     else if (!strcmp(key, "spmm_status_reset")) gf_msweep_status_reset();
     else if (!strcmp(key, "spmm_passes")) g_tune.spmm_passes = value;
-    else if (!strcmp(key, "spmm_stag")) g_tune.spmm_stag = value;
     else if (!strcmp(key, "spmm_srcmask")) g_tune.spmm_srcmask = value;
     else if (!strcmp(key, "spmm_slack")) g_tune.spmm_slack = value;
     else if (!strcmp(key, "spmm_xcd")) g_tune.spmm_xcd = value;

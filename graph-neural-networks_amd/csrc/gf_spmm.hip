@@ -507,13 +507,13 @@ extern "C" int gf_spmm_hop(const gf_plan* plan, int32_t op, const float* Xin, fl
 
     const bool fits24 = (int64_t)N < (1 << 24) && (int64_t)N * W < (int64_t)INT32_MAX;  // __umul24 offsets
     if (!g_tune.spmm_generic && fits24) {
-        if (g_tune.spmm_algo == 0 && N >= kMsDefaultMinNodes && gf_msweep_applicable(m, N, B, W)) return gf_msweep_launch(m, Xin, Xout, 0, 1, N, B, st);
+        if (g_tune.spmm_algo == 0 && N >= kMsDefaultMinNodes && gf_msweep_applicable(m, N, B, W)) return gf_msweep_launch(m, Xin, Xout, 0, 1, N, B, W, st);
         if (g_tune.spmm_algo == 5) {   // experiments: the MFMA sweep or an error (never a silent fallback)
             if (!gf_msweep_applicable(m, N, B, W)) {
                 gf_set_error("gf_spmm_hop: spmm_algo = 5 but the MFMA sweep does not apply (W = %d, B = %d, N = %d, fill = %.3f)", W, B, N, m.ms_fill);
                 return GF_ERR_UNSUPPORTED;
             }
-            return gf_msweep_launch(m, Xin, Xout, 0, 1, N, B, st);
+            return gf_msweep_launch(m, Xin, Xout, 0, 1, N, B, W, st);
         }
         if (g_tune.spmm_algo != 1) {
             switch (W) {
@@ -577,7 +577,7 @@ extern "C" int gf_khop(const gf_plan* const* plans, int32_t E, int32_t op, float
         // the MFMA sweep runs the K - 1 hops of an edge feature in ONE launch, batch entry by batch entry (gf_msweep.hip)
         const gf_csr_dev& m = plans[e]->mat[op];
         if (K > 2 && g_tune.spmm_fuse && gf_hop_uses_msweep(plans[e], op, B, W) && gf_msweep_fusion_allowed()) {
-            const int rc = gf_msweep_launch(m, Z, Z + (int64_t)(1 + e * (K - 1)) * tap, tap, K - 1, plans[e]->n, B, gf_stream(stream));
+            const int rc = gf_msweep_launch(m, Z, Z + (int64_t)(1 + e * (K - 1)) * tap, tap, K - 1, plans[e]->n, B, W, gf_stream(stream));
             if (rc != GF_OK) return rc;
             continue;
         }

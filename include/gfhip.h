@@ -246,8 +246,9 @@ int gf_lsigf_backward_ex(const gf_plan* const* plans, int32_t E, const float* dy
 
 /* ---- measurement hook: run ONE hop `iters` times on `stream` bracketed by HIP events on that stream and return
  * the average milliseconds per launch (bench.py's roofline leg; hipEvents see the launch stream, torch events may not). */
-/* which kernel a node-major hop of this shape runs: 1 = spmm_msweep_kernel (the MFMA source sweep, gf_msweep.hip: W = 32, graphs from 49 152
- * nodes on whose row groups balance, B >= 8; gf_khop then runs the K-1 hops of an edge feature in ONE launch), 0 = spmm_sell_kernel / the others */
+/* which kernel a node-major hop of this shape runs: 1 = spmm_msweep_kernel (the MFMA source sweep, gf_msweep.hip: W = 32 / 64 / 96 / 128 -- wide
+ * rows as slabs of 32 columns --, graphs from 49 152 nodes on whose row groups balance, B * W / 32 >= 8; gf_khop then runs the K-1 hops of an
+ * edge feature in ONE launch), 0 = spmm_sell_kernel / the others */
 int gf_spmm_hop_kernel(const gf_plan* plan, int32_t op, int32_t B, int32_t W);
 /* State of the fused chains of this process (no reference counterpart).  A fused launch opens with a census of its workgroups (32 on each of
  * 8 XCCs, all resident); a launch whose census fails, or that runs into its time limit, stores nothing, and the repair kernel queued behind it
@@ -267,7 +268,7 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * "spmm_fuse" (0/1 the K-1 hops of gf_khop in one launch), "spmm_bar" (0/1 XCD barrier between batch entries too), "spmm_pfd" (scalar
  * prefetch lead in loop iterations, 0 = off), "spmm_depth" (0 = 10 gathers in flight | 5), "spmm_slack" / "spmm_passes" (image: rounds
  * beyond the mean group length in percent, passes allowed per batch entry; read by gf_plan_create), timing-only: "spmm_srcmask",
- * "spmm_stag", "spmm_trace"; tests of the abandon-and-repair path: "spmm_census" (1 = census called bad | 2 = one workgroup claims the next XCC |
+ * "spmm_trace"; tests of the abandon-and-repair path: "spmm_census" (1 = census called bad | 2 = one workgroup claims the next XCC |
  * 3 = one workgroup never arrives), "spmm_tmo_ms" (time limit of census / barriers, 0 = 2000), "spmm_status_reset"; "spmm_xcd" (0/1),
  * "spmm_group" (0/1 locality groups in the row schedule of graphs with N >= 32768; read by gf_plan_create),
  * "spmm_pf" (workgroups per tile prefetching the next gather panel, -1 = heuristic, 0 = off), "spmm_ucap" (0 | 8 | 16 gathers in flight per lane), "spmm_load" (0 = plain | 1 = non-temporal gather loads),

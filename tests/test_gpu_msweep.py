@@ -27,7 +27,7 @@ def tune(**kw):
 @pytest.fixture
 def knobs():
     yield tune
-    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=16, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1, spmm_ring=0)
+    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=16, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1)
 
 
 def hop(plans, op, Xt, algo, **kw):
@@ -267,27 +267,34 @@ def test_fused_chain_beside_kernels_that_hold_compute_units(knobs):
     assert chain_status() == (0, 1)
 
 
-@pytest.mark.parametrize("n,deg,B,K,directed,weighted", [
-    (100000, 5, 24, 5, False, False),     # config 4's shape: 25 sets per wave = 25 gathers in flight per wave
-    (100000, 5, 9, 3, False, True),       # weighted: value buffers
-    (40000, 5, 17, 3, True, False),       # 10 sets
-    (60000, 4, 16, 4, False, False),      # 15 sets
-    (81000, 3, 8, 3, False, True),        # 20 sets, weighted
-    (130000, 3, 9, 3, False, False),      # two passes per batch entry
+@pytest.mark.parametrize("n,deg,B,W,K,directed,weighted", [
+    (100000, 5, 8, 64, 3, False, False),      # two slabs per entry: 16 (entry, slab) chains on 8 XCDs
+    (60000, 4, 5, 64, 4, True, True),         # B < 8 but B * W / 32 >= 8; directed, weighted, 15 sets
+    (52000, 5, 3, 96, 3, False, False),       # three slabs (a row is 384 bytes: not a power of two)
+    (81000, 3, 4, 128, 3, False, True),       # four slabs, 20 sets, weighted
+    (130000, 3, 5, 64, 3, False, False),      # two passes per (entry, slab)
 ])
-def test_msweep_lds_ring_is_bitwise_sell(n, deg, B, K, directed, weighted, knobs):
-    """spmm_ring = 1: the gathers in flight land in LDS (LDS-DMA) instead of a VGPR ring -- a whole round per wave in flight.  Same image, same
-    accumulators, same order of additions: single hops and the fused chain must reproduce SELL-8 bit for bit, both orientations."""
-    A = er(n, deg, seed=n + B + K, directed=directed, weighted=weighted)
+def test_msweep_wide_rows_are_slabs_of_the_same_image(n, deg, B, W, K, directed, weighted, knobs):
+    """W = 64 / 96 / 128 (the reference's layers are any width: graphML.py:2086-2107): a row is W / 32 slabs of 32 columns, the sweep runs the
+    SAME image once per (batch entry, slab) with {row, column} addressing (buffer resource with the row as stride).  Single hops and the fused
+    chain against SELL-8 of the same width, bit for bit, both orientations; the default configuration must pick the sweep."""
+    A = er(n, deg, seed=n + B + W, directed=directed, weighted=weighted)
     gso = SparseGSO([A])
     plans = gso.plans(DEV)
-    x0 = torch.randn(B, n, 32, device=DEV)
-    for op in (0, 1):
+    L = _lib.lib()
+    x0 = torch.randn(B, n, W, device=DEV)
+    for op, M in ((0, A.T.tocsr()), (1, A)):
         ref1 = hop(plans, op, x0, 3)
-        for rep in range(2):
-            got1 = hop(plans, op, x0, 5, spmm_ring=1, spmm_bar=rep)
-            assert torch.equal(got1, ref1), (op, rep, int((got1 != ref1).sum()), float((got1 - ref1).abs().max()))
+        want = M.astype(np.float64) @ x0[0].cpu().numpy().astype(np.float64)
+        assert relerr(ref1[0].cpu().numpy(), want) < 2e-6
+        got1 = hop(plans, op, x0, 5)
+        assert torch.equal(got1, ref1), (op, int((got1 != ref1).sum()), float((got1 - ref1).abs().max()))
         ref = khop_chain(plans, x0, K, op, spmm_algo=3)
-        for rep in range(2):
-            got = khop_chain(plans, x0, K, op, spmm_algo=5, spmm_ring=1, spmm_fuse=1, spmm_bar=0)
-            assert torch.equal(got, ref), (op, rep, int((got != ref).sum()))
+        for kw in (dict(spmm_algo=0, spmm_fuse=1), dict(spmm_algo=0, spmm_fuse=0), dict(spmm_algo=5, spmm_fuse=1, spmm_bar=1)):
+            got = khop_chain(plans, x0, K, op, **kw)
+            assert L.gf_spmm_hop_kernel(plans[0], op, B, W) == 1
+            assert torch.equal(got, ref), (op, kw, int((got != ref).sum()))
+    # the abandon-and-repair path at this width
+    tune(spmm_status_reset=1)
+    got = khop_chain(plans, x0, K, 0, spmm_algo=0, spmm_fuse=1, spmm_census=1)
+    assert torch.equal(got, khop_chain(plans, x0, K, 0, spmm_algo=3, spmm_census=0)) and chain_status()[0] == 1

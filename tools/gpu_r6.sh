@@ -3,6 +3,25 @@
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp GFHIP_EXPERIMENTS=1
 S=$1; O=gpurun_out/r06_$S; mkdir -p $O
 LIBD=$PWD/graph-neural-networks_amd/alegnn_amd
+pmc() {  # pmc <tag> <counters...> -- <hop_probe args>: one rocprofv3 pass, per-kernel averages (rows per launch are checked: a pass that died early says so)
+  local tag=$1; shift; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
+  rm -rf $O/pm; timeout 300 rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d $O/pm -o pmc -- python tools/hop_probe.py "$@" > $O/pm_$tag.log 2>&1; local rc=$?
+  python3 - "$O" "$tag" "$rc" <<'PY'
+import csv, glob, sys, collections
+O, tag, rc = sys.argv[1:4]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"{O}/pm/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r["Kernel_Name"]
+        k = "msweep" if "msweep_kernel" in kn else ("sell" if "spmm_sell" in kn else None)
+        if k: agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+n = {len(v) for v in agg.values()}
+print(f"{tag:10s} rocprofv3 exit {rc}; launches per counter: {sorted(n)}" + ("" if len(n) == 1 else "  <-- UNEVEN: pass incomplete"))
+for (k, c), v in sorted(agg.items()):
+    print(f"{tag:10s} {k:7s} {c:42s} {sum(v)/len(v):18.0f}  ({len(v)} launches)")
+PY
+  rm -rf $O/pm
+}
 case $S in
 a)  # where do the 12 ns per gather instruction go?  timing-only variants of the loop (no MFMAs / no DPP / global_load / half the MFMAs), each in
     # four regimes: as shipped; no prefetch; real sources without stores; sources confined to 1 MB (every gather hits L2) without and with stores
@@ -38,5 +57,20 @@ d)  # near scalar prefetch at a controlled rate: one row every k-th step (k = 1 
     V="v:spmm_algo=0+spmm_pfd=16"; for l in 1 2 3 4 6 8 12 16 0; do V="$V v:spmm_pfd=$l"; done
     timeout 300 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "khop chain" | sed 's/bitwise.*//' | tee -a $O/khop.log
   done
+  ;;
+e)  # counters: vector-cache requests in flight per CU with 10 gathers per wave in VGPRs vs 25 per wave in LDS (the window is not the limit)
+  for v in "d10:spmm_algo=0+spmm_ring=0+spmm_pfd=0" "ring25:spmm_algo=0+spmm_ring=1+spmm_pfd=0" "d5:spmm_algo=0+spmm_ring=0+spmm_depth=5+spmm_pfd=0"; do
+    tag=${v%%:*}; var=${v#*:}
+    pmc ${tag}_tcp TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum -- cfg4 3 v:$var | tee -a $O/pmc.log
+    pmc ${tag}_l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- cfg4 3 v:$var | tee -a $O/pmc.log
+    pmc ${tag}_ta TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum -- cfg4 3 v:$var | tee -a $O/pmc.log
+    pmc ${tag}_grbm GRBM_GUI_ACTIVE GRBM_COUNT -- cfg4 3 v:$var | tee -a $O/pmc.log
+  done
+  ;;
+f)  # wide rows, monotonic barrier, zero-in-store: msweep suite, then time (cfg4 chain; W = 64 against SELL-8)
+  timeout 1500 python -m pytest tests/test_gpu_msweep.py -x -q 2>&1 | tail -15 | tee $O/pytest_msweep.log
+  timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0 v:spmm_algo=3 v:spmm_algo=0 v:spmm_algo=0+spmm_fuse=0 v:spmm_fuse=1 2>&1 | grep "khop chain" | tee $O/khop.log
+  timeout 300 python tools/msweep_trace.py 2>&1 | tail -12 | tee $O/trace_default.log
+  PROBE_W=64 PROBE_B=64 timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=3 v:spmm_algo=0 v:spmm_algo=3 v:spmm_algo=0 2>&1 | grep "khop chain" | tee $O/khop_w64.log
   ;;
 esac

@@ -50,6 +50,7 @@ else:
     layer = w.module if wl["kind"] == "filter" else w.module.GFL[3]
     B, N = wl["B"], layer.N
     W = wl["G"] if wl["kind"] == "filter" else wl["dimF"][1]
+    W = int(os.environ.get("PROBE_W", W))      # same graph, another row width (the hop does not depend on the filter bank)
     K = wl["K"] if wl["kind"] == "filter" else wl["K"][1]
     plans = layer._gso.plans(dev)
     if L.gf_lsigf_pipeline(plans, 1, W, W, K) == 2:

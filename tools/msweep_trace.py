@@ -30,7 +30,9 @@ n0 = int((raw[0, :, 0] > 0).sum())
 if n0 > 1 and raw[0, n0 - 1, 5] > raw[0, 0, 5]:   # s_memrealtime runs at 100 MHz: the s_memtime tick rate under this load
     print(f"s_memtime ticks per microsecond (XCD 0, {n0} slots): {(raw[0, n0 - 1, 4] - raw[0, 0, 4]) / (raw[0, n0 - 1, 5] - raw[0, 0, 5]) * 100.0:.1f}")
 t = buf.astype(np.float64) / 2200.0         # s_memtime ticks = shader clocks (~2.2 GHz under this load) -> microseconds
-ok = t[:, :, 0] > 0
+ok = buf[:, :, 0] > 0
+t[:, 1:, 0] = t[:, :-1, 4]                  # a body starts where the previous one's barrier opened; the first one at its loop start (its set-up is not stamped)
+t[:, 0, 0] = t[:, 0, 1]
 names = ["start->loop (zero, drain, entry loads)", "round loop", "store issue", "barrier"]
 d = np.stack([t[:, :, i + 1] - t[:, :, i] for i in range(4)], -1)
 print("knobs:", " ".join(sys.argv[1:]))
