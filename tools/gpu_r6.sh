@@ -73,4 +73,11 @@ f)  # wide rows, monotonic barrier, zero-in-store: msweep suite, then time (cfg4
   timeout 300 python tools/msweep_trace.py 2>&1 | tail -12 | tee $O/trace_default.log
   PROBE_W=64 PROBE_B=64 timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=3 v:spmm_algo=0 v:spmm_algo=3 v:spmm_algo=0 2>&1 | grep "khop chain" | tee $O/khop_w64.log
   ;;
+g)  # does a NEAR scalar prefetch allocate in L2?  fabric read requests with one row per second step, lead 3 iterations (variant pfk2) vs no prefetch
+  export GFHIP_LIB=$LIBD/libgfhip_pfk2.so
+  pmc pf0_l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- cfg4 3 v:spmm_algo=0+spmm_pfd=0 | tee -a $O/pmc.log
+  pmc pf3_l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- cfg4 3 v:spmm_algo=0+spmm_pfd=3 | tee -a $O/pmc.log
+  pmc pf3_tcp TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum -- cfg4 3 v:spmm_algo=0+spmm_pfd=3 | tee -a $O/pmc.log
+  unset GFHIP_LIB
+  ;;
 esac
