@@ -64,8 +64,9 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 #ifndef GF_MS_EXP      // experiments (make msvariant; TIMING ONLY, results wrong): bit 0 = no MFMAs in the loop, bit 1 = plain moves instead of the DPP
 #define GF_MS_EXP 0    // broadcasts (both change the addresses: not a valid timing), bit 3 = two of the four MFMAs (round 6's global_load variant, bit 2: same time as buffer_load)
 #endif
-#ifndef GF_MS_PFK      // scalar prefetch: one source row (two s_loads) every GF_MS_PFK-th step of a wave
-#define GF_MS_PFK 1
+#ifndef GF_MS_PFP      // scalar prefetch: GF_MS_PFP source rows (two s_loads each) per GF_MS_PFQ steps of a wave
+#define GF_MS_PFP 1
+#define GF_MS_PFQ 1
 #endif
 #define GF_MS_STR2(x) #x
 #define GF_MS_STR(x) GF_MS_STR2(x)
@@ -76,7 +77,8 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 .set MS_GATHER_NT, GF_MS_NT_VALUE
 .set MS_STORE_PLAIN, GF_MS_STPLAIN_VALUE
 .set MS_EXP, GF_MS_EXP_VALUE
-.set MS_PFK, GF_MS_PFK_VALUE
+.set MS_PFP, GF_MS_PFP_VALUE
+.set MS_PFQ, GF_MS_PFQ_VALUE
 .set MS_R0, 24
 .macro MS_SETMAP D
   .set MS_A0, 24 + 4*(\D)
@@ -274,9 +276,9 @@ MS_LOOP_\uid:
     .endif
     MS_MFMA (MS_N % (\S)), 2, (MS_N % (\D))
     MS_MFMA (MS_N % (\S)), 3, (MS_N % (\D))
-    .if (\PF) && ((MS_N % MS_PFK) == 0)
-      s_load_dword \sdummy, \xptr, \spfc offset:(MS_N/MS_PFK)*0x4000
-      s_load_dword \sdummy, \xptr, \spfc offset:(MS_N/MS_PFK)*0x4000+0x40
+    .if (\PF) && ((((MS_N+1)*MS_PFP)/MS_PFQ) > ((MS_N*MS_PFP)/MS_PFQ))
+      s_load_dword \sdummy, \xptr, \spfc offset:((MS_N*MS_PFP)/MS_PFQ)*0x4000
+      s_load_dword \sdummy, \xptr, \spfc offset:((MS_N*MS_PFP)/MS_PFQ)*0x4000+0x40
     .endif
     MS_ISSUE MS_SP, (MS_N % (\D)), (MS_N & 1), (MS_RHO & 1), MS_RHO, \S, \UNI, \rs, \re, \rv, \vfg, \vslot, \vevoff, \smask, \scur, \xptr
     .set MS_N, MS_N+1
@@ -327,7 +329,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
     __shared__ unsigned s_ctl[4];                           // census result {XCC, rank, abandoned}, [3] = a barrier timed out
     asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN)
-                 "\n\t.set GF_MS_EXP_VALUE, " GF_MS_STR(GF_MS_EXP) "\n\t.set GF_MS_PFK_VALUE, " GF_MS_STR(GF_MS_PFK));
+                 "\n\t.set GF_MS_EXP_VALUE, " GF_MS_STR(GF_MS_EXP) "\n\t.set GF_MS_PFP_VALUE, " GF_MS_STR(GF_MS_PFP) "\n\t.set GF_MS_PFQ_VALUE, " GF_MS_STR(GF_MS_PFQ));
     asm volatile(GF_MS_MACROS);
     const unsigned lane = threadIdx.x & 63;
     const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

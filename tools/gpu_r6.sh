@@ -80,4 +80,16 @@ g)  # does a NEAR scalar prefetch allocate in L2?  fabric read requests with one
   pmc pf3_tcp TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum -- cfg4 3 v:spmm_algo=0+spmm_pfd=3 | tee -a $O/pmc.log
   unset GFHIP_LIB
   ;;
+h)  # the cooperative chain beside RCCL's kernels / a CU-holding kernel on another stream
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/coop_beside_rccl.py 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -8 | tee $O/coop_beside_rccl.log
+  ;;
+i)  # near scalar prefetch at p rows per q steps (12.7 M rows per hop need 0.74 rows per step and wave; a wave may have 15 scalar loads outstanding)
+  for lib in "" pf12 pf23 pf34 pf45 pf56; do
+    if [ -n "$lib" ]; then export GFHIP_LIB=$LIBD/libgfhip_$lib.so; else unset GFHIP_LIB; fi
+    echo "== lib=${lib:-shipped}" | tee -a $O/khop.log
+    V="v:spmm_algo=0+spmm_pfd=16"; for l in 1 2 3 4 5 16 0; do V="$V v:spmm_pfd=$l"; done
+    timeout 300 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "khop chain" | sed 's/bitwise.*//' | tee -a $O/khop.log
+  done
+  unset GFHIP_LIB
+  ;;
 esac
