@@ -64,9 +64,9 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 #ifndef GF_MS_EXP      // experiments (make msvariant; TIMING ONLY, results wrong): bit 0 = no MFMAs in the loop, bit 1 = plain moves instead of the DPP
 #define GF_MS_EXP 0    // broadcasts (both change the addresses: not a valid timing), bit 3 = two of the four MFMAs (round 6's global_load variant, bit 2: same time as buffer_load)
 #endif
-#ifndef GF_MS_PFP      // scalar prefetch: GF_MS_PFP source rows (two s_loads each) per GF_MS_PFQ steps of a wave
-#define GF_MS_PFP 1
-#define GF_MS_PFQ 1
+#ifndef GF_MS_PFP      // scalar prefetch: GF_MS_PFP source rows (two s_loads each) per GF_MS_PFQ steps of a wave.  3 per 4: config 4's sweep needs 0.74 rows per
+#define GF_MS_PFP 3    // step and wave (N / (rounds x 128 waves x 25 steps)) and a wave can keep 15 scalar loads outstanding: ~1.8 per step at the ~850 clocks a
+#define GF_MS_PFQ 4    // first touch takes -- 2 per step (round 5) ran into that limit and held the wave's whole instruction stream back
 #endif
 #define GF_MS_STR2(x) #x
 #define GF_MS_STR(x) GF_MS_STR2(x)

@@ -92,4 +92,11 @@ i)  # near scalar prefetch at p rows per q steps (12.7 M rows per hop need 0.74 
   done
   unset GFHIP_LIB
   ;;
+j)  # A/B, interleaved, separate processes: round 5's prefetch (2 s_loads per step, lead 16: variant pfold + spmm_pfd=16) against 3 rows per 4 steps, lead 3 (default)
+  for rep in 1 2 3 4; do
+    GFHIP_LIB=$LIBD/libgfhip_pfold.so timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0+spmm_pfd=16 v:spmm_pfd=16 2>&1 | grep "khop chain" | sed 's/^/old  /;s/bitwise.*//' | tee -a $O/ab.log
+    timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0+spmm_pfd=3 v:spmm_pfd=3 2>&1 | grep "khop chain" | sed 's/^/new  /;s/bitwise.*//' | tee -a $O/ab.log
+  done
+  timeout 1200 python -m pytest tests/test_gpu_msweep.py -x -q 2>&1 | tail -3 | tee $O/pytest_msweep.log
+  ;;
 esac
