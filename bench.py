@@ -386,6 +386,11 @@ def pmc_traffic(workload, kernel):
     if pm is None:
         return None, None
     src["kind"] = TRAFFIC_KIND
+    if pm.get("calibration"):                  # (round 6) the kernel's scalar prefetch splits a row's fetch into two 64-byte requests: calibrated as the guide asks
+        src["calibration"] = pm["calibration"]
+        src["bytes_by_rule_uncalibrated"] = pm.get("hbm_bytes_per_launch_by_rule")
+    if pm.get("passes_complete") is False:
+        return None, dict(src, warning=pm.get("warning"))
     return (pm.get("hbm_bytes_per_launch") if src["matches_running_sources"] else None), src
 
 

@@ -99,4 +99,10 @@ j)  # A/B, interleaved, separate processes: round 5's prefetch (2 s_loads per st
   done
   timeout 1200 python -m pytest tests/test_gpu_msweep.py -x -q 2>&1 | tail -3 | tee $O/pytest_msweep.log
   ;;
+l)  # image slack (rounds beyond the mean group length) x prefetch lead, now that the prefetch is near: a looser image keeps a row's uses closer together
+  for sl in 5 10 15 20 30; do
+    echo "== slack $sl" | tee -a $O/khop.log
+    timeout 300 python tools/hop_probe.py cfg4 10 spmm_slack=$sl v:spmm_algo=0+spmm_pfd=3 v:spmm_pfd=2 v:spmm_pfd=3 v:spmm_pfd=4 v:spmm_pfd=0 2>&1 | grep "khop chain" | sed 's/bitwise.*//' | tee -a $O/khop.log
+  done
+  ;;
 esac
