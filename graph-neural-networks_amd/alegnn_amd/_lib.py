@@ -72,6 +72,7 @@ _SIGNATURES = {
     "gf_nvgf_fold_taps": (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int64, _i32, _i32, _vp]),
     "gf_debug_msweep_trace": (_c.c_int, [_vp]),
     "gf_spmm_hop_kernel": (_c.c_int, [_vp, _i32, _i32, _i32]),
+    "gf_debug_msweep_info": (_c.c_int, [_vp, _i32, _c.POINTER(_i32)]),
     "gf_msweep_status": (_c.c_int, [_c.POINTER(_c.c_uint32), _c.POINTER(_i32)]),
     "gf_time_khop": (_c.c_int, [_c.POINTER(_vp), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _c.POINTER(_c.c_float)]),
     "gf_time_spmm_hop": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _c.POINTER(_c.c_float)]),

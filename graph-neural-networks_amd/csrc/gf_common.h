@@ -71,10 +71,13 @@ struct gf_csr_dev {
     // MSWEEP image (gf_msweep_image.h, round 5): the source sweep with the partial sums of a batch entry in the XCD's registers and an
     // fp32 MFMA as scatter-accumulate (spmm_msweep_kernel); built for graphs whose gather panel does not fit an XCD's L2
     int32_t ms_sets = 0, ms_passes = 0, ms_rounds = 0;   // 0 = no image
+    int32_t ms_hub_rows = 0, ms_hub_split_rows = 0, ms_hub_limit = 0, ms_hub_split = 0;   // rows computed outside the groups (gf_msweep_image.h); rows longer than ms_hub_split are summed as 32 partial chains
+    int64_t ms_hub_entries = 0;
     int32_t ms_uniform = 0;
     uint32_t* ms_ent = nullptr;     // [passes][128 waves][rounds + 2][8 positions][sets rounded up to 4]
     float* ms_val = nullptr;        // same shape (weighted GSOs only)
     uint32_t* ms_rows = nullptr;    // [passes][128 waves][sets][32]  output byte offsets
+    uint32_t* ms_hub = nullptr;     // hub rows (rows too long for a group): {block offsets [passes * 128 + 1], total words, blocks, (weighted) values}; nullptr = none
     uint32_t* ms_gate = nullptr;    // XCD barrier counters, one slot per launch in rotation
     double ms_fill = 0.0;
     // Panel (LDS-resident) SpMM image, built when N <= kPanelMaxNodes.  Work unit = OCTET (8 consecutive rows = one 128-byte

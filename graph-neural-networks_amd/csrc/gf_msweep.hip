@@ -314,14 +314,19 @@ MS_LOOP_\uid:
         GF_MS_A8(19), GF_MS_A8(20), GF_MS_A8(21), GF_MS_A8(22), GF_MS_A8(23), GF_MS_A8(24), "a250", "a251", "a252", "a253",        \
         "a254", "a255"
 
-template <int S, int UNI, int PF, int D, int IDX>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int S, int UNI, int PF, int D, int IDX, int HUB>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restrict__ val, const uint32_t* __restrict__ rows,
                         const float* __restrict__ Xin, float* __restrict__ Xtaps, size_t tapStrideBytes, int nhops, int N, int B, int passes,
                         int rounds, unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask, int pf_lead,
-                        int nostore, unsigned long long* __restrict__ trace, int census, unsigned tmo_ticks, int W) {
+                        int nostore, unsigned long long* __restrict__ trace, int census, unsigned tmo_ticks, int W,
+                        const uint32_t* __restrict__ hubpack) {
     constexpr int U = 2;                                    // rounds per loop iteration (the two entry buffers alternate by round parity)
     static_assert(IDX == 0 || PF == 0, "wide rows: no scalar prefetch");
+    static_assert(HUB == 0 || IDX == 0, "hub rows: 32-column rows only");
     static_assert((U * S) % D == 0 && D < S && S <= kMsMaxSets && S <= 32,
                   "ring slots are static: 2 S steps are a multiple of the depth; a round's buffer is reloaded (for the round two later) behind "
                   "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
@@ -436,6 +441,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             unsigned spfr = (unsigned)pf_lead * (U * chunkBytes) + wid * 128u, spfc = spfr < smaxpf ? spfr : smaxpf, sdummy;
             const char* xptr = src + (size_t)b * entryBytes;
             unsigned long long tl0, tl1;
+            if constexpr (HUB) asm volatile("MS_ZERO %0" ::"n"(S) : GF_MS_CLOBBERS);   // (the hub phase below is compiler code: it may have used any register)
             if constexpr (PF) {
                 asm volatile("MS_BODY %20, %21, %22, 1, %23, %24, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
                              : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy), "=&s"(tl0), "=&s"(tl1)
@@ -449,6 +455,87 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                              : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fgs), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
                                "s"(0), "n"(S), "n"(UNI), "n"(IDX), "n"(D), "n"(U)
                              : GF_MS_CLOBBERS);
+            }
+            if constexpr (HUB) {
+                // Hub rows (gf_msweep_image.h): this wave's quads of 4 octets x 8 positions -- rows too long for a group, each an ascending-column
+                // fmaf chain of its own (a split quad: 32 partial chains of ONE row, added in a fixed tree).  Compiler code between the asm
+                // bodies; gathers and stores through the same buffer resources (range check: gaps and missing rows cost no memory request).
+                // hubpack = {offsets of the passes x 128 waves' blocks [nw + 1], total words, the blocks, (weighted: the values, same shape)}
+                const int nw = passes * kMsWavesPerXcd;
+                const uint32_t* hw = hubpack + nw + 2;
+                const uint32_t hwords = hubpack[nw + 1];
+                uint32_t at = hubpack[pw];
+                const uint32_t end = hubpack[pw + 1];
+                // (per-lane values of this phase are re-derived here from an opaque copy of the lane id: hoisted out of the entry / hop loops they
+                //  would be live ACROSS the asm body, where the compiler has only v0-v23, and spill to scratch)
+                unsigned lh = lane;
+                asm volatile("; hub phase" : "+v"(lh));
+                const unsigned fgh = (lh & 7u) * 16u, p4 = (lh >> 3) * 4u;
+                while (at < end) {
+                    const int Lq = (int)hw[at];
+                    const bool split = hw[at + 1] != 0u;
+                    const u32x4 ro4 = *reinterpret_cast<const u32x4*>(hw + at + 4 + p4);
+                    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+                    // two steps in flight: the gathers of step j + 1 are issued before the sums of step j, the entries of step j + 2 before those
+                    // (loads return in order, so an entry word has always arrived by the time its gathers are due; the stream is padded past the
+                    // last quad, and what is read beyond a quad's end is gathered and dropped)
+                    const uint32_t* ep = hw + at + 36 + p4;
+#define GF_HUB_LD(E, V, P)                                                                                             \
+    do {                                                                                                               \
+        E = *reinterpret_cast<const u32x4*>(P);                                                                        \
+        if (!UNI) V = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>((P) + hwords));                   \
+    } while (0)
+#define GF_HUB_GATHER(X, E)                                                                                            \
+    do {                                                                                                               \
+        X[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, E.x + fgh, 0, 0));                  \
+        X[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, E.y + fgh, 0, 0));                  \
+        X[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, E.z + fgh, 0, 0));                  \
+        X[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, E.w + fgh, 0, 0));                  \
+    } while (0)
+#define GF_HUB_FMA1(A, X, V) A.x = __builtin_fmaf(V, X.x, A.x), A.y = __builtin_fmaf(V, X.y, A.y), A.z = __builtin_fmaf(V, X.z, A.z), A.w = __builtin_fmaf(V, X.w, A.w)
+#define GF_HUB_SUM(X, V) GF_HUB_FMA1(a0, X[0], V.x), GF_HUB_FMA1(a1, X[1], V.y), GF_HUB_FMA1(a2, X[2], V.z), GF_HUB_FMA1(a3, X[3], V.w)
+                    u32x4 eA, eB;
+                    f32x4 vA = {1.f, 1.f, 1.f, 1.f}, vB = vA, vC = vA, vD = vA, xA[4], xB[4];
+                    GF_HUB_LD(eA, vA, ep);
+                    GF_HUB_LD(eB, vB, ep + 32);
+                    GF_HUB_GATHER(xA, eA);
+                    GF_HUB_LD(eA, vC, ep + 64);
+                    int j = 0;
+                    for (; j + 1 < Lq; j += 2) {            // steps j (xA, vA) and j + 1 (xB, vB); eB = entries of j + 1, eA = entries of j + 2
+                        GF_HUB_GATHER(xB, eB);
+                        GF_HUB_LD(eB, vD, ep + 96);
+                        GF_HUB_SUM(xA, vA);
+                        GF_HUB_GATHER(xA, eA);
+                        GF_HUB_LD(eA, vA, ep + 128);
+                        GF_HUB_SUM(xB, vB);
+                        vB = vD;
+                        { const f32x4 t = vA; vA = vC; vC = t; }
+                        ep += 64;
+                    }
+                    if (j < Lq) GF_HUB_SUM(xA, vA);
+#undef GF_HUB_SUM
+#undef GF_HUB_FMA1
+#undef GF_HUB_GATHER
+#undef GF_HUB_LD
+                    if (split) {                            // octets in order, then the eight positions by xor 1, 2, 4 (lanes 8 p + fg: xor 8, 16, 32)
+                        f32x4 t = ((a0 + a1) + a2) + a3;
+#pragma unroll
+                        for (int m = 8; m < 64; m <<= 1) {
+                            f32x4 o;
+                            o.x = __shfl_xor(t.x, m), o.y = __shfl_xor(t.y, m), o.z = __shfl_xor(t.z, m), o.w = __shfl_xor(t.w, m);
+                            t = t + o;
+                        }
+                        if (UNI) t = t * uval;
+                        if (p4 == 0u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), ro, ro4.x + fgh, 0, 0);
+                    } else {
+                        if (UNI) a0 = a0 * uval, a1 = a1 * uval, a2 = a2 * uval, a3 = a3 * uval;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a0), ro, ro4.x + fgh, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a1), ro, ro4.y + fgh, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a2), ro, ro4.z + fgh, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a3), ro, ro4.w + fgh, 0, 0);
+                    }
+                    at += 36u + (uint32_t)Lq * 32u;
+                }
             }
             const unsigned long long t1 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
@@ -622,7 +709,7 @@ bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W) {
     // workgroup per CU on a 256-CU device (8 XCDs x 32 CUs x 4 SIMDs = the 128 waves per XCD of the image); 32-bit byte offsets inside a
     // tap; enough (entry, slab) pairs to give every XCD one
     return (W == 32 || W == 64 || W == 96 || W == 128) && m.ms_ent && m.ms_rows && m.ms_sets >= 2 * kMsDepth && (m.ms_uniform || m.ms_val) &&
-           cu_count() == 256 && B * (W / 32) >= 8 && (int64_t)N * 128 < (int64_t)kMsPad;
+           cu_count() == 256 && B * (W / 32) >= 8 && (int64_t)N * 128 < (int64_t)kMsPad && (W == 32 || !m.ms_hub);   // (hub rows: 32-column rows only)
 }
 
 int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st) {
@@ -652,17 +739,23 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     float a_uval = m.sell_uval;
     unsigned a_mask = src_mask;
     int a_W = W;
+    const uint32_t* a_hub = m.ms_hub;
     unsigned a_tmo = (unsigned)(g_tune.spmm_tmo_ms > 0 ? g_tune.spmm_tmo_ms : 2000) * 100000u;   // s_memrealtime ticks (100 MHz)
     void* args[] = {&a_ent, &a_val, &a_rows, &Xin, &Xtaps, &a_stride, &a_nhops, &a_N, &a_B, &a_passes, &a_rounds, &gate, &a_bar, &a_uval, &a_mask,
-                    &a_pfd, &a_nostore, &trace, &a_census, &a_tmo, &a_W};
+                    &a_pfd, &a_nostore, &trace, &a_census, &a_tmo, &a_W, &a_hub};
     hipError_t lerr = hipSuccess;
-#define GF_MS(SV, UV, PV, DV, XV)                                                                                                    \
+#define GF_MS(SV, UV, PV, DV, XV) \
+    do {                                                                                                                               \
+        if (m.ms_hub && (XV) == 0) GF_MSH(SV, UV, PV, DV, 0, 1);                                                                       \
+        else GF_MSH(SV, UV, PV, DV, XV, 0);                                                                                            \
+    } while (0)
+#define GF_MSH(SV, UV, PV, DV, XV, HV)                                                                                                    \
     do {                                                                                                                               \
         if (chained)                                                                                                                   \
-            lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV, XV>, grid, block, args, 0, st); \
+            lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV, XV, HV>, grid, block, args, 0, st); \
         else                                                                                                                           \
-            hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV, XV>), grid, block, 0, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
-                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_nostore, trace, a_census, a_tmo, a_W); \
+            hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV, XV, HV>), grid, block, 0, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
+                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_nostore, trace, a_census, a_tmo, a_W, a_hub); \
     } while (0)
 #define GF_MS_P(SV, UV, DV)                            \
     do {                                              \
@@ -693,6 +786,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
 #undef GF_MS_D
 #undef GF_MS_P
 #undef GF_MS
+#undef GF_MSH
     GF_HIP(lerr);
     GF_LAUNCH_CHECK("spmm_msweep_kernel");
     if (chained && !a_nostore && src_mask == 0xffffffffu) {
@@ -700,6 +794,14 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
                            Xin, Xtaps, (size_t)tapStride, nhops, N, B, W, m.ms_uniform, m.sell_uval, g_status.load());
         GF_LAUNCH_CHECK("spmm_msweep_repair_kernel");
     }
+    return GF_OK;
+}
+
+extern "C" int gf_debug_msweep_info(const gf_plan* plan, int32_t op, int32_t* out) {   // {sets, passes, rounds, fill x 1000, hub rows, split hub rows, hub limit, split limit}
+    GF_REQUIRE_ARG(plan != nullptr && out != nullptr && (op == GF_OP_FWD || op == GF_OP_BWD), "gf_debug_msweep_info: bad argument");
+    const gf_csr_dev& m = plan->mat[op];
+    out[0] = m.ms_sets, out[1] = m.ms_passes, out[2] = m.ms_rounds, out[3] = (int32_t)(m.ms_fill * 1000.0 + 0.5);
+    out[4] = m.ms_hub_rows, out[5] = m.ms_hub_split_rows, out[6] = m.ms_hub_limit, out[7] = m.ms_hub_split;
     return GF_OK;
 }
 

@@ -52,7 +52,19 @@ struct MsweepImage {
                                                      // a step's entry to the position's 8 lanes with two DPP moves
     std::vector<float> val;                          // same shape, weighted GSOs only (empty when uniform)
     std::vector<uint32_t> rows;                      // [passes][128 waves][S][32]  output byte offset (row * 128) of (set, position * 4 + slot), kMsPad = none
-    int64_t real_entries = 0;                        // fill = real_entries / (passes * 128 * S * 8 * T)
+    int64_t real_entries = 0;                        // fill = real_entries / (passes * 128 * S * 8 * T)   (entries of the rows IN groups)
+    // Hub rows (round 6): rows longer than hub_limit are in no group -- one of them would set the number of rounds every wave walks.  Each
+    // wave computes its share of them straight from these streams between its store phase and the hand-over (ascending columns, one
+    // fmaf per entry: the same chain).  A wave's block = QUADS of 4 octets (32 rows of similar length, longest first), back to back:
+    //   word 0: Lq (steps of the quad = its longest row), word 1: 1 = the quad is ONE row split over its 32 slots, words 2..3: 0
+    //   words 4..35:  output byte offset (row * 128, kMsPad = none) of (position p, octet o) at 4 + 4 p + o
+    //   then Lq x 32 words: source byte offset (row * 128, kMsPad = gap) of step j, (position p, octet o) at 36 + 32 j + 4 p + o
+    // (a lane -- position p -- reads its four octets' words of a step with one 16-byte load); hubval has the same shape (weighted GSOs).
+    int32_t hub_limit = 0, hub_rows = 0, hub_split = 0, hub_split_rows = 0;
+    int64_t hub_entries = 0;
+    std::vector<uint32_t> hub;
+    std::vector<float> hubval;
+    std::vector<uint32_t> hubptr;                    // [passes * 128 + 1] word offsets of the waves' blocks in hub
     double fill() const { return passes ? (double)real_entries / ((double)passes * kMsWavesPerXcd * sets * 8 * rounds) : 0.0; }
     size_t stream_words() const { return (size_t)(rounds + 2) * 256; }   // per (pass, wave)
     size_t at(int32_t t, int32_t p, int32_t step) const { return (size_t)t * 256 + (size_t)p * 32 + (step / 4) * 4 + (step & 3); }
@@ -65,7 +77,39 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
                                       int32_t slack_pct = 15, int32_t max_passes = 1) {
     MsweepImage im;
     if (n <= 0 || (int64_t)n * 128 >= (int64_t)kMsPad) return im;
-    const int32_t groups = (n + 3) / 4;
+    // Hub rows: candidates for the limit are multiples of the mean group length; the cost of a candidate = steps of the sweep (rounds x sets:
+    // the rounds must hold the longest group -- at least the longest row in a group plus three short ones -- and the mean with its slack)
+    // + three sweep steps per hub step (a hub step is four dependent-latency gathers, out of sweep order).  A graph whose longest row fits the
+    // rounds anyway (ER, SBM, kNN) gets no hubs and the image it always had.
+    std::vector<int32_t> degs(n);
+    for (int32_t r = 0; r < n; ++r) degs[r] = rowptr[r + 1] - rowptr[r];
+    int32_t hub_limit = 0;
+    {
+        std::vector<int32_t> sorted(degs);
+        std::sort(sorted.begin(), sorted.end());
+        const int32_t maxdeg = sorted.empty() ? 0 : sorted.back(), dq = sorted[(size_t)n / 4];
+        const double g0 = 4.0 * rowptr[n] / std::max(1, n);
+        double best = 0.0;
+        const double cands[] = {1e9, 8, 6, 4, 3, 2, 1.5, 1.25, 1.0, 0.75};
+        for (double c : cands) {
+            const int32_t H = c > 1e8 ? maxdeg : (int32_t)std::ceil(c * g0);
+            if (c < 1e8 && H >= maxdeg) continue;
+            int64_t eh = 0, nh = 0;
+            double hubsteps = 0.0;
+            for (int32_t i = n - 1; i >= 0 && sorted[i] > H; --i) ++nh, eh += sorted[i];
+            for (int64_t i = 0; i < nh; i += 32) hubsteps += sorted[n - 1 - i];          // a quad takes its longest row's steps
+            const double gl = 4.0 * (rowptr[n] - eh) / std::max<int64_t>(1, n - nh);
+            const double T = std::max(gl * (100 + slack_pct) / 100.0, (double)H + 3.0 * dq);
+            const double cost = T * kMsMaxSets + 3.0 * hubsteps / kMsWavesPerXcd;
+            if (hub_limit == 0 || cost < best) best = cost, hub_limit = H;
+        }
+    }
+    int32_t n_in = 0;                                // rows in groups
+    int64_t e_in = 0;
+    for (int32_t r = 0; r < n; ++r)
+        if (degs[r] <= hub_limit) ++n_in, e_in += degs[r];
+    if (n_in == 0) return im;
+    const int32_t groups = (n_in + 3) / 4;
     // passes: as few as the largest geometry (25 sets per wave) allows -- every pass sweeps the sources again; sets per wave: the smallest
     // geometry that holds every group in that many passes
     const int32_t passes = (int32_t)((groups + (int64_t)kMsWavesPerXcd * kMsMaxSets * 8 - 1) / ((int64_t)kMsWavesPerXcd * kMsMaxSets * 8));
@@ -78,21 +122,25 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
     // next hop of the fused chain starts its sweep at source row 0 -- are the rows that sweep gathers first.
     // rows of a band -> groups of 3 or 4: longest row first, each to the group with the fewest entries so far that still has a free slot (the
     // first rows seed one group each): every group ends with (almost) the same entry total -- the longest one sets T
-    const int32_t cap = (int32_t)std::ceil((double)rowptr[n] / std::min<int64_t>((int64_t)passes * S * kMsWavesPerXcd * 8, n) * (100 + slack_pct) / 100.0);   // rounds the slack asks for, over the mean group (before rounding to even)
+    const int32_t cap = (int32_t)std::ceil((double)e_in / std::max<int64_t>(1, std::min<int64_t>((int64_t)passes * S * kMsWavesPerXcd * 8, n_in)) * (100 + slack_pct) / 100.0);   // rounds the slack asks for, over the mean group (before rounding to even)
     // (the rows are spread EVENLY over the bands the geometry has: a band then holds a few groups of 3 rows instead of leaving the last
     // band half empty, the mean group is shorter and so is the longest -- config 4: 25 600 groups of 39.1 entries instead of 25 000 of 40.0)
     const int32_t band_groups = kMsWavesPerXcd * 8;
     const int32_t bands = passes * S;
-    const int32_t band_rows = std::min(band_groups * 4, ((n + bands - 1) / bands + 3) / 4 * 4);
+    // (bands are ranges of the rows IN groups, in row order: inrow[] lists them)
+    std::vector<int32_t> inrow;
+    inrow.reserve(n_in);
+    for (int32_t r = 0; r < n; ++r)
+        if (degs[r] <= hub_limit) inrow.push_back(r);
+    const int32_t band_rows = std::min(band_groups * 4, ((n_in + bands - 1) / bands + 3) / 4 * 4);
     const int32_t groups_all = bands * band_groups;       // (group slots; the last band may leave some empty)
     std::vector<int32_t> grow((size_t)groups_all * 4, -1);
     std::vector<int32_t> glen(groups_all, 0), gcnt(groups_all, 0);
     std::vector<int32_t> order;
     for (int32_t j = 0; j < bands; ++j) {
-        const int32_t r0 = std::min(n, j * band_rows), r1 = std::min(n, r0 + band_rows);
+        const int32_t r0 = std::min(n_in, j * band_rows), r1 = std::min(n_in, r0 + band_rows);
         const int32_t ng = std::min(band_groups, r1 - r0);        // every group slot of the band gets a seed row while rows last
-        order.resize(r1 - r0);
-        std::iota(order.begin(), order.end(), r0);
+        order.assign(inrow.begin() + r0, inrow.begin() + r1);
         std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b]; });
         std::priority_queue<std::pair<int32_t, int32_t>, std::vector<std::pair<int32_t, int32_t>>, std::greater<std::pair<int32_t, int32_t>>> open;
         for (int32_t i = 0; i < r1 - r0; ++i) {
@@ -203,6 +251,70 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
             if (v) v[at] = list[k].v;
         }
     }
+    // hub rows -> quads.  Ordinary hub rows: longest first, 32 per quad.  A row longer than hub_split is SPLIT over the 32 slots of a quad of
+    // its own (slot s = 4 p + o takes the row's entries s Lq .. s Lq + Lq - 1, Lq = ceil(length / 32)): a wave must not spend 20 times the
+    // other waves' hub time on one row; its 32 partial chains are added in a fixed tree (octets in order, then positions by xor 1, 2, 4): the
+    // one place where a row's sum is not the single ascending-column chain (deterministic; ~1e-7 relative to it).  Quads go to the waves
+    // longest first, each to the wave with the fewest hub steps so far.
+    im.hub_limit = hub_limit;
+    std::vector<int32_t> hubs;
+    for (int32_t r = 0; r < n; ++r)
+        if (degs[r] > hub_limit) hubs.push_back(r), im.hub_entries += degs[r];
+    im.hub_rows = (int32_t)hubs.size();
+    if (!hubs.empty()) {
+        std::stable_sort(hubs.begin(), hubs.end(), [&](int32_t a, int32_t b) { return degs[a] > degs[b]; });
+        const int32_t nw = passes * kMsWavesPerXcd;
+        im.hub_split = std::max<int32_t>(32, (int32_t)(2 * (im.hub_entries / 32 / nw)));
+        struct Quad { int32_t L, first, count, split; };          // rows hubs[first .. first + count)
+        std::vector<Quad> quads;
+        size_t i = 0;
+        for (; i < hubs.size() && degs[hubs[i]] > im.hub_split; ++i) quads.push_back({(degs[hubs[i]] + 31) / 32, (int32_t)i, 1, 1}), ++im.hub_split_rows;
+        for (; i < hubs.size(); i += 32) quads.push_back({degs[hubs[i]], (int32_t)i, (int32_t)std::min<size_t>(32, hubs.size() - i), 0});
+        std::stable_sort(quads.begin(), quads.end(), [](const Quad& x, const Quad& y) { return x.L > y.L; });
+        std::vector<std::vector<int32_t>> quads_of(nw);
+        std::priority_queue<std::pair<int64_t, int32_t>, std::vector<std::pair<int64_t, int32_t>>, std::greater<std::pair<int64_t, int32_t>>> load;
+        for (int32_t w = 0; w < nw; ++w) load.push({0, w});
+        for (int32_t q = 0; q < (int32_t)quads.size(); ++q) {
+            auto [l, w] = load.top();
+            load.pop();
+            quads_of[w].push_back(q);
+            load.push({l + quads[q].L + 2, w});
+        }
+        im.hubptr.assign(nw + 1, 0);
+        for (int32_t w = 0; w < nw; ++w) {
+            im.hubptr[w] = (uint32_t)im.hub.size();
+            for (int32_t q : quads_of[w]) {
+                const Quad& Q = quads[q];
+                const size_t base = im.hub.size();
+                im.hub.resize(base + 36 + (size_t)Q.L * 32, kMsPad);
+                if (!uniform) im.hubval.resize(im.hub.size(), 0.f);
+                im.hub[base] = (uint32_t)Q.L;
+                im.hub[base + 1] = (uint32_t)Q.split;
+                im.hub[base + 2] = im.hub[base + 3] = 0u;
+                if (Q.split) {
+                    const int32_t r = hubs[Q.first];
+                    im.hub[base + 4] = (uint32_t)r << 7;                       // (position 0, octet 0 stores the row)
+                    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                        const int32_t idx = k - rowptr[r], slot = idx / Q.L, j = idx % Q.L;
+                        const size_t at = base + 36 + (size_t)j * 32 + slot;
+                        im.hub[at] = (uint32_t)col[k] << 7;
+                        if (!uniform) im.hubval[at] = val[k];
+                    }
+                    continue;
+                }
+                for (int32_t ii = 0; ii < Q.count; ++ii) {
+                    const int32_t r = hubs[(size_t)Q.first + ii], o = ii / 8, pp = ii % 8;   // octet o of the quad, position pp
+                    im.hub[base + 4 + 4 * pp + o] = (uint32_t)r << 7;
+                    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                        const size_t at = base + 36 + (size_t)(k - rowptr[r]) * 32 + 4 * pp + o;
+                        im.hub[at] = (uint32_t)col[k] << 7;
+                        if (!uniform) im.hubval[at] = val[k];
+                    }
+                }
+            }
+        }
+        im.hubptr[nw] = (uint32_t)im.hub.size();
+    }
     return im;
 }
 
@@ -237,6 +349,44 @@ inline void interpret_msweep_image(const MsweepImage& im, bool uniform, float uv
                     const float* d = acc.data() + ((size_t)s * 32 + j) * W;
                     for (int32_t k = 0; k < W; ++k) Y[(size_t)(ro >> 7) * W + k] = uniform ? d[k] * uval : d[k];
                 }
+        }
+    // hub phase: per wave its quads, per (octet, position) the steps in order (gaps add 0 * 0)
+    const int32_t nw = im.hubptr.empty() ? 0 : (int32_t)im.hubptr.size() - 1;
+    std::vector<float> a((size_t)32 * W);
+    for (int32_t w = 0; w < nw; ++w)
+        for (size_t at = im.hubptr[w]; at < im.hubptr[w + 1];) {
+            const int32_t Lq = (int32_t)im.hub[at];
+            const bool split = im.hub[at + 1] != 0;
+            std::fill(a.begin(), a.end(), 0.f);
+            for (int32_t slot = 0; slot < 32; ++slot)              // slot = 4 p + o
+                for (int32_t j = 0; j < Lq; ++j) {
+                    const size_t e = at + 36 + (size_t)j * 32 + slot;
+                    if (im.hub[e] == kMsPad) continue;
+                    const float* x = X + (size_t)(im.hub[e] >> 7) * W;
+                    const float v = uniform ? 1.f : im.hubval[e];
+                    for (int32_t k = 0; k < W; ++k) a[(size_t)slot * W + k] = fmaf(v, x[k], a[(size_t)slot * W + k]);
+                }
+            if (split) {                                            // octets in order, then positions by xor 1, 2, 4 (both partners compute a + b: commutative)
+                std::vector<float> ps((size_t)8 * W);
+                for (int32_t pp = 0; pp < 8; ++pp)
+                    for (int32_t k = 0; k < W; ++k)
+                        ps[(size_t)pp * W + k] = ((a[(size_t)(4 * pp) * W + k] + a[(size_t)(4 * pp + 1) * W + k]) + a[(size_t)(4 * pp + 2) * W + k]) + a[(size_t)(4 * pp + 3) * W + k];
+                for (int32_t m = 1; m < 8; m <<= 1) {
+                    std::vector<float> nx(ps);
+                    for (int32_t pp = 0; pp < 8; ++pp)
+                        for (int32_t k = 0; k < W; ++k) nx[(size_t)pp * W + k] = ps[(size_t)pp * W + k] + ps[(size_t)(pp ^ m) * W + k];
+                    ps.swap(nx);
+                }
+                const uint32_t ro = im.hub[at + 4];
+                for (int32_t k = 0; k < W; ++k) Y[(size_t)(ro >> 7) * W + k] = uniform ? ps[k] * uval : ps[k];
+            } else {
+                for (int32_t slot = 0; slot < 32; ++slot) {
+                    const uint32_t ro = im.hub[at + 4 + slot];
+                    if (ro == kMsPad) continue;
+                    for (int32_t k = 0; k < W; ++k) Y[(size_t)(ro >> 7) * W + k] = uniform ? a[(size_t)slot * W + k] * uval : a[(size_t)slot * W + k];
+                }
+            }
+            at += 36 + (size_t)Lq * 32;
         }
 }
 

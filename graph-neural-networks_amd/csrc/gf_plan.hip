@@ -431,7 +431,12 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
     if (n >= (g_experiments ? kMsMinNodes : kMsDefaultMinNodes)) {
         MsweepImage ms = build_msweep_image(n, a.rowptr.data(), a.col.data(), a.val.data(), uni, g_tune.spmm_slack, g_tune.spmm_passes > 0 ? g_tune.spmm_passes : 1);
         d.ms_fill = ms.fill();
-        if (ms.passes >= 1 && ms.passes <= 2 && ms.fill() >= 0.6) {
+        if (ms.passes >= 1 && ms.passes <= 2 && ms.fill() >= 0.6 && ms.hub_entries * 5 <= (int64_t)a.rowptr[n] * 2) {   // (hub rows: at most 40 % of the entries)
+            d.ms_hub_rows = ms.hub_rows;
+            d.ms_hub_split_rows = ms.hub_split_rows;
+            d.ms_hub_limit = ms.hub_limit;
+            d.ms_hub_split = ms.hub_split;
+            d.ms_hub_entries = ms.hub_entries;
             d.ms_sets = ms.sets;
             d.ms_passes = ms.passes;
             d.ms_rounds = ms.rounds;
@@ -439,6 +444,19 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
             if ((rc = upload(ms.ent, &d.ms_ent, bytes))) return rc;
             if (!uni && (rc = upload(ms.val, &d.ms_val, bytes))) return rc;
             if ((rc = upload(ms.rows, &d.ms_rows, bytes))) return rc;
+            if (ms.hub_rows) {   // hub rows: one packed buffer {block offsets, total words, blocks, values}; the kernel's loads run up to four steps ahead: padded
+                const size_t hw = ms.hub.size() + 192;
+                std::vector<uint32_t> pack(ms.hubptr);
+                pack.push_back((uint32_t)hw);
+                pack.insert(pack.end(), ms.hub.begin(), ms.hub.end());
+                pack.resize(pack.size() + 192, kMsPad);
+                if (!uni) {
+                    const size_t at = pack.size();
+                    pack.resize(at + hw, 0u);
+                    memcpy(pack.data() + at, ms.hubval.data(), ms.hubval.size() * sizeof(float));
+                }
+                if ((rc = upload(pack, &d.ms_hub, bytes))) return rc;
+            }
             GF_HIP(hipMalloc((void**)&d.ms_gate, gf_msweep_gate_bytes()));
             GF_HIP(hipMemset(d.ms_gate, 0, gf_msweep_gate_bytes()));
             (void)gf_msweep_status_word();   // (pinned word for the repair kernel's report: allocated here, never under a launch)
@@ -678,6 +696,7 @@ void free_csr(gf_csr_dev& d) {
     if (d.ms_ent) (void)hipFree(d.ms_ent);
     if (d.ms_val) (void)hipFree(d.ms_val);
     if (d.ms_rows) (void)hipFree(d.ms_rows);
+    if (d.ms_hub) (void)hipFree(d.ms_hub);
     if (d.ms_gate) (void)hipFree(d.ms_gate);
     if (d.pn_slice) (void)hipFree(d.pn_slice);
     if (d.pn_oct) (void)hipFree(d.pn_oct);

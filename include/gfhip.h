@@ -292,6 +292,9 @@ int gf_tune(const char* key, int32_t value);
  * slots][8] shader-clock stamps of the XCD's first wave: {body start, round loop start, round loop end, stores issued, barrier passed, 0, 0, 0}
  * (tools/msweep_trace.py).  Synchronises the device. */
 int gf_debug_msweep_trace(unsigned long long* out);
+/* the sweep image of one orientation of a plan: out[8] = {accumulator sets per wave (0 = no image), passes, rounds, fill x 1000, hub rows (rows too long
+ * for a group: computed by the waves between store phase and hand-over), hub rows summed as 32 partial chains, the two length limits} */
+int gf_debug_msweep_info(const gf_plan* plan, int32_t op, int32_t* out);
 
 #ifdef __cplusplus
 }

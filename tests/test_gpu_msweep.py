@@ -298,3 +298,58 @@ def test_msweep_wide_rows_are_slabs_of_the_same_image(n, deg, B, W, K, directed,
     tune(spmm_status_reset=1)
     got = khop_chain(plans, x0, K, 0, spmm_algo=0, spmm_fuse=1, spmm_census=1)
     assert torch.equal(got, khop_chain(plans, x0, K, 0, spmm_algo=3, spmm_census=0)) and chain_status()[0] == 1
+
+
+def powerlaw(n, m, seed, weighted=False):
+    """Row lengths with the tail of a Barabasi-Albert graph, P(length > k) = (m / k)^2, columns uniform: a few rows of hundreds to thousands of entries."""
+    rng = np.random.RandomState(seed)
+    deg = np.minimum(n // 8, (m / np.sqrt(np.maximum(rng.uniform(size=n), 1e-9))).astype(np.int64))
+    deg[5] = 0
+    r = np.repeat(np.arange(n), deg)
+    c = rng.randint(0, n, size=r.size)
+    A = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(n, n))
+    A.sum_duplicates()
+    A.data[:] = rng.uniform(-1.0, 1.0, size=A.data.size) if weighted else 0.0625
+    return sp.csr_matrix(A)
+
+
+def msweep_info(plan, op):
+    import ctypes
+    out = (ctypes.c_int32 * 8)()
+    _lib.check(_lib.lib().gf_debug_msweep_info(plan, op, out))
+    return dict(zip(("sets", "passes", "rounds", "fill1000", "hub_rows", "hub_split_rows", "hub_limit", "hub_split"), list(out)))
+
+
+@pytest.mark.parametrize("n,m,B,K,weighted", [(100000, 5, 16, 4, False), (60000, 4, 9, 3, True), (120000, 3, 8, 3, False)])
+def test_msweep_hub_rows_are_computed_outside_the_groups(n, m, B, K, weighted, knobs):
+    """A power-law graph: rows far longer than a group's share would set the number of rounds every wave walks, so the image leaves them out of
+    the groups and each wave computes its share of them from the CSR between its store phase and the hand-over -- the same ascending-column fmaf
+    chain, so every row that is not SPLIT is bit for bit SELL-8's; the few rows longer than the split limit are summed as 32 partial chains +
+    a fixed tree (relative 1e-6).  Orientation 1 (rows of S) has the hubs, orientation 0 (rows of S^T: Poisson lengths) none; single hops, the
+    fused chain and the repaired chain."""
+    A = powerlaw(n, m, seed=n + m, weighted=weighted)
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    info = msweep_info(plans[0], 1)
+    assert info["sets"] > 0 and info["hub_rows"] > 0 and info["hub_split_rows"] > 0, info
+    deg = np.diff(A.indptr)
+    unsplit = torch.tensor(deg <= info["hub_split"], device=DEV)
+    x0 = torch.randn(B, n, 32, device=DEV)
+    L = _lib.lib()
+    for op in (1, 0):
+        assert L.gf_spmm_hop_kernel(plans[0], op, B, 32) == 1
+        ref1 = hop(plans, op, x0, 3)
+        got1 = hop(plans, op, x0, 5)
+        rows = unsplit if op == 1 else torch.ones_like(unsplit)
+        assert torch.equal(got1[:, rows], ref1[:, rows]), (op, int((got1[:, rows] != ref1[:, rows]).sum()))
+        assert float((got1 - ref1).abs().max()) <= 1e-6 * float(ref1.abs().max()) * 8
+        ref = khop_chain(plans, x0, K, op, spmm_algo=3)
+        for kw in (dict(spmm_algo=0, spmm_fuse=1), dict(spmm_algo=0, spmm_fuse=0)):
+            got = khop_chain(plans, x0, K, op, **kw)
+            if op == 0:
+                assert torch.equal(got, ref), (op, kw)
+            else:                                          # (a split row's rounding difference propagates through the later hops)
+                assert torch.equal(got[1][:, rows], ref[1][:, rows])
+                assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), (op, kw)
+        det = khop_chain(plans, x0, K, op, spmm_algo=0, spmm_fuse=1)
+        assert torch.equal(det, khop_chain(plans, x0, K, op, spmm_algo=0, spmm_fuse=1))      # run-to-run: bit for bit (fixed tree)

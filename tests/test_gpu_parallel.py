@@ -126,3 +126,66 @@ def test_data_parallel_trainer_on_the_hip_path_retraces_the_reference_run(tmp_pa
         assert np.max(np.abs(tv["costValid"] - d["costValid"])) <= 1.0 / 32 + 1e-6
     for k in ret[0][1]:
         assert torch.equal(ret[0][1][k], ret[1][1][k]), k                 # replicas never diverge
+
+
+def _chain_worker(rank, world, port, ret):
+    """Fused K-hop chains (cooperative, every-CU launches) from TWO processes on one GPU at the same time."""
+    import ctypes
+    import scipy.sparse as sp
+    from alegnn_amd import _lib
+    from alegnn_amd.gso import SparseGSO
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        n, B, K, W = 60000, 16, 4, 32
+        rng = np.random.RandomState(7)
+        r = np.repeat(np.arange(n), 4)
+        A = sp.csr_matrix((np.ones(r.size), (r, rng.randint(0, n, size=r.size))), shape=(n, n))
+        A = ((A + A.T) > 0).astype(np.float64)
+        A.setdiag(0)
+        A.eliminate_zeros()
+        gso = SparseGSO([sp.csr_matrix(A * 0.0625)])
+        plans = gso.plans(dev)
+        L = _lib.lib()
+        st = torch.cuda.current_stream().cuda_stream
+        assert L.gf_spmm_hop_kernel(plans[0], 0, B, W) == 1
+        torch.manual_seed(5)
+        Z = torch.full((K, B, n, W), float("nan"), device=dev)
+        Z[0].normal_()
+        dist.barrier()                                  # both processes start launching together
+        outs = []
+        for rep in range(40):
+            Z[1:].fill_(float("nan"))
+            _lib.check(L.gf_khop(plans, 1, 0, Z.data_ptr(), B, W, K, st))
+            if rep % 8 == 7:
+                torch.cuda.synchronize()
+                outs.append(Z.clone())
+        torch.cuda.synchronize()
+        same = all(bool(torch.equal(o, outs[0])) for o in outs)
+        # reference: the per-hop launches of the same kernel (GFHIP_MSWEEP_FUSE semantics: one launch per hop has no hand-over inside a launch)
+        f, on = ctypes.c_uint32(0), ctypes.c_int32(0)
+        L.gf_msweep_status(ctypes.byref(f), ctypes.byref(on))
+        Zr = Z.clone()
+        Zr[1:].fill_(float("nan"))
+        for k in range(1, K):
+            _lib.check(L.gf_spmm_hop(plans[0], 0, Zr[k - 1].data_ptr(), Zr[k].data_ptr(), B, W, st))
+        torch.cuda.synchronize()
+        ret[rank] = (same, bool(torch.equal(outs[-1], Zr)), int(f.value), int(on.value))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_chains_of_two_processes_on_one_gpu_do_not_trap_hang_or_differ():
+    """two processes share one GPU (this file's configuration) and both launch the one-launch K-hop chain, a cooperative grid
+    that needs every CU.  Whatever the runtime does with the two grids -- serialise them, or interleave them so that neither is whole, in which
+    case the census gives up after its time limit and the repair kernel does the work -- every chain must come out with the per-hop launches'
+    bits, and neither process may die.  The status flags say which of the two happened (informational)."""
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_chain_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for rank in range(world):
+        same, equal_ref, flags, fusion_on = ret[rank]
+        assert same and equal_ref, (rank, same, equal_ref, flags, fusion_on)
+    import warnings
+    warnings.warn(f"two processes, one GPU: status flags per rank {[ret[r][2] for r in range(world)]}, fusion still on {[ret[r][3] for r in range(world)]}")

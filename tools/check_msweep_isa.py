@@ -5,11 +5,19 @@ live values only in v0-v23.  This check compiles gf_msweep.hip to ISA and fails 
   * a compiler-emitted instruction (anything outside the ;;#ASMSTART ... ;;#ASMEND regions) names a vector register above v23 or any
     accumulator register -- the body keeps state there between (batch entry, hop) passes,
   * the kernel does not get the whole register file (.vgpr_count 512, .agpr_count 256: one wave per SIMD is what the image's geometry assumes).
+The instantiations with a hub phase (last template argument 1: compiler code that gathers and sums between two asm bodies, and re-zeroes the
+accumulators before every body) are exempt from the register rule and may spill a few registers in their cold paths (time-out, trace, row-table
+copy); they must still own the whole register file, and their spills are bounded (<= 16 each).
 Run by tests/test_host_logic.py::test_msweep_isa_register_contract (needs hipcc; no GPU)."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PK = os.path.join(ROOT, "graph-neural-networks_amd")
 LIMIT = int(os.environ.get("MS_ISA_LIMIT", "24"))                                        # first vector register the asm body owns
+
+
+def is_hub(name):
+    a = re.findall(r"Li(\d+)E", name.split("spmm_msweep_kernelI", 1)[1])
+    return len(a) >= 6 and a[5] == "1"
 
 
 def main():
@@ -22,6 +30,8 @@ def main():
     for m in re.finditer(r"^(_Z\w*spmm_msweep_kernel\w*):\s*;.*?$(.*?)s_endpgm", txt, re.S | re.M):
         nk += 1
         name, body = m.group(1), m.group(2)
+        if is_hub(name):
+            continue
         in_asm = False
         for line in body.splitlines():
             t = line.strip()
@@ -47,7 +57,9 @@ def main():
         name = nm.group(1)
         seen += 1
         f = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|agpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", blk)}
-        if f.get("vgpr_spill_count", 0) or f.get("sgpr_spill_count", 0) or f.get("private_segment_fixed_size", 0) or f.get("vgpr_count") != 512 or f.get("agpr_count") != 256:
+        hub = is_hub(name)
+        lim = 16 if hub else 0
+        if f.get("vgpr_spill_count", 0) > lim or f.get("sgpr_spill_count", 0) > lim or (f.get("private_segment_fixed_size", 0) and not hub) or f.get("vgpr_count") != 512 or f.get("agpr_count") != 256:
             bad += 1
             print(f"{name[:60]}: {f}")
     print(f"gf_msweep.hip: {nk} kernel bodies scanned, {seen} metadata blocks checked, {bad} violations")

@@ -105,4 +105,14 @@ l)  # image slack (rounds beyond the mean group length) x prefetch lead, now tha
     timeout 300 python tools/hop_probe.py cfg4 10 spmm_slack=$sl v:spmm_algo=0+spmm_pfd=3 v:spmm_pfd=2 v:spmm_pfd=3 v:spmm_pfd=4 v:spmm_pfd=0 2>&1 | grep "khop chain" | sed 's/bitwise.*//' | tee -a $O/khop.log
   done
   ;;
+m)  # two processes on one GPU, both launching fused chains
+  timeout 900 python -m pytest tests/test_gpu_parallel.py -x -q -k "two_processes" 2>&1 | tail -8 | tee $O/pytest_two_processes.log
+  ;;
+n)  # hub rows: parity, then a power-law graph at config 4's size against SELL-8
+  timeout 900 python -m pytest tests/test_gpu_msweep.py -x -q -k "hub_rows" 2>&1 | tail -12 | tee $O/pytest_hub.log
+  PROBE_GRAPH=powerlaw timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=3 v:spmm_algo=0 v:spmm_algo=3 v:spmm_algo=0 v:spmm_algo=0+spmm_fuse=0 2>&1 | grep "khop chain\|image" | tee $O/khop_powerlaw.log
+  PROBE_OP=1 PROBE_GRAPH=powerlaw timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_algo=3 v:spmm_algo=0 v:spmm_algo=3 v:spmm_algo=0 2>&1 | grep "khop chain\|image" | tee -a $O/khop_powerlaw.log
+  timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0 v:spmm_algo=0 2>&1 | grep "khop chain" | tee $O/khop_er.log
+  bash tools/gpu_r6.sh m
+  ;;
 esac

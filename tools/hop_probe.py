@@ -34,6 +34,18 @@ if os.environ.get("PROBE_GRAPH") == "band":   # same N / degree, every neighbour
         A.setdiag(0); A.eliminate_zeros()
         return sp.csr_matrix(A / 20.0)
     graphgen.er = band
+if os.environ.get("PROBE_GRAPH") == "powerlaw":   # same N, mean degree ~10, row lengths with a Barabasi-Albert tail (P(len > k) = (5 / k)^2), symmetrised
+    import numpy as np, scipy.sparse as sp
+    from alegnn_amd import graphgen
+    def powerlaw(N, avg_degree=10.0, seed=0, **kw):
+        rng = np.random.RandomState(seed)
+        deg = np.minimum(N // 8, (0.25 * avg_degree / np.sqrt(np.maximum(rng.uniform(size=N), 1e-9))).astype(np.int64))
+        r = np.repeat(np.arange(N), deg)
+        A = sp.csr_matrix((np.ones(r.size), (r, rng.randint(0, N, size=r.size))), shape=(N, N))
+        A = ((A + A.T) > 0).astype(np.float64)
+        A.setdiag(0); A.eliminate_zeros()
+        return sp.csr_matrix(A / 40.0)
+    graphgen.er = powerlaw
 w = bench.Workload(name, wl, dev, 0)
 st = torch.cuda.current_stream().cuda_stream
 if wl["kind"] == "evgf":
@@ -53,6 +65,11 @@ else:
     W = int(os.environ.get("PROBE_W", W))      # same graph, another row width (the hop does not depend on the filter bank)
     K = wl["K"] if wl["kind"] == "filter" else wl["K"][1]
     plans = layer._gso.plans(dev)
+    OP = int(os.environ.get("PROBE_OP", 0))
+    if hasattr(L, "gf_debug_msweep_info"):
+        info = (ctypes.c_int32 * 8)()
+        if L.gf_debug_msweep_info(plans[0], OP, info) == 0:
+            print("sweep image {sets, passes, rounds, fill x 1000, hub rows, split hub rows, hub limit, split limit}:", list(info), flush=True)
     if L.gf_lsigf_pipeline(plans, 1, W, W, K) == 2:
         Z = torch.randn(K, B * W // 4, N, 4, device=dev)
         for _ in range(iters):
@@ -70,7 +87,7 @@ else:
                         k, v = kv.split("=")
                         assert L.gf_tune(k.encode(), int(v)) == 0, k
                 Z[1:].fill_(float("nan"))
-                _lib.check(L.gf_time_khop(plans, 1, 0, Z.data_ptr(), B, W, K, max(iters, 3), st, ctypes.byref(ms)))
+                _lib.check(L.gf_time_khop(plans, 1, OP, Z.data_ptr(), B, W, K, max(iters, 3), st, ctypes.byref(ms)))
                 torch.cuda.synchronize()
                 same = "" if ref is None else f"  bitwise == first variant: {bool(torch.equal(ref, Z[1:]))}"
                 if ref is None:

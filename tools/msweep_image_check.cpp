@@ -21,6 +21,10 @@ static int check(int32_t n, double avg_deg, int hubs, uint32_t seed, int W, bool
     for (int32_t i = 0; i < n; ++i) {
         int d = (i % 17 == 3) ? 0 : pd(rng);
         if (i < hubs) d = std::min(n, 60 + 40 * i);
+        if (hubs < 0) {                               // power-law degrees, P(d > k) = (m / k)^2 with m = avg_deg / 2: the tail of a Barabasi-Albert graph
+            const double u = std::max(1e-9, std::generate_canonical<double, 32>(rng));
+            d = (int)std::min<double>(n / 4, 0.5 * avg_deg / std::sqrt(u));
+        }
         std::vector<int32_t> c(d);
         for (auto& x : c) x = un(rng);
         std::sort(c.begin(), c.end());
@@ -41,13 +45,27 @@ static int check(int32_t n, double avg_deg, int hubs, uint32_t seed, int W, bool
     int bad = 0;
     for (int32_t i = 0; i < n; ++i)
         for (int w = 0; w < W; ++w) {
-            float a = 0.f;
-            for (int32_t q = rp[i]; q < rp[i + 1]; ++q) a = fmaf(uniform ? 1.f : val[q], X[(size_t)col[q] * W + w], a);
-            if (uniform) a *= 0.37f;
-            if (memcmp(&a, &Y[(size_t)i * W + w], 4) != 0) ++bad;
+            float a = 0.f, mag = 0.f;
+            for (int32_t q = rp[i]; q < rp[i + 1]; ++q) {
+                a = fmaf(uniform ? 1.f : val[q], X[(size_t)col[q] * W + w], a);
+                mag += std::fabs((uniform ? 1.f : val[q]) * X[(size_t)col[q] * W + w]);
+            }
+            if (uniform) a *= 0.37f, mag *= 0.37f;
+            const bool split = im.hub_split_rows && rp[i + 1] - rp[i] > im.hub_split;      // a split hub row: 32 partial chains + a fixed tree
+            if (split ? std::fabs(a - Y[(size_t)i * W + w]) > 2e-6f * mag : memcmp(&a, &Y[(size_t)i * W + w], 4) != 0) ++bad;
         }
     printf("n=%d deg=%.1f hubs=%d %s slack=%d: sets=%d passes=%d rounds=%d fill=%.4f image=%.1f MB", n, avg_deg, hubs, uniform ? "uniform" : "weighted",
            slack, im.sets, im.passes, im.rounds, im.fill(), (im.ent.size() + im.val.size() + im.rows.size()) * 4 / 1e6);
+    if (im.hub_rows) {
+        size_t steps = 0, mx = 0;
+        for (size_t w = 0; w + 1 < im.hubptr.size(); ++w) {
+            size_t st = 0;
+            for (size_t at = im.hubptr[w]; at < im.hubptr[w + 1]; at += 36 + (size_t)im.hub[at] * 32) st += im.hub[at];
+            steps += st, mx = std::max(mx, st);
+        }
+        printf("  hubs: limit %d, %d rows (%d split, longer than %d), %.1f %% of the entries, hub steps per wave mean %.1f max %zu", im.hub_limit, im.hub_rows,
+               im.hub_split_rows, im.hub_split, 100.0 * im.hub_entries / std::max<int64_t>(1, rp[n]), (double)steps / (im.hubptr.size() - 1), mx);
+    }
     if (sim) printf("  LRU hit rate: %.3f (28k lines) %.3f (12k) %.3f (6k)", simulate_msweep_hits(im, n, 28000), simulate_msweep_hits(im, n, 12000), simulate_msweep_hits(im, n, 6000));
     printf("  %s\n", bad ? "MISMATCH" : "ok");
     return bad;
@@ -76,6 +94,8 @@ int main(int argc, char** argv) {
         for (int i = 2; i < argc; ++i) bad += check(n, 10.0, 0, 4, 1, true, atoi(argv[i]), 1, true);
         return bad != 0;
     }
+    bad += check(100000, 10.0, -1, 9, 1, true, 5, 1, true);    // power-law degrees: hub rows computed outside the groups
+    bad += check(60000, 8.0, -1, 10, 2, false, 5, 1);
     bad += check(1, 0.0, 0, 1, 2, true, 15, 1);             // (10 sets is the smallest geometry)
     bad += check(203, 6.0, 0, 2, 2, false, 15, 1);
     bad += check(4099, 10.0, 3, 3, 2, true, 15, 1);
