@@ -326,7 +326,6 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                         const uint32_t* __restrict__ hubpack) {
     constexpr int U = 2;                                    // rounds per loop iteration (the two entry buffers alternate by round parity)
     static_assert(IDX == 0 || PF == 0, "wide rows: no scalar prefetch");
-    static_assert(HUB == 0 || IDX == 0, "hub rows: 32-column rows only");
     static_assert((U * S) % D == 0 && D < S && S <= kMsMaxSets && S <= 32,
                   "ring slots are static: 2 S steps are a multiple of the depth; a round's buffer is reloaded (for the round two later) behind "
                   "its last use and has been waited for (in-order returns) before the ring reaches that round; D < S keeps that reload "
@@ -470,7 +469,11 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                 //  would be live ACROSS the asm body, where the compiler has only v0-v23, and spill to scratch)
                 unsigned lh = lane;
                 asm volatile("; hub phase" : "+v"(lh));
-                const unsigned fgh = (lh & 7u) * 16u, p4 = (lh >> 3) * 4u;
+                const unsigned fgh = (lh & 7u) * 16u + (IDX ? (unsigned)(ve - b * nslab) * 128u : 0u), p4 = (lh >> 3) * 4u;
+                // wide rows: the body's resources address {row, column}; this phase uses byte offsets (row index capped so that a gap's offset cannot wrap into range)
+                const __amdgpu_buffer_rsrc_t rsh = IDX ? __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)b * entryBytes), 0, (int)entryBytes, 0x00020000) : rs;
+                const __amdgpu_buffer_rsrc_t roh = IDX ? __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (size_t)b * entryBytes), 0, nostore ? 0 : (int)entryBytes, 0x00020000) : ro;
+#define GF_HUB_OFF(E) (IDX ? ((((E) >> 7) < 0x7fffffu ? ((E) >> 7) : 0x7fffffu)) * rowBytes + fgh : (E) + fgh)
                 while (at < end) {
                     const int Lq = (int)hw[at];
                     const bool split = hw[at + 1] != 0u;
@@ -487,10 +490,10 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     } while (0)
 #define GF_HUB_GATHER(X, E)                                                                                            \
     do {                                                                                                               \
-        X[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, E.x + fgh, 0, 0));                  \
-        X[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, E.y + fgh, 0, 0));                  \
-        X[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, E.z + fgh, 0, 0));                  \
-        X[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, E.w + fgh, 0, 0));                  \
+        X[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, GF_HUB_OFF(E.x), 0, 0));                  \
+        X[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, GF_HUB_OFF(E.y), 0, 0));                  \
+        X[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, GF_HUB_OFF(E.z), 0, 0));                  \
+        X[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, GF_HUB_OFF(E.w), 0, 0));                  \
     } while (0)
 #define GF_HUB_FMA1(A, X, V) A.x = __builtin_fmaf(V, X.x, A.x), A.y = __builtin_fmaf(V, X.y, A.y), A.z = __builtin_fmaf(V, X.z, A.z), A.w = __builtin_fmaf(V, X.w, A.w)
 #define GF_HUB_SUM(X, V) GF_HUB_FMA1(a0, X[0], V.x), GF_HUB_FMA1(a1, X[1], V.y), GF_HUB_FMA1(a2, X[2], V.z), GF_HUB_FMA1(a3, X[3], V.w)
@@ -526,17 +529,18 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                             t = t + o;
                         }
                         if (UNI) t = t * uval;
-                        if (p4 == 0u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), ro, ro4.x + fgh, 0, 0);
+                        if (p4 == 0u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), roh, GF_HUB_OFF(ro4.x), 0, 0);
                     } else {
                         if (UNI) a0 = a0 * uval, a1 = a1 * uval, a2 = a2 * uval, a3 = a3 * uval;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a0), ro, ro4.x + fgh, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a1), ro, ro4.y + fgh, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a2), ro, ro4.z + fgh, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a3), ro, ro4.w + fgh, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a0), roh, GF_HUB_OFF(ro4.x), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a1), roh, GF_HUB_OFF(ro4.y), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a2), roh, GF_HUB_OFF(ro4.z), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a3), roh, GF_HUB_OFF(ro4.w), 0, 0);
                     }
                     at += 36u + (uint32_t)Lq * 32u;
                 }
             }
+#undef GF_HUB_OFF
             const unsigned long long t1 = trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
             const bool dependent = nhops > 1 && pass == passes - 1 && hop + 1 < nhops;   // the next hop gathers what this one stores
@@ -709,7 +713,7 @@ bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W) {
     // workgroup per CU on a 256-CU device (8 XCDs x 32 CUs x 4 SIMDs = the 128 waves per XCD of the image); 32-bit byte offsets inside a
     // tap; enough (entry, slab) pairs to give every XCD one
     return (W == 32 || W == 64 || W == 96 || W == 128) && m.ms_ent && m.ms_rows && m.ms_sets >= 2 * kMsDepth && (m.ms_uniform || m.ms_val) &&
-           cu_count() == 256 && B * (W / 32) >= 8 && (int64_t)N * 128 < (int64_t)kMsPad && (W == 32 || !m.ms_hub);   // (hub rows: 32-column rows only)
+           cu_count() == 256 && B * (W / 32) >= 8 && (int64_t)N * 128 < (int64_t)kMsPad;
 }
 
 int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st) {
@@ -746,7 +750,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     hipError_t lerr = hipSuccess;
 #define GF_MS(SV, UV, PV, DV, XV) \
     do {                                                                                                                               \
-        if (m.ms_hub && (XV) == 0) GF_MSH(SV, UV, PV, DV, 0, 1);                                                                       \
+        if (m.ms_hub) GF_MSH(SV, UV, PV, DV, XV, 1);                                                                                   \
         else GF_MSH(SV, UV, PV, DV, XV, 0);                                                                                            \
     } while (0)
 #define GF_MSH(SV, UV, PV, DV, XV, HV)                                                                                                    \

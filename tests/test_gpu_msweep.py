@@ -320,13 +320,14 @@ def msweep_info(plan, op):
     return dict(zip(("sets", "passes", "rounds", "fill1000", "hub_rows", "hub_split_rows", "hub_limit", "hub_split"), list(out)))
 
 
-@pytest.mark.parametrize("n,m,B,K,weighted", [(100000, 5, 16, 4, False), (60000, 4, 9, 3, True), (120000, 3, 8, 3, False)])
-def test_msweep_hub_rows_are_computed_outside_the_groups(n, m, B, K, weighted, knobs):
+@pytest.mark.parametrize("n,m,B,K,weighted,W", [(100000, 5, 16, 4, False, 32), (60000, 4, 9, 3, True, 32), (120000, 3, 8, 3, False, 32),
+                                               (60000, 4, 5, 3, False, 64), (52000, 3, 3, 3, True, 96)])
+def test_msweep_hub_rows_are_computed_outside_the_groups(n, m, B, K, weighted, W, knobs):
     """A power-law graph: rows far longer than a group's share would set the number of rounds every wave walks, so the image leaves them out of
     the groups and each wave computes its share of them from the CSR between its store phase and the hand-over -- the same ascending-column fmaf
     chain, so every row that is not SPLIT is bit for bit SELL-8's; the few rows longer than the split limit are summed as 32 partial chains +
-    a fixed tree (relative 1e-6).  Orientation 1 (rows of S) has the hubs, orientation 0 (rows of S^T: Poisson lengths) none; single hops, the
-    fused chain and the repaired chain."""
+    a fixed tree (relative 1e-6).  Orientation 1 (rows of S) has the hubs, orientation 0 (rows of S^T: Poisson lengths) none; single hops and
+    the fused chain; 32-column rows and wide rows (slabs)."""
     A = powerlaw(n, m, seed=n + m, weighted=weighted)
     gso = SparseGSO([A])
     plans = gso.plans(DEV)
@@ -334,10 +335,10 @@ def test_msweep_hub_rows_are_computed_outside_the_groups(n, m, B, K, weighted, k
     assert info["sets"] > 0 and info["hub_rows"] > 0 and info["hub_split_rows"] > 0, info
     deg = np.diff(A.indptr)
     unsplit = torch.tensor(deg <= info["hub_split"], device=DEV)
-    x0 = torch.randn(B, n, 32, device=DEV)
+    x0 = torch.randn(B, n, W, device=DEV)
     L = _lib.lib()
     for op in (1, 0):
-        assert L.gf_spmm_hop_kernel(plans[0], op, B, 32) == 1
+        assert L.gf_spmm_hop_kernel(plans[0], op, B, W) == 1
         ref1 = hop(plans, op, x0, 3)
         got1 = hop(plans, op, x0, 5)
         rows = unsplit if op == 1 else torch.ones_like(unsplit)

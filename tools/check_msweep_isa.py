@@ -7,7 +7,7 @@ live values only in v0-v23.  This check compiles gf_msweep.hip to ISA and fails 
   * the kernel does not get the whole register file (.vgpr_count 512, .agpr_count 256: one wave per SIMD is what the image's geometry assumes).
 The instantiations with a hub phase (last template argument 1: compiler code that gathers and sums between two asm bodies, and re-zeroes the
 accumulators before every body) are exempt from the register rule and may spill a few registers in their cold paths (time-out, trace, row-table
-copy); they must still own the whole register file, and their spills are bounded (<= 16 each).
+copy); they must still own the whole register file, and their spills are bounded (<= 32 each).
 Run by tests/test_host_logic.py::test_msweep_isa_register_contract (needs hipcc; no GPU)."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,7 +58,7 @@ def main():
         seen += 1
         f = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|agpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", blk)}
         hub = is_hub(name)
-        lim = 16 if hub else 0
+        lim = 32 if hub else 0
         if f.get("vgpr_spill_count", 0) > lim or f.get("sgpr_spill_count", 0) > lim or (f.get("private_segment_fixed_size", 0) and not hub) or f.get("vgpr_count") != 512 or f.get("agpr_count") != 256:
             bad += 1
             print(f"{name[:60]}: {f}")
