@@ -61,8 +61,8 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 #ifndef GF_MS_STPLAIN   // output rows with plain stores (1, default) or non-temporal ones (0; make variant): plain stores leave the rows in the XCD's
 #define GF_MS_STPLAIN 1 // L2, and the rows stored LAST are the lowest bands -- the ones the next hop of the fused chain gathers first (1.24 -> 1.13 ms at config 4)
 #endif
-#ifndef GF_MS_EXP      // experiments (make msvariant; TIMING ONLY, results wrong): bit 0 = no MFMAs in the loop, bit 1 = plain moves instead of the DPP
-#define GF_MS_EXP 0    // broadcasts (both change the addresses: not a valid timing), bit 3 = two of the four MFMAs (round 6's global_load variant, bit 2: same time as buffer_load)
+#ifndef GF_MS_EXP      // experiment (make msvariant; TIMING ONLY, results wrong): 8 = two of the four MFMAs of a step (round 6's other timing builds -- no MFMAs,
+#define GF_MS_EXP 0    // plain moves for the DPP broadcasts, global_load for buffer_load -- are in git history at e5e8983; profiles/r06_a_decompose)
 #endif
 #ifndef GF_MS_PFP      // scalar prefetch: GF_MS_PFP source rows (two s_loads each) per GF_MS_PFQ steps of a wave.  3 per 4: config 4's sweep needs 0.74 rows per
 #define GF_MS_PFP 3    // step and wave (N / (rounds x 128 waves x 25 steps)) and a wave can keep 15 scalar loads outstanding: ~1.8 per step at the ~850 clocks a
@@ -87,7 +87,7 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
   .set MS_V0, MS_E0 + 8              // value buffers (weighted GSOs)
 .endm
 .macro MS_MFMA s, q, k
-  .if (MS_EXP & 1) || ((MS_EXP & 8) && ((\q) & 1))
+  .if (MS_EXP & 8) && ((\q) & 1)
   .elseif ((\s)*16 + (\q)*4) < 256
     v_mfma_f32_4x4x1_16b_f32 a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3], v[MS_A0+(\k)], v[MS_R0+4*(\k)+(\q)], a[(\s)*16+(\q)*4:(\s)*16+(\q)*4+3]
   .else
@@ -121,15 +121,10 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 // position p for step 4 i + sp % 4.  MS_BCAST1 broadcasts lane (sp / 4) % 4 inside every quad, MS_BCAST2 copies the quad that holds it
 // over the position's other quad (rows of 16 lanes = two positions; banks = quads): two DPP moves, with >= 2 instructions between them.
 .macro MS_BCAST1 dst, src, sp
-  .if MS_EXP & 2
-  v_mov_b32 v[\dst], v[\src]
-  .else
   v_mov_b32_dpp v[\dst], v[\src] quad_perm:[((\sp)/4)%4,((\sp)/4)%4,((\sp)/4)%4,((\sp)/4)%4] row_mask:0xf bank_mask:0xf
-  .endif
 .endm
 .macro MS_BCAST2 dst, sp
-  .if MS_EXP & 2
-  .elseif ((\sp)/16) == 0
+  .if ((\sp)/16) == 0
     v_mov_b32_dpp v[\dst], v[\dst] row_shr:4 row_mask:0xf bank_mask:0xa
   .else
     v_mov_b32_dpp v[\dst], v[\dst] row_shl:4 row_mask:0xf bank_mask:0x5

@@ -115,4 +115,8 @@ n)  # hub rows: parity, then a power-law graph at config 4's size against SELL-8
   timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0 v:spmm_algo=0 2>&1 | grep "khop chain" | tee $O/khop_er.log
   bash tools/gpu_r6.sh m
   ;;
+q)  # SELL-8 against the sweep by size / degree / batch / width on the final kernel (DESIGN 3.1g "by size")
+  timeout 1400 python tools/msweep_sizes.py 50000,10,0,256 60000,10,0,128 80000,10,0,128 100000,10,0,128 100000,10,1,128 100000,10,0,100 100000,10,0,9 100000,20,0,64 100000,4,0,128 \
+      120000,10,0,128 150000,10,0,128 200000,10,0,64 100000,10,0,64,64 100000,10,0,32,128 2>&1 | grep "^N=" | tee $O/sizes.log
+  ;;
 esac

@@ -21,26 +21,28 @@ for kv in sys.argv[1:]:
     if "=" in kv:
         k, v = kv.split("="); tune(**{k: int(v)})
 if args:
-    cases = [tuple(int(x) for x in a.split(",")) for a in args]
+    cases = [tuple(int(x) for x in a.split(",")) for a in args]   # n,deg,weighted,B[,W]
 K = 5
-for n, deg, weighted, B in cases:
+for case in cases:
+    n, deg, weighted, B = case[:4]
+    W = case[4] if len(case) > 4 else 32
     A = graphgen.er(n, avg_degree=float(deg), seed=1)
     if weighted:
         A = sp.csr_matrix(A); A.data = np.random.RandomState(2).uniform(0.1, 1.0, A.data.size)
     gso = SparseGSO([sp.csr_matrix(A)])
     plans = gso.plans(dev)
-    Z = torch.empty(K, B, n, 32, device=dev); Z[0].normal_()
+    Z = torch.empty(K, B, n, W, device=dev); Z[0].normal_()
     ms = ctypes.c_float(); out = []
     ref = None
     for name, kw in (("sell", dict(spmm_algo=3)), ("msweep", dict(spmm_algo=5))):
         tune(**kw)
         Z[1:].fill_(float("nan"))
-        rc = L.gf_time_khop(plans, 1, 0, Z.data_ptr(), B, 32, K, 5, st, ctypes.byref(ms))
+        rc = L.gf_time_khop(plans, 1, 0, Z.data_ptr(), B, W, K, 5, st, ctypes.byref(ms))
         torch.cuda.synchronize()
         if rc != 0:
             out.append(f"{name}: n/a"); continue
         same = "" if ref is None else (" bitwise" if torch.equal(ref, Z[1:]) else " DIFFERENT")
         if ref is None: ref = Z[1:].clone()
         out.append(f"{name}: {ms.value / (K - 1):.4f} ms/hop{same}")
-    print(f"N={n} deg={deg} {'weighted' if weighted else 'uniform'} B={B} nnz={A.nnz}: " + "  ".join(out), flush=True)
+    print(f"N={n} deg={deg} {'weighted' if weighted else 'uniform'} B={B} W={W} nnz={A.nnz}: " + "  ".join(out), flush=True)
     del Z, ref, gso, plans
