@@ -151,8 +151,9 @@ struct gf_tuning {
     int spmm_algo = 0;          // 0 = default (the MFMA source sweep where gf_msweep_applicable says so, else SELL-8), 1 = CSR workgroup-staged kernel
                                 // (first version), 3 = SELL-8 always, 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED
     int spmm_bar = 0;           // MFMA sweep: XCD barrier between batch entries too (0 = only between the hops of an entry, where the next hop reads what this one stored)
-    int spmm_pfd = 3;           // MFMA sweep: scalar prefetch of the source rows this many loop iterations (of two rounds) ahead of the sweep's nominal position, 0 = off
-                                // (round 6: 3 = six rounds -- a row's first use comes up to ~5 rounds early; from 4 on the rows start to fall out of the 4 MiB L2 again)
+    int spmm_pfd = 0;           // MFMA sweep: scalar prefetch of the source rows this many loop iterations (of two rounds) ahead of the sweep's nominal position; 0 = auto:
+                                // (rounds + 7) / 14 -- a row's first use comes up to ~ rounds / 8 early (config 4: 42 rounds -> 3 iterations; from 4 on the rows start to
+                                // fall out of the 4 MiB L2 again; a degree-4 graph with 18 rounds wants 1, a degree-20 one with 84 rounds 6); -1 = off
     int spmm_passes = 2;        // MFMA sweep image: passes (sweeps of the sources) allowed per batch entry -- 1: N <= 102 400, 2: up to 204 800 (set BEFORE gf_plan_create)
     int spmm_census = 0;        // MFMA sweep, experiments (tests of the abandon-and-repair path): 1 = the census is called bad, 2 = one workgroup claims the
                                 // next XCC (a 33 / 31 census), 3 = one workgroup never arrives (the others run into the time limit: the slot is poisoned)

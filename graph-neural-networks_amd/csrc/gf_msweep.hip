@@ -723,7 +723,8 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
         trace = g_trace;
     }
     const bool wide = W != 32;                  // slabs of 32 columns: {row, column} addressing, no scalar prefetch
-    const bool pf = g_tune.spmm_pfd > 0 && !wide;
+    const int pfd = g_tune.spmm_pfd > 0 ? g_tune.spmm_pfd : (g_tune.spmm_pfd == 0 ? std::max(1, (m.ms_rounds + 7) / 14) : 0);
+    const bool pf = pfd > 0 && !wide;
     const bool deep = g_tune.spmm_depth != 5;   // ring of 10 gathers; 5: experiments
     // A fused chain depends on its XCD barriers (hop h + 1 gathers what hop h stored): it is launched COOPERATIVELY -- the runtime starts the
     // grid only when all 256 workgroups can be resident together -- and opens with the census (kernel); the repair kernel behind it runs
@@ -733,7 +734,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     const float* a_val = m.ms_val;
     const uint32_t* a_rows = m.ms_rows;
     size_t a_stride = (size_t)tapStride * 4;
-    int a_nhops = nhops, a_N = N, a_B = B, a_passes = m.ms_passes, a_rounds = m.ms_rounds, a_bar = use_barrier, a_pfd = g_tune.spmm_pfd,
+    int a_nhops = nhops, a_N = N, a_B = B, a_passes = m.ms_passes, a_rounds = m.ms_rounds, a_bar = use_barrier, a_pfd = pfd,
         a_nostore = g_tune.spmm_store == 3, a_census = chained ? 1 + (g_tune.spmm_census > 0 ? g_tune.spmm_census : 0) : 0;
     float a_uval = m.sell_uval;
     unsigned a_mask = src_mask;

@@ -266,7 +266,7 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * "spmm_algo" (0 = default: the MFMA source sweep (gf_msweep.hip) where it applies, else the SELL-8 wave kernel | 1 = CSR workgroup
  * kernel | 3 = SELL-8 always | 5 = the MFMA source sweep or GF_ERR_UNSUPPORTED where it does not apply), the sweep's own knobs:
  * "spmm_fuse" (0/1 the K-1 hops of gf_khop in one launch), "spmm_bar" (0/1 XCD barrier between batch entries too), "spmm_pfd" (scalar
- * prefetch lead in loop iterations, 0 = off), "spmm_depth" (0 = 10 gathers in flight | 5), "spmm_slack" / "spmm_passes" (image: rounds
+ * prefetch lead in loop iterations: 0 = auto from the image's rounds, -1 = off), "spmm_depth" (0 = 10 gathers in flight | 5), "spmm_slack" / "spmm_passes" (image: rounds
  * beyond the mean group length in percent, passes allowed per batch entry; read by gf_plan_create), timing-only: "spmm_srcmask",
  * "spmm_trace"; tests of the abandon-and-repair path: "spmm_census" (1 = census called bad | 2 = one workgroup claims the next XCC |
  * 3 = one workgroup never arrives), "spmm_tmo_ms" (time limit of census / barriers, 0 = 2000), "spmm_status_reset"; "spmm_xcd" (0/1),

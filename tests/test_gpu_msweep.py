@@ -27,7 +27,7 @@ def tune(**kw):
 @pytest.fixture
 def knobs():
     yield tune
-    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=3, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1)
+    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=0, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1)
 
 
 def hop(plans, op, Xt, algo, **kw):

@@ -119,4 +119,9 @@ q)  # SELL-8 against the sweep by size / degree / batch / width on the final ker
   timeout 1400 python tools/msweep_sizes.py 50000,10,0,256 60000,10,0,128 80000,10,0,128 100000,10,0,128 100000,10,1,128 100000,10,0,100 100000,10,0,9 100000,20,0,64 100000,4,0,128 \
       120000,10,0,128 150000,10,0,128 200000,10,0,64 100000,10,0,64,64 100000,10,0,32,128 2>&1 | grep "^N=" | tee $O/sizes.log
   ;;
+r)  # prefetch lead by graph degree (rounds): auto = (rounds + 7) / 14 against fixed leads
+  for c in 100000,4,0,128 100000,10,0,128 100000,20,0,64 60000,10,0,128; do
+    for l in 0 1 2 3 6 -1; do echo -n "pfd=$l  "; timeout 300 python tools/msweep_sizes.py $c spmm_pfd=$l 2>&1 | grep "^N="; done
+  done | tee $O/lead_by_degree.log
+  ;;
 esac
