@@ -8,11 +8,13 @@
 // other census (or a grid that does not become resident within the time limit) ends the launch without a store, and the repair
 // kernel queued behind it (spmm_msweep_repair_kernel, gated on the launch's flag) computes the chain row by row: slower, same bits,
 // no trap, no host synchronisation.  A single hop (no hand-over) keeps workgroup L on team L % 8: there a wrong guess costs speed only.
-// XCD x works through batch entries x, x + 8, ...: its 128 waves hold
+// XCD x works through the (batch entry, 32-column slab) pairs x, x + 8, ... (rows of 64 / 96 / 128 columns are 2 / 3 / 4 slabs of the same image,
+// addressed {row, column} through a strided buffer resource): its 128 waves hold
 // the entry's whole output (S sets x 32 rows x 32 features per wave) in accumulator registers, walk the entry's source rows together
 // (T rounds of S steps; a step = one 8-row gather + four v_mfma_f32_4x4x1_16b_f32) and store; the K - 1 hops of an entry run back to
 // back in one launch with an XCD barrier between them (hop h + 1 gathers what hop h stored -- with plain stores, so that the rows
-// stored last, the lowest row bands, are still in the XCD's L2 when the next hop's sweep starts with them).
+// stored last, the lowest row bands, are still in the XCD's L2 when the next hop's sweep starts with them).  Rows too long for a group (hub
+// rows, gf_msweep_image.h) are summed by the waves between store phase and hand-over, in compiler code (template HUB).
 //
 // The body of a (batch entry, pass) is ONE inline-asm block written with assembler macros (MS_* below): hipcc's scheduler and register
 // allocator cannot express this kernel -- given the same program as C++ with builtins it hoisted the gathers into vmcnt(0) groups,
@@ -31,6 +33,8 @@
 // assembler from that order (MS_RLCOUNT).  Wait states the hardware does not interlock (VALU write -> MFMA read: 2; MFMA write ->
 // VALU / VMEM read: up to 19) are covered by distance: an A operand is written D steps before its MFMAs, the two DPP moves of an entry
 // have two MFMAs between them (VALU write -> DPP read: 2), accumulators are read only after the loop (s_nop block in MS_BODY).
+// The store phase zeroes each accumulator behind its read: the body's registers carry state between asm statements, and
+// tools/check_msweep_isa.py (a CPU test) fails the build when a compiler-emitted instruction names one of them or anything spills.
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
