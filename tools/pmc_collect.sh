@@ -13,8 +13,8 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum T
   echo "pmc$i $? $c" >> $O/passes.txt           # (rocprofv3 on this image often dies at tool teardown, after the CSV is complete: the exit code is recorded, the rows are counted below)
 done
 if [ "$KN" = spmm_msweep_kernel ]; then   # calibration pass: the same launch without the scalar prefetch (whose 64-byte requests the x2 rule counts as 128-byte ones)
-  GFHIP_EXPERIMENTS=1 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum --output-format csv -d $O/pmc_nopf -o pmc -- python tools/hop_probe.py $WL 3 spmm_pfd=0 > $O/pmc_nopf.log 2>&1
-  echo "pmc_nopf $? TCC_EA0_RDREQ_sum(spmm_pfd=0)" >> $O/passes.txt
+  GFHIP_EXPERIMENTS=1 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum --output-format csv -d $O/pmc_nopf -o pmc -- python tools/hop_probe.py $WL 3 spmm_pfd=-1 > $O/pmc_nopf.log 2>&1
+  echo "pmc_nopf $? TCC_EA0_RDREQ_sum(spmm_pfd=-1)" >> $O/passes.txt
 fi
 python - "$WL" "$KN" "$TAG" "$O" <<'PY'
 import csv, glob, collections, json, sys
