@@ -171,3 +171,64 @@ def test_config5_full_size_against_oracle():
                 u = Phi.T @ u + d
             dxo[g] += wd_all[f, g] * u
     assert relerr(x.grad[bsel].cpu().numpy(), dxo) < GRAD_RTOL
+
+
+def test_wide_layer_at_config4_size_against_oracle():
+    """The widths of BASELINE configs[2]'s second layer (64 -> 32, movieGNN's F = [1, 64, 32], reference examples/movieGNN.py:259-276) on
+    config 4's graph: the forward hops move 64-column rows (round 6: two slabs of the sweep's image), the adjoint hops 32-column rows.
+    The DEFAULT path (this test also runs in the product configuration), y / dx on two batch entries, dh / db on the whole batch."""
+    N, B, G, F, K = 100_000, 8, 64, 32, 3
+    A = graphgen.er(N, seed=0)
+    torch.manual_seed(4)
+    layer = gml.GraphFilter(G, F, K, 1, True)
+    layer.addGSO(A)
+    layer.to(DEV)
+    plans = layer._gso.plans(DEV)
+    assert _lib.lib().gf_lsigf_pipeline(plans, 1, G, F, K) == 1
+    assert _lib.lib().gf_spmm_hop_kernel(plans[0], 0, B, G) == 1 and _lib.lib().gf_spmm_hop_kernel(plans[0], 1, B, F) == 1   # the sweep, both ways
+    x = torch.randn(B, G, N, device=DEV, requires_grad=True)
+    y = layer(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    w, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+    sl = [0, 7]
+    xs, dys = x.detach()[sl].cpu().numpy(), dy[sl].cpu().numpy()
+    assert relerr(y.detach()[sl].cpu().numpy(), orc.lsigf_sparse(w, A, xs, b)) < FWD_RTOL
+    dx, _, _ = orc.lsigf_sparse_grads(w, A, xs, b, dys)
+    assert relerr(x.grad[sl].cpu().numpy(), dx) < GRAD_RTOL
+    dh, db = streamed_tap_grads(w, A, x.detach().cpu().numpy(), dy.cpu().numpy(), chunk=4)
+    assert relerr(layer.weight.grad.cpu().numpy(), dh) < GRAD_RTOL
+    assert relerr(layer.bias.grad.cpu().numpy(), db) < GRAD_RTOL
+
+
+def test_power_law_graph_at_config4_size_against_oracle():
+    """A directed graph whose out-degrees have a Barabasi-Albert tail (rows of hundreds of entries among rows of five): the sweep's image leaves
+    the long rows out of its groups and the waves sum them separately (round 6, hub rows; the longest ones as 32 partial chains).  Default path,
+    forward and backward (the two orientations: one with hub rows, one without), against the float64 oracle."""
+    N, B, G, F, K = 100_000, 8, 32, 32, 3
+    rng = np.random.RandomState(12)
+    deg = np.minimum(N // 8, (5.0 / np.sqrt(np.maximum(rng.uniform(size=N), 1e-9))).astype(np.int64))
+    r = np.repeat(np.arange(N), deg)
+    A = sp.csr_matrix((np.ones(r.size), (r, rng.randint(0, N, size=r.size))), shape=(N, N))
+    A.sum_duplicates()
+    A.data[:] = 1.0 / 64.0
+    A = sp.csr_matrix(A)
+    torch.manual_seed(5)
+    layer = gml.GraphFilter(G, F, K, 1, True)
+    layer.addGSO(A)
+    layer.to(DEV)
+    plans = layer._gso.plans(DEV)
+    assert _lib.lib().gf_spmm_hop_kernel(plans[0], 0, B, G) == 1 and _lib.lib().gf_spmm_hop_kernel(plans[0], 1, B, F) == 1
+    x = torch.randn(B, G, N, device=DEV, requires_grad=True)
+    y = layer(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    w, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+    sl = [0, 5]
+    xs, dys = x.detach()[sl].cpu().numpy(), dy[sl].cpu().numpy()
+    assert relerr(y.detach()[sl].cpu().numpy(), orc.lsigf_sparse(w, A, xs, b)) < FWD_RTOL
+    dx, _, _ = orc.lsigf_sparse_grads(w, A, xs, b, dys)
+    assert relerr(x.grad[sl].cpu().numpy(), dx) < GRAD_RTOL
+    dh, db = streamed_tap_grads(w, A, x.detach().cpu().numpy(), dy.cpu().numpy(), chunk=4)
+    assert relerr(layer.weight.grad.cpu().numpy(), dh) < GRAD_RTOL
+    assert relerr(layer.bias.grad.cpu().numpy(), db) < GRAD_RTOL
