@@ -124,4 +124,13 @@ r)  # prefetch lead by graph degree (rounds): auto = (rounds + 7) / 14 against f
     for l in 0 1 2 3 6 -1; do echo -n "pfd=$l  "; timeout 300 python tools/msweep_sizes.py $c spmm_pfd=$l 2>&1 | grep "^N="; done
   done | tee $O/lead_by_degree.log
   ;;
+u)  # (NO-GO, code not kept: git stash of this session) prefetch pattern per hop as a RUNTIME mask (s_bitcmp + branch per step, one row slot per step):
+    # first hop of an entry (rows from HBM) x later hops (rows from the Infinity Cache), against the previous commit's library: every pattern slower
+  for rep in 1 2; do
+    GFHIP_LIB=$LIBD/libgfhip_prev.so timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0 v:spmm_algo=0 2>&1 | grep "khop chain" | sed 's/^/prev /;s/bitwise.*//' | tee -a $O/patterns.log
+    V="v:spmm_algo=0+spmm_pfpat0=119+spmm_pfpat1=119"
+    for p1 in 119 255 127 85; do for p0 in 255 119 85 17 0; do V="$V v:spmm_pfpat0=$p0+spmm_pfpat1=$p1"; done; done
+    timeout 400 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "khop chain" | sed 's/^/new  /;s/bitwise.*//' | tee -a $O/patterns.log
+  done
+  ;;
 esac
