@@ -151,9 +151,14 @@ static int lsigf_forward_impl(const gf_plan* const* plans, int32_t E, const floa
         return gf_contract_panel_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream),
                                         (lx & 4) ? 1 : 0, nullptr);
     }
-    int rc = (lx & 2) ? GF_OK : gf_layout_bgn_to_bng(x, Z, B, G, Nin, N, stream);
-    if (rc != GF_OK) return rc;
-    rc = gf_khop(plans, E, GF_OP_FWD, Z, B, G, K, stream);
+    // large graphs, 32 columns, one edge feature: the layout pass rides in the fused chain launch (each XCD writes an entry's tap 0 right before it
+    // walks the entry: gf_msweep.hip); everything else: layout kernel, then the hops
+    int rc = (!(lx & 2) && E == 1) ? gf_khop_with_layout(plans[0], GF_OP_FWD, x, nullptr, Z, B, G, K, Nin, gf_stream(stream)) : GF_ERR_UNSUPPORTED;
+    if (rc == GF_ERR_UNSUPPORTED) {
+        rc = (lx & 2) ? GF_OK : gf_layout_bgn_to_bng(x, Z, B, G, Nin, N, stream);
+        if (rc != GF_OK) return rc;
+        rc = gf_khop(plans, E, GF_OP_FWD, Z, B, G, K, stream);
+    }
     if (rc != GF_OK) return rc;
     return gf_contract_launch(Z, h, bias, y, B, N, Nin, G, F, E, K, /*transpose_bank | relu << 1=*/relu << 1, gf_stream(stream),
                               (lx & 4) ? 1 : 0, nullptr);
@@ -208,7 +213,12 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
         return rc;
     }
     // P[0] = dy, node-major, rows >= Nin zero -- unless the next layer's backward already wrote it there (lx bit 1)
-    int rc = (lx & 2) ? GF_OK
+    // (as in the forward: where the adjoint chain is one fused sweep launch, dy's layout pass -- and the ReLU mask -- ride in it)
+    const bool chain_first = dx && ((dh && g_tune.bwd_fuse && gf_bwd_fused_supported(G, F, E, K)) || !(dh || dbias));   // the hops are the first consumer of P[0]
+    int rc = (!(lx & 2) && E == 1 && chain_first) ? gf_khop_with_layout(plans[0], GF_OP_BWD, dy, y_relu, P, B, F, K, Nin, gf_stream(stream)) : GF_ERR_UNSUPPORTED;
+    const bool hopped = rc == GF_OK;
+    if (rc == GF_ERR_UNSUPPORTED)
+        rc = (lx & 2) ? GF_OK
              : y_relu ? gf_layout_masked_launch(dy, y_relu, P, B, F, Nin, N, gf_stream(stream))
                       : gf_layout_bgn_to_bng(dy, P, B, F, Nin, N, stream);
     if (rc != GF_OK) return rc;
@@ -217,7 +227,7 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
         // one pass over the adjoint stack for dx and dh (dh_t = X0^T P_t), as in the panel pipeline: the separate tap-gradient kernel
         // re-reads the whole forward stack (8.2 GB at config 4)
         GF_REQUIRE_ARG(Z != nullptr, "gf_lsigf_backward: the saved tap stack Z is required for dh");
-        rc = gf_khop(plans, E, GF_OP_BWD, P, B, F, K, stream);
+        rc = hopped ? GF_OK : gf_khop(plans, E, GF_OP_BWD, P, B, F, K, stream);
         if (rc != GF_OK) return rc;
         return gf_bwd_fused_panel_launch(P, Z, h, dx, dh, dbias, workspace, workspace_bytes, B, N, Nin, G, F, E, K, gf_stream(stream),
                                          /*node_major=*/1, dxr, dx_mask);
@@ -228,7 +238,7 @@ static int lsigf_backward_impl(const gf_plan* const* plans, int32_t E, const flo
         if (rc != GF_OK) return rc;
     }
     if (dx) {
-        rc = gf_khop(plans, E, GF_OP_BWD, P, B, F, K, stream);
+        rc = hopped ? GF_OK : gf_khop(plans, E, GF_OP_BWD, P, B, F, K, stream);
         if (rc != GF_OK) return rc;
         rc = gf_contract_launch(P, h, nullptr, dx, B, N, Nin, G, F, E, K, /*transpose_bank=*/1, gf_stream(stream), dxr, dx_mask);
     }

@@ -155,6 +155,7 @@ struct gf_tuning {
                                 // (rounds + 7) / 14 -- a row's first use comes up to ~ rounds / 8 early (config 4: 42 rounds -> 3 iterations; from 4 on the rows start to
                                 // fall out of the 4 MiB L2 again; a degree-4 graph with 18 rounds wants 1, a degree-20 one with 84 rounds 6); -1 = off
     int spmm_passes = 2;        // MFMA sweep image: passes (sweeps of the sources) allowed per batch entry -- 1: N <= 102 400, 2: up to 204 800 (set BEFORE gf_plan_create)
+    int spmm_xlayout = 1;       // MFMA sweep: the boundary layout pass (x / dy -> tap 0) inside the fused chain launch (32-column rows, one edge feature); 0 = separate kernel
     int spmm_census = 0;        // MFMA sweep, experiments (tests of the abandon-and-repair path): 1 = the census is called bad, 2 = one workgroup claims the
                                 // next XCC (a 33 / 31 census), 3 = one workgroup never arrives (the others run into the time limit: the slot is poisoned)
     int spmm_tmo_ms = 0;        // MFMA sweep, experiments: time limit of the census / the barriers in ms (0 = 2000)
@@ -198,7 +199,13 @@ extern gf_tuning g_tune;
 // internal launchers shared between translation units
 bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W);
 // nhops hops in one launch: hop h reads Xin (h = 0) or Xtaps + (h - 1) * tapStride floats and writes Xtaps + h * tapStride floats
-int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st);
+// xref != nullptr (W == 32): the boundary layout pass is part of the launch -- every batch entry's x[b][0..32)[0..Nin) (reference layout; xmask: entries
+// whose mask is <= 0 give 0) is written to Xin[b] as node-major rows (rows >= Nin zero) by the XCD that then walks the entry through its hops
+int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st,
+                     const float* xref = nullptr, const float* xmask = nullptr, int Nin = 0);
+// gf_khop for one edge feature with the layout pass folded into the launch where the sweep runs fused (else GF_ERR_UNSUPPORTED: the caller
+// runs the layout kernel and gf_khop)
+int gf_khop_with_layout(const gf_plan* plan, int op, const float* xref, const float* xmask, float* Z, int B, int W, int K, int Nin, hipStream_t st);
 size_t gf_msweep_gate_bytes();
 unsigned* gf_msweep_status_word();          // pinned host word the repair kernel reports into (allocated on first use: call at plan creation)
 bool gf_msweep_fusion_allowed();            // false once a launch had to be repaired, or with GFHIP_MSWEEP_FUSE=0

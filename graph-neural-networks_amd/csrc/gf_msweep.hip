@@ -316,13 +316,17 @@ MS_LOOP_\uid:
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int S, int UNI, int PF, int D, int IDX, int HUB>
+// PH: phases of compiler code around the asm bodies -- bit 0: hub rows (after the store phase), bit 1: the boundary layout pass x[B, 32, Nin] ->
+// tap 0 as a pre-phase of every batch entry (before its first hop).  Instantiations with PH != 0 zero their accumulators before every body.
+template <int S, int UNI, int PF, int D, int IDX, int PH>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restrict__ val, const uint32_t* __restrict__ rows,
                         const float* __restrict__ Xin, float* __restrict__ Xtaps, size_t tapStrideBytes, int nhops, int N, int B, int passes,
                         int rounds, unsigned* __restrict__ gate, int use_barrier, float uval, unsigned src_mask, int pf_lead,
                         int nostore, unsigned long long* __restrict__ trace, int census, unsigned tmo_ticks, int W,
-                        const uint32_t* __restrict__ hubpack) {
+                        const uint32_t* __restrict__ hubpack, const float* __restrict__ xref, const float* __restrict__ xmask, int Nin) {
+    constexpr int HUB = PH & 1, XP = (PH >> 1) & 1;
+    static_assert(XP == 0 || IDX == 0, "layout pre-phase: 32-column rows");
     constexpr int U = 2;                                    // rounds per loop iteration (the two entry buffers alternate by round parity)
     static_assert(IDX == 0 || PF == 0, "wide rows: no scalar prefetch");
     static_assert((U * S) % D == 0 && D < S && S <= kMsMaxSets && S <= 32,
@@ -331,6 +335,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                   "inside the two rounds of an iteration (12-bit instruction offsets)");
     __shared__ unsigned s_rows[kThreads / 64][S * 32];      // per wave: output byte offsets of (set, position, slot)
     __shared__ unsigned s_ctl[4];                           // census result {XCC, rank, abandoned}, [3] = a barrier timed out
+    __shared__ float s_tile[XP ? kThreads / 64 : 1][XP ? 32 * 65 : 1];   // layout pre-phase: per wave a 32 x 64 (+1) transpose tile
     asm volatile(".set GF_MS_NT_VALUE, " GF_MS_STR(GF_MS_NT) "\n\t.set GF_MS_STPLAIN_VALUE, " GF_MS_STR(GF_MS_STPLAIN)
                  "\n\t.set GF_MS_EXP_VALUE, " GF_MS_STR(GF_MS_EXP) "\n\t.set GF_MS_PFP_VALUE, " GF_MS_STR(GF_MS_PFP) "\n\t.set GF_MS_PFQ_VALUE, " GF_MS_STR(GF_MS_PFQ));
     asm volatile(GF_MS_MACROS);
@@ -409,6 +414,38 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
     // Batch entry b runs through all its hops before the XCD takes the next entry (hop h reads the tap hop h - 1 wrote: Xin for the
     // first, then Xtaps + (h - 1) taps; it writes Xtaps + h taps): the rows a hop gathers first were written by this XCD a moment ago
     // and are still in its L2 (the image stores the lowest row bands last).
+    // Team barrier (used between the hops of an entry, and behind the layout pre-phase): see the comment at its first use below.
+    auto team_barrier = [&](bool drain) -> bool {
+        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wv == 0) {
+            // ONE monotonic counter per team: arrival = fetch-add, the barrier opens when the count reaches the next multiple of 32 (exactly 32
+            // arrivals per barrier, so launches start on a multiple and nothing has to be reset; the last arriver is through after one L2
+            // round trip, the others after their next poll).  Wrap-around: compared as a signed difference.
+            unsigned t = 1u;
+            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ctr) : "memory");
+            if ((t & 31u) != 31u) {
+                const unsigned target = (t & ~31u) + 32u;
+                const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
+                bool open = false;
+                while (!open) {
+                    __builtin_amdgcn_s_sleep(2);
+                    unsigned v = 0u;
+                    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(ctr) : "memory");
+                    open = (int)(v - target) >= 0;
+                    if (!open && __builtin_amdgcn_s_memrealtime() - tb > (unsigned long long)tmo_ticks) break;
+                }
+                if (!open && lane == 0) {           // a team mate is gone: abandon the launch (the repair kernel redoes the whole chain)
+                    ag_store(cs + kCsPoison, 1u);
+                    ag_store(cs + kCsRepair, 1u);
+                    s_ctl[3] = 1u;
+                }
+            }
+        }
+        __syncthreads();
+        return s_ctl[3] == 0u;
+    };
+
     // Wide rows (IDX: W = 64 / 96 / 128 floats): a batch entry is W / 32 independent SLABS of 32 columns -- the same image, the same
     // sums; a gather addresses {row, slab column} through a buffer resource whose stride is the row (range check: row < N).  The XCD's
     // work list is the (entry, slab) pairs x, x + 8, ...
@@ -423,6 +460,58 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
         char* dst = reinterpret_cast<char*>(Xtaps) + (size_t)hop * tapStrideBytes;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)b * entryBytes), IDX ? (short)rowBytes : (short)0, IDX ? N : (int)tapBytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (size_t)b * entryBytes), IDX ? (short)rowBytes : (short)0, nostore ? 0 : (IDX ? N : (int)tapBytes), 0x00020000);
+        if constexpr (XP) {
+            if (hop == 0) {
+                // Boundary layout pass of this entry (graphML.py:2131-2135 zero-pad + the permute the reference does at :170): x[b][g][n] (reference layout,
+                // n < Nin) -> tap 0 rows X0[b][n][0..32), rows n >= Nin zero; xmask (backward behind a fused ReLU): entries whose mask is <= 0 give 0.
+                // The team's 128 waves take blocks of 64 nodes, HIGHEST first: the rows written last are the ones hop 0's sweep gathers first and
+                // are still in the XCD's L2 -- what made the later hops of an entry faster than its first.  Three blocks of loads in flight per
+                // wave; transposed through a wave-private LDS tile (LDS operations of one wave execute in order: no barrier).
+                // (loads through ONE buffer resource with per-lane byte offsets: 32 row base pointers in SGPRs, hoisted out of the block loop, would be
+                //  live across the asm bodies and spill; the row pitch passes through an opaque asm per block so that its multiples are not hoisted)
+                const size_t xbytes = (size_t)32u * (size_t)Nin * 4u;
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xref + (size_t)b * 32u * (size_t)Nin), 0, (int)xbytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)((xmask ? xmask : xref) + (size_t)b * 32u * (size_t)Nin), 0, (int)xbytes, 0x00020000);
+                const bool masked = xmask != nullptr;
+                float* tile = &s_tile[wv][0];
+                const int nblk = (N + 63) >> 6;
+                unsigned lx = lane;
+                asm volatile("; layout phase" : "+v"(lx));
+                const unsigned px = lx >> 3, fx = lx & 7u;
+                float va[32], vb[32], vc[32];
+                auto ld = [&](float (&v)[32], int blk) {
+                    unsigned pitch = (unsigned)Nin * 4u;
+                    asm volatile("" : "+s"(pitch));
+                    const int n = blk * 64 + (int)lx;
+                    unsigned off = (blk >= 0 && n < Nin) ? (unsigned)n * 4u : 0xfffffff0u;     // (out of range: the load returns 0 without a memory request)
+#pragma unroll
+                    for (int g = 0; g < 32; ++g) {
+                        float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+                        if (masked && !(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, off, 0, 0)) > 0.f)) t = 0.f;
+                        v[g] = t;
+                        off = off < 0xfffffff0u ? off + pitch : off;
+                    }
+                };
+                int blk = nblk - 1 - (int)wid;
+                ld(va, blk);
+                ld(vb, blk - kMsWavesPerXcd);
+                for (; blk >= 0; blk -= kMsWavesPerXcd) {
+                    ld(vc, blk - 2 * kMsWavesPerXcd);
+#pragma unroll
+                    for (int g = 0; g < 32; ++g) tile[g * 65 + lx] = va[g];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const unsigned r = (unsigned)it * 8u + px;
+                        f32x4 o;
+                        o.x = tile[(4 * fx + 0) * 65 + r], o.y = tile[(4 * fx + 1) * 65 + r], o.z = tile[(4 * fx + 2) * 65 + r], o.w = tile[(4 * fx + 3) * 65 + r];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, ((unsigned)blk * 64u + r) * 128u + fx * 16u, 0, 0);   // (range check: rows >= N dropped)
+                    }
+#pragma unroll
+                    for (int g = 0; g < 32; ++g) va[g] = vb[g], vb[g] = vc[g];
+                }
+                if (!team_barrier(true)) return;       // hop 0 gathers rows other CUs of the team stored
+            }
+        }
         for (int pass = 0; pass < passes; ++pass) {
             const size_t pw = (size_t)pass * kMsWavesPerXcd + wid;
             if (table_of != pass) {   // wave-private copy (LDS operations of one wave execute in order: no barrier)
@@ -439,7 +528,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             unsigned spfr = (unsigned)pf_lead * (U * chunkBytes) + wid * 128u, spfc = spfr < smaxpf ? spfr : smaxpf, sdummy;
             const char* xptr = src + (size_t)b * entryBytes;
             unsigned long long tl0, tl1;
-            if constexpr (HUB) asm volatile("MS_ZERO %0" ::"n"(S) : GF_MS_CLOBBERS);   // (the hub phase below is compiler code: it may have used any register)
+            if constexpr (PH != 0) asm volatile("MS_ZERO %0" ::"n"(S) : GF_MS_CLOBBERS);   // (the phases of compiler code may have used any register)
             if constexpr (PF) {
                 asm volatile("MS_BODY %20, %21, %22, 1, %23, %24, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
                              : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy), "=&s"(tl0), "=&s"(tl1)
@@ -550,34 +639,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                 // the team IS the set of workgroups on one XCC (census above), so counters and rows live in the one L2 they all use.  The
                 // census has seen all 256 workgroups resident; a barrier that still does not open within the time limit (a team mate died)
                 // abandons the launch the same way a bad census does.
-                if (dependent) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (wv == 0) {
-                    // ONE monotonic counter per team: arrival = fetch-add, the barrier opens when the count reaches the next multiple of 32 (exactly 32
-                    // arrivals per barrier, so launches start on a multiple and nothing has to be reset; the last arriver is through after one L2
-                    // round trip, the others after their next poll).  Wrap-around: compared as a signed difference.
-                    unsigned t = 1u;
-                    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ctr) : "memory");
-                    if ((t & 31u) != 31u) {
-                        const unsigned target = (t & ~31u) + 32u;
-                        const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
-                        bool open = false;
-                        while (!open) {
-                            __builtin_amdgcn_s_sleep(2);
-                            unsigned v = 0u;
-                            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(ctr) : "memory");
-                            open = (int)(v - target) >= 0;
-                            if (!open && __builtin_amdgcn_s_memrealtime() - tb > (unsigned long long)tmo_ticks) break;
-                        }
-                        if (!open && lane == 0) {           // a team mate is gone: abandon the launch (the repair kernel redoes the whole chain)
-                            ag_store(cs + kCsPoison, 1u);
-                            ag_store(cs + kCsRepair, 1u);
-                            s_ctl[3] = 1u;
-                        }
-                    }
-                }
-                __syncthreads();
-                if (s_ctl[3]) return;
+                if (!team_barrier(dependent)) return;
             }
             const int slot = ((ve >> 3) * nhops + hop) * passes + pass;   // (entry, hop, pass) bodies done by this XCD
             if (trace && wid == 0 && lane == 0 && slot < 64) {    // (experiments) phase stamps of the XCD's first wave: previous stores drained + entries
@@ -597,8 +659,25 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
 __global__ __launch_bounds__(512) void spmm_msweep_repair_kernel(unsigned* __restrict__ cs, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                  const float* __restrict__ val, const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
                                                                  float* __restrict__ Xtaps, size_t tapStride, int nhops, int N, int B, int W, int uniform, float uval,
-                                                                 unsigned* __restrict__ status) {
+                                                                 unsigned* __restrict__ status, const float* __restrict__ xref, const float* __restrict__ xmask, int Nin) {
     if (ag_load(cs + kCsRepair) == 0u) return;
+    if (xref)   // the abandoned launch would have written tap 0 itself (layout pre-phase): x[b][g][n] -> X0[b][n][g], rows >= Nin zero, masked
+        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+            float* x0 = const_cast<float*>(Xin) + (size_t)b * N * W;
+            for (int64_t idx = threadIdx.x; idx < (int64_t)N * W; idx += blockDim.x) {
+                const int n = (int)(idx / W), g = (int)(idx - (int64_t)n * W);
+                float t = 0.f;
+                if (n < Nin) {
+                    const size_t at = ((size_t)b * W + g) * (size_t)Nin + n;
+                    t = xref[at];
+                    if (xmask && !(xmask[at] > 0.f)) t = 0.f;
+                }
+                x0[idx] = t;
+            }
+            __syncthreads();
+            __threadfence();
+            __syncthreads();
+        }
     const int W4 = W >> 2;                                  // float4 columns per row
     for (int b = blockIdx.x; b < B; b += gridDim.x)
         for (int hop = 0; hop < nhops; ++hop) {
@@ -715,7 +794,8 @@ bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W) {
            cu_count() == 256 && B * (W / 32) >= 8 && (int64_t)N * 128 < (int64_t)kMsPad;
 }
 
-int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st) {
+int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st,
+                     const float* xref, const float* xmask, int Nin) {
     unsigned* gate = m.ms_gate + (size_t)slot_of(st) * kMsSlotWords;
     const int use_barrier = g_tune.spmm_bar;
     dim3 grid(256), block(kThreads);
@@ -733,7 +813,8 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     // A fused chain depends on its XCD barriers (hop h + 1 gathers what hop h stored): it is launched COOPERATIVELY -- the runtime starts the
     // grid only when all 256 workgroups can be resident together -- and opens with the census (kernel); the repair kernel behind it runs
     // only if the sweep abandoned the launch.  A single hop has no such dependence and takes the plain launch.
-    const bool chained = nhops > 1 || use_barrier;
+    const bool chained = nhops > 1 || use_barrier || xref != nullptr;   // (the layout pre-phase hands rows over inside the team too)
+    GF_REQUIRE_ARG(xref == nullptr || W == 32, "gf_msweep_launch: the layout pre-phase takes 32-column rows");
     const uint32_t* a_ent = m.ms_ent;
     const float* a_val = m.ms_val;
     const uint32_t* a_rows = m.ms_rows;
@@ -744,13 +825,17 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     unsigned a_mask = src_mask;
     int a_W = W;
     const uint32_t* a_hub = m.ms_hub;
+    int a_Nin = Nin;
     unsigned a_tmo = (unsigned)(g_tune.spmm_tmo_ms > 0 ? g_tune.spmm_tmo_ms : 2000) * 100000u;   // s_memrealtime ticks (100 MHz)
     void* args[] = {&a_ent, &a_val, &a_rows, &Xin, &Xtaps, &a_stride, &a_nhops, &a_N, &a_B, &a_passes, &a_rounds, &gate, &a_bar, &a_uval, &a_mask,
-                    &a_pfd, &a_nostore, &trace, &a_census, &a_tmo, &a_W, &a_hub};
+                    &a_pfd, &a_nostore, &trace, &a_census, &a_tmo, &a_W, &a_hub, &xref, &xmask, &a_Nin};
     hipError_t lerr = hipSuccess;
 #define GF_MS(SV, UV, PV, DV, XV) \
     do {                                                                                                                               \
-        if (m.ms_hub) GF_MSH(SV, UV, PV, DV, XV, 1);                                                                                   \
+        if (xref && (XV) == 0) {                                                                                                       \
+            if (m.ms_hub) GF_MSH(SV, UV, PV, DV, 0, 3);                                                                                \
+            else GF_MSH(SV, UV, PV, DV, 0, 2);                                                                                         \
+        } else if (m.ms_hub) GF_MSH(SV, UV, PV, DV, XV, 1);                                                                            \
         else GF_MSH(SV, UV, PV, DV, XV, 0);                                                                                            \
     } while (0)
 #define GF_MSH(SV, UV, PV, DV, XV, HV)                                                                                                    \
@@ -759,7 +844,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
             lerr = hipLaunchCooperativeKernel((const void*)spmm_msweep_kernel<SV, UV, PV, DV, XV, HV>, grid, block, args, 0, st); \
         else                                                                                                                           \
             hipLaunchKernelGGL((spmm_msweep_kernel<SV, UV, PV, DV, XV, HV>), grid, block, 0, st, a_ent, a_val, a_rows, Xin, Xtaps, a_stride, a_nhops, a_N, a_B, \
-                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_nostore, trace, a_census, a_tmo, a_W, a_hub); \
+                               a_passes, a_rounds, gate, a_bar, a_uval, a_mask, a_pfd, a_nostore, trace, a_census, a_tmo, a_W, a_hub, xref, xmask, a_Nin); \
     } while (0)
 #define GF_MS_P(SV, UV, DV)                            \
     do {                                              \
@@ -795,7 +880,7 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     GF_LAUNCH_CHECK("spmm_msweep_kernel");
     if (chained && !a_nostore && src_mask == 0xffffffffu) {
         hipLaunchKernelGGL(spmm_msweep_repair_kernel, dim3((unsigned)(B < 512 ? B : 512)), dim3(512), 0, st, gate + kMsCensusWord, m.rowptr, m.col, m.val, m.rowid,
-                           Xin, Xtaps, (size_t)tapStride, nhops, N, B, W, m.ms_uniform, m.sell_uval, g_status.load());
+                           Xin, Xtaps, (size_t)tapStride, nhops, N, B, W, m.ms_uniform, m.sell_uval, g_status.load(), xref, xmask, Nin);
         GF_LAUNCH_CHECK("spmm_msweep_repair_kernel");
     }
     return GF_OK;

@@ -68,6 +68,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_depth")) g_tune.spmm_depth = value;
     else if (!strcmp(key, "spmm_fuse")) g_tune.spmm_fuse = value;
     else if (!strcmp(key, "spmm_trace")) g_tune.spmm_trace = value;
+    else if (!strcmp(key, "spmm_xlayout")) g_tune.spmm_xlayout = value;
     else if (!strcmp(key, "spmm_census")) g_tune.spmm_census = value;
     else if (!strcmp(key, "spmm_tmo_ms")) g_tune.spmm_tmo_ms = value;
     else if (!strcmp(key, "spmm_status_reset")) gf_msweep_status_reset();

@@ -591,6 +591,12 @@ extern "C" int gf_khop(const gf_plan* const* plans, int32_t E, int32_t op, float
     return GF_OK;
 }
 
+int gf_khop_with_layout(const gf_plan* plan, int op, const float* xref, const float* xmask, float* Z, int B, int W, int K, int Nin, hipStream_t st) {
+    if (!(K > 1 && W == 32 && g_tune.spmm_fuse && g_tune.spmm_xlayout && gf_hop_uses_msweep(plan, op, B, W) && gf_msweep_fusion_allowed())) return GF_ERR_UNSUPPORTED;
+    const int64_t tap = (int64_t)B * plan->n * W;
+    return gf_msweep_launch(plan->mat[op], Z, Z + tap, tap, K - 1, plan->n, B, W, st, xref, xmask, Nin);
+}
+
 extern "C" int gf_time_khop(const gf_plan* const* plans, int32_t E, int32_t op, float* Z, int32_t B, int32_t W, int32_t K, int32_t iters,
                             void* stream, float* avg_ms) {
     GF_REQUIRE_ARG(avg_ms && iters > 0, "gf_time_khop: bad iters / NULL avg_ms");

@@ -27,7 +27,7 @@ def tune(**kw):
 @pytest.fixture
 def knobs():
     yield tune
-    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=0, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1)
+    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=0, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1, spmm_xlayout=1)
 
 
 def hop(plans, op, Xt, algo, **kw):
@@ -354,3 +354,42 @@ def test_msweep_hub_rows_are_computed_outside_the_groups(n, m, B, K, weighted, W
                 assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), (op, kw)
         det = khop_chain(plans, x0, K, op, spmm_algo=0, spmm_fuse=1)
         assert torch.equal(det, khop_chain(plans, x0, K, op, spmm_algo=0, spmm_fuse=1))      # run-to-run: bit for bit (fixed tree)
+
+
+@pytest.mark.parametrize("graph,n,B,K,Nin,act", [("er", 60000, 16, 4, 60000, None), ("er", 100000, 9, 3, 99000, "relu"), ("erw", 52000, 8, 3, 52000, "relu"),
+                                                ("powerlaw", 100000, 8, 3, 100000, None)])
+def test_layout_pass_inside_the_fused_chain_is_bitwise_the_separate_kernel(graph, n, B, K, Nin, act, knobs):
+    """Round 6: on large graphs (32-column rows, one edge feature) the boundary layout pass -- x [B,G,Nin] -> node-major tap 0, zero rows beyond
+    Nin (graphML.py:2131-2135), in the backward dy masked by the fused ReLU -- is a pre-phase of the fused chain launch: each XCD writes an entry's
+    tap 0 right before it walks the entry.  A pure data movement: the whole layer (y, dx, dh, db through the C ABI's gf_lsigf_forward / _backward,
+    plain and with the fused ReLU, Nin < N, a graph with hub rows) must come out bit for bit as with the separate layout kernel
+    (spmm_xlayout = 0), also when the launch is abandoned and repaired."""
+    from alegnn_amd import functional as F_
+    A = powerlaw(n, 5, seed=3) if graph == "powerlaw" else er(n, 4, seed=n, weighted=graph == "erw")
+    gso = SparseGSO([A])
+    torch.manual_seed(7)
+    h = (torch.randn(32, 1, K, 32, device=DEV) * 0.1).requires_grad_()
+    bias = (torch.randn(32, 1, device=DEV) * 0.1).requires_grad_()
+    x = torch.randn(B, 32, Nin, device=DEV, requires_grad=True)
+    dy = torch.randn(B, 32, Nin, device=DEV)
+
+    def run(**kw):
+        tune(**kw)
+        for t in (h, bias, x):
+            t.grad = None
+        y = F_.LSIGF(h, gso, x, bias, activation=act)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in (y, x.grad, h.grad, bias.grad)]
+
+    ref = run(spmm_algo=0, spmm_fuse=1, spmm_xlayout=0)
+    assert _lib.lib().gf_spmm_hop_kernel(gso.plans(DEV)[0], 0, B, 32) == 1
+    for rep in range(2):
+        got = run(spmm_xlayout=1)
+        for a, r, name in zip(got, ref, ("y", "dx", "dh", "db")):
+            assert torch.equal(a, r), (name, rep, int((a != r).sum()))
+    tune(spmm_status_reset=1)
+    got = run(spmm_xlayout=1, spmm_census=1)                # abandoned launches: the repair kernel lays tap 0 out itself
+    assert chain_status()[0] == 1
+    for a, r, name in zip(got, ref, ("y", "dx", "dh", "db")):
+        assert torch.equal(a, r), ("repaired", name, int((a != r).sum()))

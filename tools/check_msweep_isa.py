@@ -5,9 +5,9 @@ live values only in v0-v23.  This check compiles gf_msweep.hip to ISA and fails 
   * a compiler-emitted instruction (anything outside the ;;#ASMSTART ... ;;#ASMEND regions) names a vector register above v23 or any
     accumulator register -- the body keeps state there between (batch entry, hop) passes,
   * the kernel does not get the whole register file (.vgpr_count 512, .agpr_count 256: one wave per SIMD is what the image's geometry assumes).
-The instantiations with a hub phase (last template argument 1: compiler code that gathers and sums between two asm bodies, and re-zeroes the
-accumulators before every body) are exempt from the register rule and may spill a few registers in their cold paths (time-out, trace, row-table
-copy); they must still own the whole register file, and their spills are bounded (<= 32 each).
+The instantiations with phases of compiler code around the asm bodies (last template argument != 0: hub rows, the layout pre-phase; they re-zero
+the accumulators before every body) are exempt from the register rule and may spill a few registers in their cold paths (time-out, trace, row-table
+copy); they must still own the whole register file, and their spills are bounded (<= 48 each).
 Run by tests/test_host_logic.py::test_msweep_isa_register_contract (needs hipcc; no GPU)."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ LIMIT = int(os.environ.get("MS_ISA_LIMIT", "24"))                               
 
 def is_hub(name):
     a = re.findall(r"Li(\d+)E", name.split("spmm_msweep_kernelI", 1)[1])
-    return len(a) >= 6 and a[5] == "1"
+    return len(a) >= 6 and a[5] != "0"
 
 
 def main():
@@ -58,7 +58,7 @@ def main():
         seen += 1
         f = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|agpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", blk)}
         hub = is_hub(name)
-        lim = 32 if hub else 0
+        lim = 48 if hub else 0
         if f.get("vgpr_spill_count", 0) > lim or f.get("sgpr_spill_count", 0) > lim or (f.get("private_segment_fixed_size", 0) and not hub) or f.get("vgpr_count") != 512 or f.get("agpr_count") != 256:
             bad += 1
             print(f"{name[:60]}: {f}")

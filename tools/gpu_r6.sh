@@ -133,4 +133,8 @@ u)  # (NO-GO, code not kept: git stash of this session) prefetch pattern per hop
     timeout 400 python tools/hop_probe.py cfg4 10 $V 2>&1 | grep "khop chain" | sed 's/^/new  /;s/bitwise.*//' | tee -a $O/patterns.log
   done
   ;;
+w)  # the layout pass inside the fused chain launch: parity, then the step with and without it
+  timeout 900 python -m pytest tests/test_gpu_msweep.py -x -q -k "layout_pass" 2>&1 | tail -12 | tee $O/pytest_layout.log
+  for v in 1 0 1 0; do echo -n "spmm_xlayout=$v  "; timeout 300 python bench.py --no-cpu-baseline --steps 30 --warmup 5 --tune spmm_xlayout=$v 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"; done | tee $O/bench_xlayout.log
+  ;;
 esac
