@@ -504,7 +504,11 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                         const unsigned r = (unsigned)it * 8u + px;
                         f32x4 o;
                         o.x = tile[(4 * fx + 0) * 65 + r], o.y = tile[(4 * fx + 1) * 65 + r], o.z = tile[(4 * fx + 2) * 65 + r], o.w = tile[(4 * fx + 3) * 65 + r];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, ((unsigned)blk * 64u + r) * 128u + fx * 16u, 0, 0);   // (range check: rows >= N dropped)
+                        // (range check: rows >= N dropped.  Issued through asm: the compiler's wait-count pass then counts loads only -- with a store it
+                        //  can see pending it waits for vmcnt(0), i.e. for the two blocks of loads just issued, once per block; the s_nop: a 16-byte
+                        //  store reads its data registers up to two cycles after issue)
+                        const unsigned so = ((unsigned)blk * 64u + r) * 128u + fx * 16u;
+                        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(o), "v"(so), "s"(rs) : "memory");
                     }
 #pragma unroll
                     for (int g = 0; g < 32; ++g) va[g] = vb[g], vb[g] = vc[g];
@@ -659,7 +663,7 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
 __global__ __launch_bounds__(512) void spmm_msweep_repair_kernel(unsigned* __restrict__ cs, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                  const float* __restrict__ val, const int32_t* __restrict__ rowid, const float* __restrict__ Xin,
                                                                  float* __restrict__ Xtaps, size_t tapStride, int nhops, int N, int B, int W, int uniform, float uval,
-                                                                 unsigned* __restrict__ status, const float* __restrict__ xref, const float* __restrict__ xmask, int Nin) {
+                                                                 unsigned* __restrict__ status, const float* __restrict__ xref, const float* __restrict__ xmask, int Nin, int split_above) {
     if (ag_load(cs + kCsRepair) == 0u) return;
     if (xref)   // the abandoned launch would have written tap 0 itself (layout pre-phase): x[b][g][n] -> X0[b][n][g], rows >= Nin zero, masked
         for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -685,11 +689,31 @@ __global__ __launch_bounds__(512) void spmm_msweep_repair_kernel(unsigned* __res
             float* dst = Xtaps + (size_t)hop * tapStride + (size_t)b * N * W;
             for (int64_t idx = threadIdx.x; idx < (int64_t)N * W4; idx += blockDim.x) {
                 const int p = (int)(idx / W4), c4 = (int)(idx - (int64_t)p * W4) * 4;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int q = rowptr[p]; q < rowptr[p + 1]; ++q) {
-                    const float4 x = *reinterpret_cast<const float4*>(src + (size_t)col[q] * W + c4);
-                    const float v = uniform ? 1.f : val[q];
-                    acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
+                const int q0 = rowptr[p], q1 = rowptr[p + 1];
+                auto chain = [&](int a, int b2) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int q = a; q < b2; ++q) {
+                        const float4 x = *reinterpret_cast<const float4*>(src + (size_t)col[q] * W + c4);
+                        const float v = uniform ? 1.f : val[q];
+                        acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
+                    }
+                    return acc;
+                };
+                auto add4 = [](const float4& a, const float4& b2) { return make_float4(a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w); };
+                float4 acc;
+                if (split_above > 0 && q1 - q0 > split_above) {
+                    // a SPLIT hub row of the sweep (gf_msweep_image.h): 32 partial chains over contiguous runs of L entries, added octets first, then
+                    // the eight positions as a binary tree -- the sweep's order, so that a repaired launch has its bits
+                    const int L = (q1 - q0 + 31) / 32;
+                    float4 ps[8];
+                    for (int pp = 0; pp < 8; ++pp) {
+                        float4 t = chain(std::min(q1, q0 + (4 * pp) * L), std::min(q1, q0 + (4 * pp + 1) * L));
+                        for (int o = 1; o < 4; ++o) t = add4(t, chain(std::min(q1, q0 + (4 * pp + o) * L), std::min(q1, q0 + (4 * pp + o + 1) * L)));
+                        ps[pp] = t;
+                    }
+                    acc = add4(add4(add4(ps[0], ps[1]), add4(ps[2], ps[3])), add4(add4(ps[4], ps[5]), add4(ps[6], ps[7])));
+                } else {
+                    acc = chain(q0, q1);
                 }
                 if (uniform) { acc.x *= uval; acc.y *= uval; acc.z *= uval; acc.w *= uval; }
                 *reinterpret_cast<float4*>(dst + (size_t)rowid[p] * W + c4) = acc;
@@ -880,7 +904,8 @@ int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_
     GF_LAUNCH_CHECK("spmm_msweep_kernel");
     if (chained && !a_nostore && src_mask == 0xffffffffu) {
         hipLaunchKernelGGL(spmm_msweep_repair_kernel, dim3((unsigned)(B < 512 ? B : 512)), dim3(512), 0, st, gate + kMsCensusWord, m.rowptr, m.col, m.val, m.rowid,
-                           Xin, Xtaps, (size_t)tapStride, nhops, N, B, W, m.ms_uniform, m.sell_uval, g_status.load(), xref, xmask, Nin);
+                           Xin, Xtaps, (size_t)tapStride, nhops, N, B, W, m.ms_uniform, m.sell_uval, g_status.load(), xref, xmask, Nin,
+                           m.ms_hub ? std::max(m.ms_hub_limit, m.ms_hub_split) : 0);
         GF_LAUNCH_CHECK("spmm_msweep_repair_kernel");
     }
     return GF_OK;
