@@ -492,26 +492,36 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
                         off = off < 0xfffffff0u ? off + pitch : off;
                     }
                 };
-                int blk = nblk - 1 - (int)wid;
-                ld(va, blk);
-                ld(vb, blk - kMsWavesPerXcd);
-                for (; blk >= 0; blk -= kMsWavesPerXcd) {
-                    ld(vc, blk - 2 * kMsWavesPerXcd);
+                auto put = [&](const float (&v)[32], int blk) {   // one block through the wave's LDS tile, out as full 128-byte rows
 #pragma unroll
-                    for (int g = 0; g < 32; ++g) tile[g * 65 + lx] = va[g];
+                    for (int g = 0; g < 32; ++g) tile[g * 65 + lx] = v[g];
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
                         const unsigned r = (unsigned)it * 8u + px;
                         f32x4 o;
                         o.x = tile[(4 * fx + 0) * 65 + r], o.y = tile[(4 * fx + 1) * 65 + r], o.z = tile[(4 * fx + 2) * 65 + r], o.w = tile[(4 * fx + 3) * 65 + r];
                         // (range check: rows >= N dropped.  Issued through asm: the compiler's wait-count pass then counts loads only -- with a store it
-                        //  can see pending it waits for vmcnt(0), i.e. for the two blocks of loads just issued, once per block; the s_nop: a 16-byte
-                        //  store reads its data registers up to two cycles after issue)
+                        //  can see pending it waits for vmcnt(0), i.e. for the blocks of loads just issued; the s_nop: a 16-byte store reads its data
+                        //  registers up to two cycles after issue)
                         const unsigned so = ((unsigned)blk * 64u + r) * 128u + fx * 16u;
                         asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(o), "v"(so), "s"(rs) : "memory");
                     }
-#pragma unroll
-                    for (int g = 0; g < 32; ++g) va[g] = vb[g], vb[g] = vc[g];
+                };
+                // three register sets in rotation by code position (a copy between sets would wait for the loads it reads): two blocks of loads are in
+                // flight while the third is transposed and stored
+                constexpr int kStep = kMsWavesPerXcd;
+                int blk = nblk - 1 - (int)wid;
+                ld(va, blk);
+                ld(vb, blk - kStep);
+                for (; blk >= 0; blk -= 3 * kStep) {
+                    ld(vc, blk - 2 * kStep);
+                    put(va, blk);
+                    if (blk - kStep < 0) break;
+                    ld(va, blk - 3 * kStep);
+                    put(vb, blk - kStep);
+                    if (blk - 2 * kStep < 0) break;
+                    ld(vb, blk - 4 * kStep);
+                    put(vc, blk - 2 * kStep);
                 }
                 if (!team_barrier(true)) return;       // hop 0 gathers rows other CUs of the team stored
             }
