@@ -423,7 +423,10 @@ def filter_hop_roofline(L, plans, name, B, N, W, K, nnz, dev):
         if L.gf_spmm_hop_kernel(plans[0], 0, B, W) == 1:
             kern, hops = "spmm_msweep_kernel", K - 1
             note = ("the K-1 hops of gf_khop in ONE launch, batch entry by batch entry: an XCD holds an entry's output rows in its register "
-                    "files, its waves walk the source rows together (every row leaves HBM once per hop), fp32 MFMA scatter-accumulate")
+                    "files, its waves walk the source rows together (every row leaves HBM once per hop), fp32 MFMA scatter-accumulate.  This is the "
+                    "launch timed here and in the PMC summary (template arguments <.., 0, 0>).  In the timed STEP the layer's launches of the same kernel "
+                    "(<.., 0, 2> in a rocprofv3 kernel trace) also carry the boundary layout pass x / dy -> tap 0 as a pre-phase (round 6: 2 x B x N x W x 4 "
+                    "more algorithmic bytes per launch, ~0.3 ms longer) in place of the two separate layout kernels")
         else:
             kern, hops = "spmm_sell_kernel", 1
             ms.value /= (K - 1)
