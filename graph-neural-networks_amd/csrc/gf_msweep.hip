@@ -225,7 +225,7 @@ __device__ __forceinline__ unsigned ag_add(unsigned* p, unsigned v) { return __h
 .endm
 // S sets, ring depth D, two rounds per loop iteration (the entry buffers alternate by round parity; 2 S steps must be a multiple of D: ring
 // slots are static); scur = byte offset of the iteration's first round in the entry stream, sit = iterations left
-.macro MS_BODY S, UNI, IDX, PF, D, U, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, stl0, stl1, uid
+.macro MS_BODY S, UNI, IDX, PF, D, rs, ro, re, rv, vfg, vslot, vevoff, vrow, smask, suval, xptr, smaxpf, schunk, scur, sit, spfr, spfc, sdummy, stl0, stl1, uid
   MS_SETMAP \D
   .set MS_IDX, \IDX
   s_nop 4                                      // (an SGPR operand the compiler has just written with a VALU instruction -- v_readfirstlane / v_readlane -- needs five wait states before
@@ -544,17 +544,17 @@ void spmm_msweep_kernel(const uint32_t* __restrict__ ent, const float* __restric
             unsigned long long tl0, tl1;
             if constexpr (PH != 0) asm volatile("MS_ZERO %0" ::"n"(S) : GF_MS_CLOBBERS);   // (the phases of compiler code may have used any register)
             if constexpr (PF) {
-                asm volatile("MS_BODY %20, %21, %22, 1, %23, %24, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
+                asm volatile("MS_BODY %20, %21, %22, 1, %23, %7, %8, %9, %10, %11, %12, %13, %14, %15, %16, %17, %18, %19, %0, %1, %2, %3, %4, %5, %6, %="
                              : "+s"(scur), "+s"(sit), "+s"(spfr), "+s"(spfc), "=&s"(sdummy), "=&s"(tl0), "=&s"(tl1)
                              : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fgs), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
-                               "s"(xptr), "s"(smaxpf), "s"(U * chunkBytes), "n"(S), "n"(UNI), "n"(IDX), "n"(D), "n"(U)
+                               "s"(xptr), "s"(smaxpf), "s"(U * chunkBytes), "n"(S), "n"(UNI), "n"(IDX), "n"(D)
                              : GF_MS_CLOBBERS);
             } else {   // (no scalar prefetch: its six operands are not materialised)
                 (void)spfr; (void)spfc; (void)sdummy; (void)xptr; (void)smaxpf;
-                asm volatile("MS_BODY %15, %16, %17, 0, %18, %19, %4, %5, %6, %7, %8, %9, %10, %11, %12, %13, %14, %14, %14, %0, %1, %14, %14, %14, %2, %3, %="
+                asm volatile("MS_BODY %15, %16, %17, 0, %18, %4, %5, %6, %7, %8, %9, %10, %11, %12, %13, %14, %14, %14, %0, %1, %14, %14, %14, %2, %3, %="
                              : "+s"(scur), "+s"(sit), "=&s"(tl0), "=&s"(tl1)
                              : "s"(rs), "s"(ro), "s"(re), "s"(rv), "v"(fgs), "v"(slotbit), "v"(evoff), "v"(rowlds), "s"(smask), "s"(uval),
-                               "s"(0), "n"(S), "n"(UNI), "n"(IDX), "n"(D), "n"(U)
+                               "s"(0), "n"(S), "n"(UNI), "n"(IDX), "n"(D)
                              : GF_MS_CLOBBERS);
             }
             if constexpr (HUB) {
