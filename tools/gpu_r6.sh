@@ -137,4 +137,14 @@ w)  # the layout pass inside the fused chain launch: parity, then the step with 
   timeout 900 python -m pytest tests/test_gpu_msweep.py -x -q -k "layout_pass" 2>&1 | tail -12 | tee $O/pytest_layout.log
   for v in 1 0 1 0; do echo -n "spmm_xlayout=$v  "; timeout 300 python bench.py --no-cpu-baseline --steps 30 --warmup 5 --tune spmm_xlayout=$v 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"; done | tee $O/bench_xlayout.log
   ;;
+y)  # (NO-GO, code not kept) scalar prefetch of the wave's own entry stream (4 rounds ahead) on top of the row prefetch: A/B, interleaved processes, both positions
+  for rep in 1 2 3; do
+    for lib in nopfe "" pfe23; do
+      if [ -n "$lib" ]; then export GFHIP_LIB=$LIBD/libgfhip_$lib.so; else unset GFHIP_LIB; fi
+      timeout 300 python tools/hop_probe.py cfg4 10 v:spmm_algo=0 v:spmm_algo=0 2>&1 | grep "khop chain" | sed "s/^/${lib:-pfe34} /;s/bitwise.*//" | tee -a $O/ab.log
+    done
+  done
+  unset GFHIP_LIB
+  timeout 900 python -m pytest tests/test_gpu_msweep.py -x -q 2>&1 | tail -3 | tee $O/pytest_msweep.log
+  ;;
 esac
