@@ -96,6 +96,8 @@ int main(int argc, char** argv) {
     }
     bad += check(100000, 10.0, -1, 9, 1, true, 5, 1, true);    // power-law degrees: hub rows computed outside the groups
     bad += check(60000, 8.0, -1, 10, 2, false, 5, 1);
+    bad += check(50000, 200.0, 0, 12, 1, true, 5, 1);          // every row long: no hub rows, many rounds
+    bad += check(52000, 2.0, 40, 13, 2, false, 5, 1);          // very sparse with 40 rows of 60 .. 1620 entries
     bad += check(1, 0.0, 0, 1, 2, true, 15, 1);             // (10 sets is the smallest geometry)
     bad += check(203, 6.0, 0, 2, 2, false, 15, 1);
     bad += check(4099, 10.0, 3, 3, 2, true, 15, 1);
