@@ -74,7 +74,7 @@ struct MsweepImage {
 // (the kernel sums the gathered rows and scales once, as spmm_sell_kernel<UNI = 1> does).  slack_pct: rounds beyond the MEAN
 // group length, in percent -- the room the placement has to keep round ~ source (config 4: 5 % -> T = 42 for groups of 39.1: measured best).
 inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const int32_t* col, const float* val, bool uniform,
-                                      int32_t slack_pct = 15, int32_t max_passes = 1) {
+                                      int32_t slack_pct = 15, int32_t max_passes = 1, int32_t force_hub_limit = 0) {
     MsweepImage im;
     if (n <= 0 || (int64_t)n * 128 >= (int64_t)kMsPad) return im;
     // Hub rows: candidates for the limit are multiples of the mean group length; the cost of a candidate = steps of the sweep (rounds x sets:
@@ -103,6 +103,7 @@ inline MsweepImage build_msweep_image(int32_t n, const int32_t* rowptr, const in
             const double cost = T * kMsMaxSets + 3.0 * hubsteps / kMsWavesPerXcd;
             if (hub_limit == 0 || cost < best) best = cost, hub_limit = H;
         }
+        if (force_hub_limit > 0) hub_limit = force_hub_limit;      // (experiments: the cost model's choice against fixed limits)
     }
     int32_t n_in = 0;                                // rows in groups
     int64_t e_in = 0;

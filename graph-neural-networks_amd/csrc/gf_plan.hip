@@ -69,6 +69,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_fuse")) g_tune.spmm_fuse = value;
     else if (!strcmp(key, "spmm_trace")) g_tune.spmm_trace = value;
     else if (!strcmp(key, "spmm_xlayout")) g_tune.spmm_xlayout = value;
+    else if (!strcmp(key, "spmm_hublim")) g_tune.spmm_hublim = value;
     else if (!strcmp(key, "spmm_census")) g_tune.spmm_census = value;
     else if (!strcmp(key, "spmm_tmo_ms")) g_tune.spmm_tmo_ms = value;
     else if (!strcmp(key, "spmm_status_reset")) gf_msweep_status_reset();
@@ -430,7 +431,7 @@ int upload_csr(int32_t n, const HostCsr& a, bool sorted, const std::vector<int32
     // process builds it only where the default hop uses it (kMsDefaultMinNodes); between kMsMinNodes and there the kernel can only be
     // asked for through gf_tune (spmm_algo = 5), i.e. in GFHIP_EXPERIMENTS=1 processes -- only those pay for that image.
     if (n >= (g_experiments ? kMsMinNodes : kMsDefaultMinNodes)) {
-        MsweepImage ms = build_msweep_image(n, a.rowptr.data(), a.col.data(), a.val.data(), uni, g_tune.spmm_slack, g_tune.spmm_passes > 0 ? g_tune.spmm_passes : 1);
+        MsweepImage ms = build_msweep_image(n, a.rowptr.data(), a.col.data(), a.val.data(), uni, g_tune.spmm_slack, g_tune.spmm_passes > 0 ? g_tune.spmm_passes : 1, g_tune.spmm_hublim);
         d.ms_fill = ms.fill();
         if (ms.passes >= 1 && ms.passes <= 2 && ms.fill() >= 0.6 && ms.hub_entries * 5 <= (int64_t)a.rowptr[n] * 2) {   // (hub rows: at most 40 % of the entries)
             d.ms_hub_rows = ms.hub_rows;

@@ -393,3 +393,28 @@ def test_layout_pass_inside_the_fused_chain_is_bitwise_the_separate_kernel(graph
     assert chain_status()[0] == 1
     for a, r, name in zip(got, ref, ("y", "dx", "dh", "db")):
         assert torch.equal(a, r), ("repaired", name, int((a != r).sum()))
+
+
+def test_two_edge_features_on_a_large_graph_are_bitwise_sell(knobs):
+    """E = 2 (graphML.py:154: tap 0 shared, K - 1 taps per edge feature): two fused chains per layer call, each on its own plan and gate; the
+    whole layer (y, dx, dh, db) bit for bit what the SELL-8 hops give."""
+    from alegnn_amd import functional as F_
+    n = 60000
+    gso = SparseGSO([er(n, 4, seed=1), er(n, 4, seed=2)])
+    torch.manual_seed(0)
+    h = (torch.randn(32, 2, 3, 32, device=DEV) * 0.1).requires_grad_()
+    b = torch.zeros(32, 1, device=DEV, requires_grad=True)
+    x = torch.randn(8, 32, n, device=DEV, requires_grad=True)
+    dy = torch.randn(8, 32, n, device=DEV)
+    outs = []
+    for algo in (3, 0):
+        tune(spmm_algo=algo)
+        for t in (h, b, x):
+            t.grad = None
+        y = F_.LSIGF(h, gso, x, b)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        outs.append([t.detach().clone() for t in (y, x.grad, h.grad, b.grad)])
+    assert _lib.lib().gf_spmm_hop_kernel(gso.plans(DEV)[0], 0, 8, 32) == 1
+    for a, r, name in zip(outs[1], outs[0], ("y", "dx", "dh", "db")):
+        assert torch.equal(a, r), name

@@ -147,4 +147,10 @@ y)  # (NO-GO, code not kept) scalar prefetch of the wave's own entry stream (4 r
   unset GFHIP_LIB
   timeout 900 python -m pytest tests/test_gpu_msweep.py -x -q 2>&1 | tail -3 | tee $O/pytest_msweep.log
   ;;
+z)  # hub rows: the cost model's length limit against fixed ones (power-law graph at config 4's size, B = 128)
+  for lim in 0 12 16 20 27 35 45 60 90 150; do
+    echo -n "spmm_hublim=$lim  " | tee -a $O/hublim.log
+    PROBE_GRAPH=powerlaw timeout 300 python tools/hop_probe.py cfg4 5 spmm_hublim=$lim v:spmm_algo=0 v:spmm_algo=0 2>&1 | grep "khop chain\|image" | sed 's/khop chain cfg4 K=5 //;s/bitwise.*//' | tr '\n' ' ' | tee -a $O/hublim.log; echo | tee -a $O/hublim.log
+  done
+  ;;
 esac
