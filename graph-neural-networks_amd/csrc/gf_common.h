@@ -157,6 +157,7 @@ struct gf_tuning {
     int spmm_passes = 2;        // MFMA sweep image: passes (sweeps of the sources) allowed per batch entry -- 1: N <= 102 400, 2: up to 204 800 (set BEFORE gf_plan_create)
     int spmm_xlayout = 1;       // MFMA sweep: the boundary layout pass (x / dy -> tap 0) inside the fused chain launch (32-column rows, one edge feature); 0 = separate kernel
     int spmm_hublim = 0;        // MFMA sweep image, experiments: rows longer than this are hub rows (0 = the builder's cost model; set BEFORE gf_plan_create)
+    int spmm_minwork = 5;       // MFMA sweep: fewest (batch entry, 32-column slab) pairs it takes (fewer: SELL-8 is faster -- an XCD walks a pair in ~65 us per hop alone or not)
     int spmm_census = 0;        // MFMA sweep, experiments (tests of the abandon-and-repair path): 1 = the census is called bad, 2 = one workgroup claims the
                                 // next XCC (a 33 / 31 census), 3 = one workgroup never arrives (the others run into the time limit: the slot is poisoned)
     int spmm_tmo_ms = 0;        // MFMA sweep, experiments: time limit of the census / the barriers in ms (0 = 2000)

@@ -823,9 +823,10 @@ void gf_msweep_status_reset() {   // experiments (gf_tune("spmm_status_reset", 1
 bool gf_msweep_applicable(const gf_csr_dev& m, int N, int B, int W) {
     // rows of 32 columns, or of 2 / 3 / 4 slabs of 32 (the image is the same: a slab is a 128-byte column block of the row); an image; one
     // workgroup per CU on a 256-CU device (8 XCDs x 32 CUs x 4 SIMDs = the 128 waves per XCD of the image); 32-bit byte offsets inside a
-    // tap; enough (entry, slab) pairs to give every XCD one
+    // tap; enough (entry, slab) pairs: an XCD walks a pair in ~65 us per hop however many of the 8 are busy, SELL-8 takes 0.02 ms per pair -- from 5 pairs
+    // on the sweep wins (5 .. 7 pairs: 0.074-0.076 against 0.094-0.107 ms per hop at config 4's graph; profiles/r06_l_share/share_short.log)
     return (W == 32 || W == 64 || W == 96 || W == 128) && m.ms_ent && m.ms_rows && m.ms_sets >= 2 * kMsDepth && (m.ms_uniform || m.ms_val) &&
-           cu_count() == 256 && B * (W / 32) >= 8 && (int64_t)N * 128 < (int64_t)kMsPad;
+           cu_count() == 256 && B * (W / 32) >= g_tune.spmm_minwork && (int64_t)N * 128 < (int64_t)kMsPad;
 }
 
 int gf_msweep_launch(const gf_csr_dev& m, const float* Xin, float* Xtaps, int64_t tapStride, int nhops, int N, int B, int W, hipStream_t st,

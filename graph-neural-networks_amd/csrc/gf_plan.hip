@@ -71,6 +71,7 @@ extern "C" int gf_tune(const char* key, int32_t value) {
     else if (!strcmp(key, "spmm_xlayout")) g_tune.spmm_xlayout = value;
     else if (!strcmp(key, "spmm_hublim")) g_tune.spmm_hublim = value;
     else if (!strcmp(key, "spmm_census")) g_tune.spmm_census = value;
+    else if (!strcmp(key, "spmm_minwork")) g_tune.spmm_minwork = value < 1 ? 1 : value;
     else if (!strcmp(key, "spmm_tmo_ms")) g_tune.spmm_tmo_ms = value;
     else if (!strcmp(key, "spmm_status_reset")) gf_msweep_status_reset();
     else if (!strcmp(key, "spmm_passes")) g_tune.spmm_passes = value;

@@ -270,7 +270,8 @@ int gf_time_spmm_hop(const gf_plan* plan, int32_t op, const float* X_in, float* 
  * beyond the mean group length in percent, passes allowed per batch entry; read by gf_plan_create), timing-only: "spmm_srcmask",
  * "spmm_trace"; tests of the abandon-and-repair path: "spmm_census" (1 = census called bad | 2 = one workgroup claims the next XCC |
  * 3 = one workgroup never arrives), "spmm_tmo_ms" (time limit of census / barriers, 0 = 2000), "spmm_status_reset"; "spmm_xlayout" (0/1 the boundary layout pass
- * inside the fused chain launch), "spmm_hublim" (image: rows longer than this are hub rows, 0 = the builder's cost model; read by gf_plan_create); "spmm_xcd" (0/1),
+ * inside the fused chain launch), "spmm_hublim" (image: rows longer than this are hub rows, 0 = the builder's cost model; read by gf_plan_create); "spmm_minwork" (fewest (batch entry,
+ * 32-column slab) pairs the sweep takes, default 5: below, SELL-8 is faster); "spmm_xcd" (0/1),
  * "spmm_group" (0/1 locality groups in the row schedule of graphs with N >= 32768; read by gf_plan_create),
  * "spmm_pf" (workgroups per tile prefetching the next gather panel, -1 = heuristic, 0 = off), "spmm_ucap" (0 | 8 | 16 gathers in flight per lane), "spmm_load" (0 = plain | 1 = non-temporal gather loads),
  * "spmm_store" (0 = plain | 1 = write-through sc1 | 2 = non-temporal output stores), "contract_generic" (0/1),

@@ -27,7 +27,8 @@ def tune(**kw):
 @pytest.fixture
 def knobs():
     yield tune
-    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=0, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1, spmm_xlayout=1)
+    tune(spmm_algo=0, spmm_bar=0, spmm_slack=5, spmm_group=1, spmm_pfd=0, spmm_census=0, spmm_tmo_ms=0, spmm_fuse=1, spmm_status_reset=1, spmm_xlayout=1,
+         spmm_minwork=5)
 
 
 def hop(plans, op, Xt, algo, **kw):
@@ -418,3 +419,29 @@ def test_two_edge_features_on_a_large_graph_are_bitwise_sell(knobs):
     assert _lib.lib().gf_spmm_hop_kernel(gso.plans(DEV)[0], 0, 8, 32) == 1
     for a, r, name in zip(outs[1], outs[0], ("y", "dx", "dh", "db")):
         assert torch.equal(a, r), name
+
+
+@pytest.mark.parametrize("graph,n,B,W,K", [("er", 100000, 5, 32, 4), ("erw", 60000, 7, 32, 3), ("er", 66000, 3, 64, 3), ("powerlaw", 60000, 6, 32, 3),
+                                           ("er", 52000, 2, 96, 3)])
+def test_work_lists_of_five_to_seven_pairs_run_as_the_sweep(graph, n, B, W, K, knobs):
+    """Round 6: the sweep takes work lists from 5 (batch entry, 32-column slab) pairs on (an XCD walks a pair in the same time alone or beside seven
+    others; from 5 pairs that beats SELL-8: profiles/r06_l_share/); XCDs beyond the list leave at once.  Default path: the fused chain and the
+    hop-by-hop launches bit for bit SELL-8 (rows the image splits: 1e-6), a repaired launch too; 4 pairs stay with SELL-8."""
+    A = powerlaw(n, 5, seed=n) if graph == "powerlaw" else er(n, 4, seed=n + B, weighted=graph == "erw")
+    gso = SparseGSO([A])
+    plans = gso.plans(DEV)
+    L = _lib.lib()
+    x0 = torch.randn(B, n, W, device=DEV)
+    assert L.gf_spmm_hop_kernel(plans[0], 0, 4 // (W // 32), W) == 0
+    for op in (0, 1):
+        assert L.gf_spmm_hop_kernel(plans[0], op, B, W) == 1
+        sell = khop_chain(plans, x0, K, op, spmm_algo=3)
+        for kw in (dict(spmm_fuse=1), dict(spmm_fuse=0), dict(spmm_fuse=1, spmm_census=1)):
+            tune(spmm_status_reset=1)
+            got = khop_chain(plans, x0, K, op, spmm_algo=0, **kw)
+            assert chain_status()[0] == (1 if "spmm_census" in kw else 0)
+            if msweep_info(plans[0], op)["hub_split_rows"] == 0:
+                assert torch.equal(got, sell), (op, kw, int((got != sell).sum()))
+            else:
+                assert float((got - sell).abs().max()) <= 1e-5 * float(sell.abs().max()), (op, kw)
+        tune(spmm_census=0, spmm_status_reset=1)

@@ -153,4 +153,16 @@ z)  # hub rows: the cost model's length limit against fixed ones (power-law grap
     PROBE_GRAPH=powerlaw timeout 300 python tools/hop_probe.py cfg4 5 spmm_hublim=$lim v:spmm_algo=0 v:spmm_algo=0 2>&1 | grep "khop chain\|image" | sed 's/khop chain cfg4 K=5 //;s/bitwise.*//' | tr '\n' ' ' | tee -a $O/hublim.log; echo | tee -a $O/hublim.log
   done
   ;;
+share)  # (NO-GO, code not kept: profiles/r06_l_share/shared_last_round.patch) the last round of a work list that is no multiple of 8, shared by groups of XCDs:
+    # chain time per hop with / without, and short work lists against SELL-8 (kept: the sweep from 5 pairs on, knob spmm_minwork)
+  for B in 9 10 12 17 20 100 129; do
+    PROBE_B=$B timeout 300 python tools/hop_probe.py cfg4 5 v:spmm_share=0 v:spmm_share=1 v:spmm_share=0 v:spmm_share=1 2>&1 | grep "khop chain" | sed "s/^/B=$B  /;s/khop chain cfg4 K=5 //" | tee -a $O/share.log
+  done
+  for B in 1 2 3 4 5 6 7; do
+    PROBE_B=$B timeout 300 python tools/hop_probe.py cfg4 5 spmm_minwork=1 v:spmm_algo=3 v:spmm_algo=5+spmm_share=1 v:spmm_algo=5+spmm_share=0 v:spmm_algo=3 v:spmm_algo=5+spmm_share=1 2>&1 | grep "khop chain" | sed "s/^/B=$B  /;s/khop chain cfg4 K=5 //" | tee -a $O/share_short.log
+  done
+  for W in 64 128; do for B in 1 3 5; do
+    PROBE_W=$W PROBE_B=$B timeout 300 python tools/hop_probe.py cfg4 5 spmm_minwork=1 v:spmm_algo=3 v:spmm_algo=5+spmm_share=1 v:spmm_algo=5+spmm_share=0 2>&1 | grep "khop chain" | sed "s/^/W=$W B=$B  /;s/khop chain cfg4 K=5 //" | tee -a $O/share_short.log
+  done; done
+  ;;
 esac

@@ -47,7 +47,7 @@ for it in range(cases):
     F = int(rng.choice([32, 32, 64, 16, 128]))
     K = int(rng.choice([1, 2, 3, 5]))
     E = int(rng.choice([1, 1, 1, 2]))
-    B = int(rng.choice([8, 9, 12, 16]))
+    B = int(rng.choice([5, 6, 8, 9, 12, 16]))
     bias = bool(rng.randint(4))
     Nin = n if rng.randint(3) else int(n * rng.uniform(0.5, 0.99))
     act = "relu" if rng.randint(3) == 0 else None
