@@ -247,7 +247,7 @@ int gf_lsigf_backward_ex(const gf_plan* const* plans, int32_t E, const float* dy
 /* ---- measurement hook: run ONE hop `iters` times on `stream` bracketed by HIP events on that stream and return
  * the average milliseconds per launch (bench.py's roofline leg; hipEvents see the launch stream, torch events may not). */
 /* which kernel a node-major hop of this shape runs: 1 = spmm_msweep_kernel (the MFMA source sweep, gf_msweep.hip: W = 32 / 64 / 96 / 128 -- wide
- * rows as slabs of 32 columns --, graphs from 49 152 nodes on whose row groups balance, B * W / 32 >= 8; gf_khop then runs the K-1 hops of an
+ * rows as slabs of 32 columns --, graphs from 49 152 nodes on whose row groups balance, B * W / 32 >= 5; gf_khop then runs the K-1 hops of an
  * edge feature in ONE launch), 0 = spmm_sell_kernel / the others */
 int gf_spmm_hop_kernel(const gf_plan* plan, int32_t op, int32_t B, int32_t W);
 /* State of the fused chains of this process (no reference counterpart).  A fused launch opens with a census of its workgroups (32 on each of
