@@ -70,8 +70,8 @@ __global__ __launch_bounds__(GF_CHAIN_MAXT) void spmm_chain_kernel(const int32_t
     const int Tc = Wc * 64;
     const bool gatherer = wave < Wc;
     f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
-    // gathers address LDS absolutely (see gf_panel.hip): the dynamic panel is the only LDS object, so it starts at address 0
-    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+    // gathers address LDS absolutely (see gf_panel.hip): the dynamic panel is the only LDS object, so it starts at address 0 (the launcher
+    // asks the runtime that the kernel holds no static LDS: gf_require_no_static_lds)
     const unsigned regionB = (unsigned)(N + 1) * 16u;  // bytes between the two panels of a pass
     const int region4 = N + 1;                         // ... in float4
     const u32x4* col4 = reinterpret_cast<const u32x4*>(cols) + lane;  // [word][lane]: 8 x 16-bit columns = two group-rows
@@ -350,6 +350,7 @@ int gf_spmm_chain_launch(const gf_plan* plan, int op, const float* Xin, float* X
     const kern_t kern = np == 2 ? (uniform ? (kern_t)spmm_chain_kernel<1, 2> : (kern_t)spmm_chain_kernel<0, 2>)
                                 : (uniform ? (kern_t)spmm_chain_kernel<1, 1> : (kern_t)spmm_chain_kernel<0, 1>);
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
+    if (const int rc = gf_require_no_static_lds((const void*)kern, "spmm_chain_kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.cn_gtab, m.cn_rowoff, (const void*)m.cn_col8, m.cn_val4, m.pn_uval,
                        Xin, Xout, N, nPanels, m.cn_sets, nHops, tapStride, g_tune.spmm_store, storers);
     GF_LAUNCH_CHECK("spmm_chain_kernel");

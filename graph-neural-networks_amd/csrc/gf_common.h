@@ -228,6 +228,9 @@ int gf_spmm_chain_launch(const gf_plan* plan, int op, const float* Xin, float* X
                          hipStream_t st);
 // kernels that need more than 64 KiB of dynamic LDS: raise the limit once per (device, kernel), not on every launch
 hipError_t gf_grant_lds(const void* kernel, size_t lds_bytes);
+// kernels that address their dynamic LDS panel ABSOLUTELY (it must start at LDS address 0): GF_OK when the kernel's code object holds no static
+// __shared__ object, GF_ERR_UNSUPPORTED (with a message) otherwise -- asked of the runtime once per (device, kernel), before the launch
+int gf_require_no_static_lds(const void* kernel, const char* name);
 int gf_pack_panels_launch(const float* x, float* Xp, int B, int C, int Nin, int N, hipStream_t st, const float* mask);
 int gf_layout_masked_launch(const float* dy, const float* y, float* X, int B, int G, int Nin, int N, hipStream_t st);
 int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* Xout, int nPanels, hipStream_t st);

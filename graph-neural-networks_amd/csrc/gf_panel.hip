@@ -69,8 +69,8 @@ __global__ __launch_bounds__(1024) void spmm_panel_kernel(const int2* __restrict
     const colw* col4 = reinterpret_cast<const colw*>(cols) + lane;
     // gathers address LDS absolutely: the dynamic panel is this kernel's only LDS object, so it starts at LDS address 0 and a
     // stored byte offset IS the ds_read address (through the `panel` symbol the compiler adds a relocatable base -- a useless
-    // v_add per gather in an issue-bound loop)
-    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // a static __shared__ object would shift the panel
+    // v_add per gather in an issue-bound loop).  A static __shared__ object would shift the panel: the launcher asks the runtime that there
+    // is none (gf_require_no_static_lds) and refuses the launch otherwise
     const unsigned lds_zero = 0u;
     const f32x4* val4 = reinterpret_cast<const f32x4*>(vals) + lane;
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(1024) void spmm_panel_db_kernel(const int2* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nW = (int)(blockDim.x >> 6), Wg = nW - nLoaders;
     const bool gatherer = wave < Wg;
-    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // the panels start at LDS address 0 (absolute ds_read addresses)
+    // the panels start at LDS address 0 (absolute ds_read addresses; no static LDS: checked by the launcher, gf_require_no_static_lds)
     f32x4* lds4 = reinterpret_cast<f32x4*>(panel);
     const int region4 = N + 1;
     const unsigned regionB = (unsigned)region4 * 16u, bufB = NP * regionB;
@@ -557,6 +557,7 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
         if (gdb > nG) gdb = nG;
         auto kdb = uniform ? spmm_panel_db_kernel<1, 2> : spmm_panel_db_kernel<0, 2>;
         if (lds_db > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kdb, lds_db));
+        if (const int rc = gf_require_no_static_lds((const void*)kdb, "spmm_panel_db_kernel")) return rc;
         hipLaunchKernelGGL(kdb, dim3((unsigned)gdb), dim3(thr_db), lds_db, st, m.pn_slice, m.pn_oct, (const uint2*)m.pn_col2, m.pn_val4, m.pn_uval,
                            Xin, Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, m.pn_ushift, loaders);
         GF_LAUNCH_CHECK("spmm_panel_db_kernel");
@@ -568,6 +569,7 @@ int gf_spmm_panel_launch(const gf_plan* plan, int op, const float* Xin, float* X
                   : np == 2 ? (uniform ? (kern_t)spmm_panel_kernel<1, 2> : (kern_t)spmm_panel_kernel<0, 2>)
                             : (uniform ? (kern_t)spmm_panel_kernel<1, 1> : (kern_t)spmm_panel_kernel<0, 1>);
     if (lds > 64 * 1024) GF_HIP(gf_grant_lds((const void*)kern, lds));
+    if (const int rc = gf_require_no_static_lds((const void*)kern, "spmm_panel_kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(thr), lds, st, m.pn_slice, m.pn_oct, uniform ? (const void*)m.pn_col4 : (const void*)m.pn_col2, m.pn_val4, m.pn_uval, Xin,
                        Xout, N, m.pn_slices, nPanels, m.pn_sentinel, g_tune.spmm_store, m.pn_ushift, g_tune.panel_rotate, split);
     GF_LAUNCH_CHECK("spmm_panel_kernel");

@@ -53,6 +53,24 @@ hipError_t gf_grant_lds(const void* kernel, size_t lds_bytes) {
     return e;
 }
 
+int gf_require_no_static_lds(const void* kernel, const char* name) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> checked;
+    int dev = 0;
+    GF_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (checked.count({dev, kernel})) return GF_OK;
+    hipFuncAttributes attr;
+    GF_HIP(hipFuncGetAttributes(&attr, kernel));
+    if (attr.sharedSizeBytes != 0) {
+        gf_set_error("%s: the kernel holds %zu bytes of static LDS; its gathers address the dynamic panel from LDS address 0 (build error, not a data error)",
+                     name, (size_t)attr.sharedSizeBytes);
+        return GF_ERR_UNSUPPORTED;
+    }
+    checked.insert({dev, kernel});
+    return GF_OK;
+}
+
 extern "C" int gf_tune(const char* key, int32_t value) {
     GF_REQUIRE_ARG(key != nullptr, "gf_tune: key is NULL");
     if (!g_experiments) {
