@@ -4,7 +4,8 @@ rows, the layout pass inside the fused launch) through the host layer, forward +
 graphML.py:152-175 and :2125-2144 restated with sparse S).  Varies: graph kind, weights, G / F (also widths the sweep does not take), K (also 1),
 E (1, 2), bias, Nin < N (the layer pads, graphML.py:2131-2135), fused ReLU (SelectionGNN's layers), batch sizes that are no multiple of 8.
 y / dx on two batch entries, dh / db on the whole batch; tolerances of tests/_util.py.
-usage: python tools/layer_fuzz.py [cases] [seed]        (test infrastructure: the oracle is the checker, never the path measured)"""
+usage: [FUZZ_N=100,1682,5000,...] [FUZZ_B=1,3,20,...] python tools/layer_fuzz.py [cases] [seed]   (other graph sizes / batch sizes: the panel, chain and
+SELL-8 pipelines; test infrastructure: the oracle is the checker, never the path measured)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-neural-networks_amd"), os.path.join(ROOT, "tests")]
@@ -39,7 +40,7 @@ def graph(kind, n, deg, weighted, seed):
 
 bad = 0
 for it in range(cases):
-    n = int(rng.choice([33000, 50000, 65536, 100000, 131000, 204800]))
+    n = int(rng.choice([int(v) for v in os.environ["FUZZ_N"].split(",")] if os.environ.get("FUZZ_N") else [33000, 50000, 65536, 100000, 131000, 204800]))
     kind = str(rng.choice(["er", "er", "powerlaw", "directed"]))
     deg = int(rng.choice([4, 10, 16]))
     weighted = bool(rng.randint(2))
@@ -47,7 +48,7 @@ for it in range(cases):
     F = int(rng.choice([32, 32, 64, 16, 128]))
     K = int(rng.choice([1, 2, 3, 5]))
     E = int(rng.choice([1, 1, 1, 2]))
-    B = int(rng.choice([5, 6, 8, 9, 12, 16]))
+    B = int(rng.choice([int(v) for v in os.environ["FUZZ_B"].split(",")] if os.environ.get("FUZZ_B") else [5, 6, 8, 9, 12, 16]))
     bias = bool(rng.randint(4))
     Nin = n if rng.randint(3) else int(n * rng.uniform(0.5, 0.99))
     act = "relu" if rng.randint(3) == 0 else None
