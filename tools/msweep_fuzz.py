@@ -26,7 +26,7 @@ for it in range(cases):
     B = int(rng.choice([3, 8, 9, 16, 33]))
     B = max(B, -(-8 // (W // 32)))
     while K * B * n * W * 4 > 6e9: B = max(1, B // 2)
-    if B * (W // 32) < 8: continue
+    if B * (W // 32) < 5: continue
     if kind == "powerlaw":
         d = np.minimum(n // 8, (0.5 * deg / np.sqrt(np.maximum(rng.uniform(size=n), 1e-9))).astype(np.int64))
     else:
