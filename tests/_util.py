@@ -60,3 +60,19 @@ class ArrayData:
         import torch
         wrong = torch.sum(torch.abs(torch.argmax(yHat, dim=1) - y) > tol)
         return wrong.to(self.dtype) / len(y)
+
+
+def large_gfilter_inputs(N, B, G, Nin, seed):
+    """Inputs of tests/golden/large/gfilter_*.npz, regenerated from the seed (numpy's legacy RandomState is stable across versions): the GSO as scipy CSR
+    (an undirected graph of mean degree ~6 with per-edge weights, no self loops), x [B,G,Nin], dy [B,F,Nin] is drawn by the caller's F.  The fixture
+    stores the checksums that pin the regeneration (nnz, sum of the weights, sum of x)."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(seed)
+    r = np.repeat(np.arange(N), 3)
+    c = rng.randint(0, N, size=r.size)
+    A = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(N, N))
+    A = sp.triu(A + A.T, k=1).tocsr()
+    A.data[:] = rng.uniform(0.05, 0.2, size=A.data.size)
+    A = sp.csr_matrix(A + A.T)
+    x = rng.randn(B, G, Nin)
+    return A, x

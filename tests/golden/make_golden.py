@@ -712,5 +712,45 @@ def main():
     local_gnn_case("sbm100_pool", sbm, [2, 8, 8], [3, 3], [30, 12], "MaxPoolLocal", [2, 3], [6, 3], B=4, seed=2)
 
 
+def large_graph_filter_case(name, N, B, G, F, K, Nin, seed, nsample=1024):
+    """The LITERAL reference at the size where the node-major hop becomes the MFMA source sweep (round 6; the smallest graph that path serves by
+    default is 49 152 nodes): gml.GraphFilter with the DENSE S [1, N, N] in float64 (19 GB at N = 49 152), forward and autograd.  torch.matmul would
+    materialise the broadcast S once per batch entry, so the layer is called entry by entry (the reference's own code on x[b:b+1]; the parameter
+    gradients accumulate over the calls, as autograd defines them).  The fixture holds no inputs but the seed (tests/_util.py: large_gfilter_inputs
+    regenerates graph and signals; checksums pin that), the parameters, and of the outputs: y and dx at `nsample` random nodes, their sums and sums of
+    squares over ALL nodes per (b, feature), dweight and dbias in full.  Not part of the unflagged recipe (minutes, 25 GB): --large-only writes
+    tests/golden/large/."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from _util import large_gfilter_inputs
+    out_dir = os.path.join(OUT, "large")
+    os.makedirs(out_dir, exist_ok=True)
+    A, x = large_gfilter_inputs(N, B, G, Nin, seed)
+    rng = np.random.RandomState(seed + 1)
+    dy = rng.randn(B, F, Nin)
+    idx = np.sort(rng.choice(Nin, size=nsample, replace=False))
+    torch.manual_seed(seed)
+    layer = gml.GraphFilter(G, F, K, 1, True)
+    S = A.toarray()[None]                                        # the reference's dense [E, N, N]
+    layer.addGSO(torch.from_numpy(S))
+    ys, dxs = [], []
+    for b in range(B):
+        xt = torch.tensor(x[b:b + 1], requires_grad=True)
+        y = layer(xt)                                            # graphML.py:2125-2144 -> LSIGF :83-176
+        y.backward(torch.tensor(dy[b:b + 1]))
+        ys.append(y.detach().numpy()[0])
+        dxs.append(xt.grad.numpy()[0])
+        print(f"  entry {b}: max|y| {np.abs(ys[-1]).max():.3g}", flush=True)
+    y, dx = np.stack(ys), np.stack(dxs)
+    np.savez_compressed(os.path.join(out_dir, f"gfilter_{name}.npz"), cfg=np.array([N, B, G, F, K, Nin, seed, nsample], dtype=np.int64), idx=idx.astype(np.int64),
+                        weight=layer.weight.detach().numpy(), bias=layer.bias.detach().numpy(), y_idx=y[:, :, idx], dx_idx=dx[:, :, idx],
+                        y_sum=y.sum(-1), y_sq=(y * y).sum(-1), dx_sum=dx.sum(-1), dx_sq=(dx * dx).sum(-1),
+                        dweight=layer.weight.grad.numpy(), dbias=layer.bias.grad.numpy(),
+                        check=np.array([A.nnz, A.data.sum(), x.sum(), dy.sum()], dtype=np.float64))
+    print(f"large/gfilter_{name}: N={N} Nin={Nin} nnz={A.nnz} B={B} {G}->{F} K={K}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--large-only" in sys.argv:
+        large_graph_filter_case("er49152_Nin48152", N=49152, B=8, G=32, F=32, K=3, Nin=48152, seed=11)
+    else:
+        main()

@@ -232,3 +232,35 @@ def test_power_law_graph_at_config4_size_against_oracle():
     dh, db = streamed_tap_grads(w, A, x.detach().cpu().numpy(), dy.cpu().numpy(), chunk=4)
     assert relerr(layer.weight.grad.cpu().numpy(), dh) < GRAD_RTOL
     assert relerr(layer.bias.grad.cpu().numpy(), db) < GRAD_RTOL
+
+
+def test_sweep_size_layer_against_the_literal_reference():
+    """tests/golden/large/ (round 6): the reference's own GraphFilter run with the dense 49 152 x 49 152 GSO in float64 -- forward + autograd, Nin < N -- at
+    the smallest size where the node-major hops are the MFMA source sweep (with the layout pass inside the fused launch, both orientations).  Default
+    path; y and dx at the fixture's 1024 nodes, their sums of squares over all nodes, dweight and dbias in full."""
+    import glob
+    import os
+    from _util import GOLDEN, large_gfilter_inputs
+    f = sorted(glob.glob(os.path.join(GOLDEN, "large", "gfilter_*.npz")))
+    assert f
+    d = dict(np.load(f[0], allow_pickle=False))
+    N, B, G, F, K, Nin, seed, _ = (int(v) for v in d["cfg"])
+    A, x = large_gfilter_inputs(N, B, G, Nin, seed)
+    dy = np.random.RandomState(seed + 1).randn(B, F, Nin)
+    assert A.nnz == int(d["check"][0]) and abs(x.sum() - d["check"][2]) < 1e-6
+    layer = gml.GraphFilter(G, F, K, 1, True)
+    layer.load_state_dict({"weight": torch.tensor(d["weight"], dtype=torch.float32), "bias": torch.tensor(d["bias"], dtype=torch.float32)})
+    layer.addGSO(A)
+    layer.to(DEV)
+    plans = layer._gso.plans(DEV)
+    assert _lib.lib().gf_spmm_hop_kernel(plans[0], 0, B, G) == 1 and _lib.lib().gf_spmm_hop_kernel(plans[0], 1, B, F) == 1
+    xt = torch.tensor(x, dtype=torch.float32, device=DEV, requires_grad=True)
+    y = layer(xt)
+    assert tuple(y.shape) == (B, F, Nin)
+    y.backward(torch.tensor(dy, dtype=torch.float32, device=DEV))
+    idx = d["idx"]
+    yh, dxh = y.detach().double().cpu().numpy(), xt.grad.double().cpu().numpy()
+    assert relerr(yh[:, :, idx], d["y_idx"]) < FWD_RTOL and relerr((yh * yh).sum(-1), d["y_sq"]) < FWD_RTOL
+    assert relerr(dxh[:, :, idx], d["dx_idx"]) < GRAD_RTOL and relerr((dxh * dxh).sum(-1), d["dx_sq"]) < GRAD_RTOL
+    assert relerr(layer.weight.grad.cpu().numpy(), d["dweight"]) < GRAD_RTOL
+    assert relerr(layer.bias.grad.cpu().numpy(), d["dbias"]) < GRAD_RTOL

@@ -182,3 +182,35 @@ def test_node_variant_oracle_matches_reference(path):
     if "f_h" in d:                                                  # functional form, per-node bias
         yf = nvo.nvgf_sparse(d["f_h"], [S[e] for e in range(E)], d["f_x"], d["f_b"])
         assert relerr(yf, d["f_y"]) < 1e-12
+
+
+def _large_case():
+    import glob
+    import os
+    from _util import GOLDEN, large_gfilter_inputs
+    f = sorted(glob.glob(os.path.join(GOLDEN, "large", "gfilter_*.npz")))
+    assert f, "tests/golden/large/gfilter_*.npz missing"
+    d = dict(np.load(f[0], allow_pickle=False))
+    N, B, G, F, K, Nin, seed, _ = (int(v) for v in d["cfg"])
+    A, x = large_gfilter_inputs(N, B, G, Nin, seed)
+    dy = np.random.RandomState(seed + 1).randn(B, F, Nin)
+    assert A.nnz == int(d["check"][0]) and abs(A.data.sum() - d["check"][1]) < 1e-9 and abs(x.sum() - d["check"][2]) < 1e-6 and abs(dy.sum() - d["check"][3]) < 1e-6, \
+        "the inputs regenerated from the seed are not the ones the fixture was made with"
+    return d, A, x, dy
+
+
+def test_sparse_restatement_matches_the_literal_reference_at_the_sweeps_size():
+    """tests/golden/large/: gml.GraphFilter run LITERALLY (dense S of 49 152 x 49 152 in float64, forward + autograd, Nin < N) at the smallest size the
+    MFMA source sweep serves -- until round 6 the sparse restatement had been checked against the literal reference up to N = 1e4 only.  y and dx at
+    1024 random nodes, their sums of squares over all nodes, dweight and dbias in full."""
+    d, A, x, dy = _large_case()
+    idx = d["idx"]
+    N, Nin = A.shape[0], x.shape[2]
+    y = orc.graph_filter_forward_sparse(d["weight"], d["bias"], A, x)
+    assert relerr(y[:, :, idx], d["y_idx"]) < 1e-12 and relerr((y * y).sum(-1), d["y_sq"]) < 1e-12 and relerr(y.sum(-1), d["y_sum"]) < 1e-10
+    xp = np.zeros((x.shape[0], x.shape[1], N)); xp[:, :, :Nin] = x
+    dyp = np.zeros((dy.shape[0], dy.shape[1], N)); dyp[:, :, :Nin] = dy
+    dx, dh, db = orc.lsigf_sparse_grads(d["weight"], A, xp, d["bias"], dyp)
+    dx = dx[:, :, :Nin]
+    assert relerr(dx[:, :, idx], d["dx_idx"]) < 1e-12 and relerr((dx * dx).sum(-1), d["dx_sq"]) < 1e-12
+    assert relerr(dh, d["dweight"]) < 1e-11 and relerr(db, d["dbias"]) < 1e-11
