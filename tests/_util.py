@@ -62,17 +62,25 @@ class ArrayData:
         return wrong.to(self.dtype) / len(y)
 
 
-def large_gfilter_inputs(N, B, G, Nin, seed):
+def large_gfilter_inputs(N, B, G, Nin, seed, kind=0):
     """Inputs of tests/golden/large/gfilter_*.npz, regenerated from the seed (numpy's legacy RandomState is stable across versions): the GSO as scipy CSR
-    (an undirected graph of mean degree ~6 with per-edge weights, no self loops), x [B,G,Nin], dy [B,F,Nin] is drawn by the caller's F.  The fixture
+    (kind 0: an undirected graph of mean degree ~6 with per-edge weights, no self loops; kind 1: directed with power-law row lengths), x [B,G,Nin], dy [B,F,Nin] is drawn by the caller's F.  The fixture
     stores the checksums that pin the regeneration (nnz, sum of the weights, sum of x)."""
     import scipy.sparse as sp
     rng = np.random.RandomState(seed)
-    r = np.repeat(np.arange(N), 3)
-    c = rng.randint(0, N, size=r.size)
-    A = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(N, N))
-    A = sp.triu(A + A.T, k=1).tocsr()
-    A.data[:] = rng.uniform(0.05, 0.2, size=A.data.size)
-    A = sp.csr_matrix(A + A.T)
+    if kind == 1:        # directed, row lengths with a power-law tail (a few rows of hundreds to thousands of entries: the sweep's hub rows), weighted
+        deg = np.minimum(N // 8, (3.0 / np.sqrt(np.maximum(rng.uniform(size=N), 1e-9))).astype(np.int64))
+        r = np.repeat(np.arange(N), deg)
+        A = sp.csr_matrix((np.ones(r.size), (r, rng.randint(0, N, size=r.size))), shape=(N, N))
+        A.sum_duplicates()
+        A.data[:] = rng.uniform(0.2, 1.0, size=A.data.size) / 24.0
+        A = sp.csr_matrix(A)
+    else:
+        r = np.repeat(np.arange(N), 3)
+        c = rng.randint(0, N, size=r.size)
+        A = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(N, N))
+        A = sp.triu(A + A.T, k=1).tocsr()
+        A.data[:] = rng.uniform(0.05, 0.2, size=A.data.size)
+        A = sp.csr_matrix(A + A.T)
     x = rng.randn(B, G, Nin)
     return A, x

@@ -712,7 +712,7 @@ def main():
     local_gnn_case("sbm100_pool", sbm, [2, 8, 8], [3, 3], [30, 12], "MaxPoolLocal", [2, 3], [6, 3], B=4, seed=2)
 
 
-def large_graph_filter_case(name, N, B, G, F, K, Nin, seed, nsample=1024):
+def large_graph_filter_case(name, N, B, G, F, K, Nin, seed, nsample=1024, kind=0):
     """The LITERAL reference at the size where the node-major hop becomes the MFMA source sweep (round 6; the smallest graph that path serves by
     default is 49 152 nodes): gml.GraphFilter with the DENSE S [1, N, N] in float64 (19 GB at N = 49 152), forward and autograd.  torch.matmul would
     materialise the broadcast S once per batch entry, so the layer is called entry by entry (the reference's own code on x[b:b+1]; the parameter
@@ -724,7 +724,7 @@ def large_graph_filter_case(name, N, B, G, F, K, Nin, seed, nsample=1024):
     from _util import large_gfilter_inputs
     out_dir = os.path.join(OUT, "large")
     os.makedirs(out_dir, exist_ok=True)
-    A, x = large_gfilter_inputs(N, B, G, Nin, seed)
+    A, x = large_gfilter_inputs(N, B, G, Nin, seed, kind)
     rng = np.random.RandomState(seed + 1)
     dy = rng.randn(B, F, Nin)
     idx = np.sort(rng.choice(Nin, size=nsample, replace=False))
@@ -741,7 +741,7 @@ def large_graph_filter_case(name, N, B, G, F, K, Nin, seed, nsample=1024):
         dxs.append(xt.grad.numpy()[0])
         print(f"  entry {b}: max|y| {np.abs(ys[-1]).max():.3g}", flush=True)
     y, dx = np.stack(ys), np.stack(dxs)
-    np.savez_compressed(os.path.join(out_dir, f"gfilter_{name}.npz"), cfg=np.array([N, B, G, F, K, Nin, seed, nsample], dtype=np.int64), idx=idx.astype(np.int64),
+    np.savez_compressed(os.path.join(out_dir, f"gfilter_{name}.npz"), cfg=np.array([N, B, G, F, K, Nin, seed, nsample] + ([kind] if kind else []), dtype=np.int64), idx=idx.astype(np.int64),
                         weight=layer.weight.detach().numpy(), bias=layer.bias.detach().numpy(), y_idx=y[:, :, idx], dx_idx=dx[:, :, idx],
                         y_sum=y.sum(-1), y_sq=(y * y).sum(-1), dx_sum=dx.sum(-1), dx_sq=(dx * dx).sum(-1),
                         dweight=layer.weight.grad.numpy(), dbias=layer.bias.grad.numpy(),
@@ -751,6 +751,9 @@ def large_graph_filter_case(name, N, B, G, F, K, Nin, seed, nsample=1024):
 
 if __name__ == "__main__":
     if "--large-only" in sys.argv:
-        large_graph_filter_case("er49152_Nin48152", N=49152, B=8, G=32, F=32, K=3, Nin=48152, seed=11)
+        if "--second" not in sys.argv:
+            large_graph_filter_case("er49152_Nin48152", N=49152, B=8, G=32, F=32, K=3, Nin=48152, seed=11)
+        if "--first" not in sys.argv:     # 64 -> 32 on a directed power-law graph: wide rows forward, hub rows in the adjoint orientation
+            large_graph_filter_case("pl49152_G64", N=49152, B=6, G=64, F=32, K=3, Nin=49152, seed=12, kind=1)
     else:
         main()

@@ -234,18 +234,24 @@ def test_power_law_graph_at_config4_size_against_oracle():
     assert relerr(layer.bias.grad.cpu().numpy(), db) < GRAD_RTOL
 
 
-def test_sweep_size_layer_against_the_literal_reference():
-    """tests/golden/large/ (round 6): the reference's own GraphFilter run with the dense 49 152 x 49 152 GSO in float64 -- forward + autograd, Nin < N -- at
-    the smallest size where the node-major hops are the MFMA source sweep (with the layout pass inside the fused launch, both orientations).  Default
-    path; y and dx at the fixture's 1024 nodes, their sums of squares over all nodes, dweight and dbias in full."""
+def _large_files():
     import glob
     import os
-    from _util import GOLDEN, large_gfilter_inputs
-    f = sorted(glob.glob(os.path.join(GOLDEN, "large", "gfilter_*.npz")))
-    assert f
-    d = dict(np.load(f[0], allow_pickle=False))
-    N, B, G, F, K, Nin, seed, _ = (int(v) for v in d["cfg"])
-    A, x = large_gfilter_inputs(N, B, G, Nin, seed)
+    from _util import GOLDEN
+    return sorted(glob.glob(os.path.join(GOLDEN, "large", "gfilter_*.npz")))
+
+
+@pytest.mark.parametrize("path", _large_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_sweep_size_layer_against_the_literal_reference(path):
+    """tests/golden/large/ (round 6): the reference's own GraphFilter run with the dense 49 152 x 49 152 GSO in float64 -- forward + autograd -- at the
+    smallest size where the node-major hops are the MFMA source sweep: an undirected weighted graph, 32 -> 32, Nin < N (layout pass inside the fused
+    launch, both orientations); a directed power-law graph, 64 -> 32 (wide rows forward, hub rows in the adjoint orientation).  Default path; y and dx
+    at the fixture's 1024 nodes, their sums of squares over all nodes, dweight and dbias in full."""
+    from _util import large_gfilter_inputs
+    d = dict(np.load(path, allow_pickle=False))
+    N, B, G, F, K, Nin, seed = (int(v) for v in d["cfg"][:7])
+    kind = int(d["cfg"][8]) if len(d["cfg"]) > 8 else 0
+    A, x = large_gfilter_inputs(N, B, G, Nin, seed, kind)
     dy = np.random.RandomState(seed + 1).randn(B, F, Nin)
     assert A.nnz == int(d["check"][0]) and abs(x.sum() - d["check"][2]) < 1e-6
     layer = gml.GraphFilter(G, F, K, 1, True)

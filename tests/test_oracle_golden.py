@@ -184,26 +184,36 @@ def test_node_variant_oracle_matches_reference(path):
         assert relerr(yf, d["f_y"]) < 1e-12
 
 
-def _large_case():
+def _large_files():
     import glob
     import os
-    from _util import GOLDEN, large_gfilter_inputs
-    f = sorted(glob.glob(os.path.join(GOLDEN, "large", "gfilter_*.npz")))
-    assert f, "tests/golden/large/gfilter_*.npz missing"
-    d = dict(np.load(f[0], allow_pickle=False))
-    N, B, G, F, K, Nin, seed, _ = (int(v) for v in d["cfg"])
-    A, x = large_gfilter_inputs(N, B, G, Nin, seed)
+    from _util import GOLDEN
+    return sorted(glob.glob(os.path.join(GOLDEN, "large", "gfilter_*.npz")))
+
+
+def _large_case(path):
+    from _util import large_gfilter_inputs
+    d = dict(np.load(path, allow_pickle=False))
+    N, B, G, F, K, Nin, seed = (int(v) for v in d["cfg"][:7])
+    kind = int(d["cfg"][8]) if len(d["cfg"]) > 8 else 0
+    A, x = large_gfilter_inputs(N, B, G, Nin, seed, kind)
     dy = np.random.RandomState(seed + 1).randn(B, F, Nin)
     assert A.nnz == int(d["check"][0]) and abs(A.data.sum() - d["check"][1]) < 1e-9 and abs(x.sum() - d["check"][2]) < 1e-6 and abs(dy.sum() - d["check"][3]) < 1e-6, \
         "the inputs regenerated from the seed are not the ones the fixture was made with"
     return d, A, x, dy
 
 
-def test_sparse_restatement_matches_the_literal_reference_at_the_sweeps_size():
-    """tests/golden/large/: gml.GraphFilter run LITERALLY (dense S of 49 152 x 49 152 in float64, forward + autograd, Nin < N) at the smallest size the
-    MFMA source sweep serves -- until round 6 the sparse restatement had been checked against the literal reference up to N = 1e4 only.  y and dx at
-    1024 random nodes, their sums of squares over all nodes, dweight and dbias in full."""
-    d, A, x, dy = _large_case()
+def test_large_fixtures_present():
+    assert len(_large_files()) >= 2
+
+
+@pytest.mark.parametrize("path", _large_files(), ids=case_id)
+def test_sparse_restatement_matches_the_literal_reference_at_the_sweeps_size(path):
+    """tests/golden/large/: gml.GraphFilter run LITERALLY (dense S of 49 152 x 49 152 in float64, forward + autograd) at the smallest size the MFMA
+    source sweep serves -- until round 6 the sparse restatement had been checked against the literal reference up to N = 1e4 only.  (An undirected
+    weighted graph with Nin < N, 32 -> 32; a directed power-law graph, 64 -> 32.)  y and dx at 1024 random nodes, their sums of squares over all
+    nodes, dweight and dbias in full."""
+    d, A, x, dy = _large_case(path)
     idx = d["idx"]
     N, Nin = A.shape[0], x.shape[2]
     y = orc.graph_filter_forward_sparse(d["weight"], d["bias"], A, x)
