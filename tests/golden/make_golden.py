@@ -702,6 +702,16 @@ def main():
     selection_gnn_case("cfg1_sbm100", sbm, [1, 32, 32], [5, 5], [10, 10], "MaxPoolLocal", [6, 8], [5], B=6)
     # config 3 shapes (examples/movieGNN.py:259-276): F=[1,64,32], K=[5,5], NoPool, MLP [1]; graph = fbego (MovieLens needs network)
     selection_gnn_case("cfg3_fbego", fb[0], [1, 64, 32], [5, 5], [234, 234], "NoPool", [1, 1], [1], B=5)
+    # a mid-size graph (round 6): N = 5200 is beyond the two-panel LDS limit (5119) -- the K-hop chain kernel with one panel per workgroup --
+    # with MaxPoolLocal down to 1300 and 260 nodes (zero-padded second layer, neighbourhoods of 2 and 3 hops on a 5200-node graph)
+    rng = np.random.RandomState(44)
+    r = np.repeat(np.arange(5200), 5)
+    c = rng.randint(0, 5200, size=r.size)
+    mid = np.zeros((5200, 5200))
+    mid[r, c] = 1.0
+    mid = ((mid + mid.T) > 0) * (1.0 / 14.0)
+    np.fill_diagonal(mid, 0.0)
+    selection_gnn_case("mid_rnd5200", mid, [1, 32, 32], [5, 5], [1300, 260], "MaxPoolLocal", [2, 3], [5], B=4, seed=5)
     # ---- the callers that reuse LSIGF and the trainer run (row f-4): the same calls as the
     # --*-only flags above, so that the unflagged recipe regenerates EVERY committed fixture
     nvgf_cases(sbm, asym, asym37, ring)

@@ -247,9 +247,10 @@ def test_graph_filter_zero_padding_matches_reference(path):
     assert relerr(layer.bias.grad.cpu().numpy(), d["dbias"]) < GRAD_RTOL
 
 
-@pytest.mark.parametrize("name", ["cfg1_sbm100", "cfg3_fbego"])
+@pytest.mark.parametrize("name", ["cfg1_sbm100", "cfg3_fbego", "mid_rnd5200"])
 def test_selection_gnn_matches_reference(name):
-    """BASELINE configs[0] (sourceLocGNN SBM N=100, K=5, F=[1,32,32]) and the config-3 architecture, with the
+    """BASELINE configs[0] (sourceLocGNN SBM N=100, K=5, F=[1,32,32]), the config-3 architecture, and (round 6) the config-1 architecture on a
+    5200-node graph with MaxPoolLocal down to 1300 / 260 nodes (one-panel chain kernel, pooling neighbourhoods on a mid-size graph), with the
     reference's weights: forward, input gradient and every parameter gradient."""
     d = load(os.path.join(GOLDEN, f"selgnn_{name}.npz"))
     cfg = d["cfg"]
