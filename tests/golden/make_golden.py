@@ -759,11 +759,17 @@ def large_graph_filter_case(name, N, B, G, F, K, Nin, seed, nsample=1024, kind=0
     print(f"large/gfilter_{name}: N={N} Nin={Nin} nnz={A.nnz} B={B} {G}->{F} K={K}")
 
 
+LARGE = [  # python tests/golden/make_golden.py --large-only [name ...]
+    dict(name="er49152_Nin48152", N=49152, B=8, G=32, F=32, K=3, Nin=48152, seed=11),           # the sweep's smallest size, layout pass with Nin < N
+    dict(name="pl49152_G64", N=49152, B=6, G=64, F=32, K=3, Nin=49152, seed=12, kind=1),        # directed power-law graph: wide rows forward, hub rows in the adjoint
+    dict(name="er10000_K5", N=10000, B=8, G=32, F=32, K=5, Nin=10000, seed=13),                 # config 2's size and taps: the LDS panel pipeline
+]
+
 if __name__ == "__main__":
     if "--large-only" in sys.argv:
-        if "--second" not in sys.argv:
-            large_graph_filter_case("er49152_Nin48152", N=49152, B=8, G=32, F=32, K=3, Nin=48152, seed=11)
-        if "--first" not in sys.argv:     # 64 -> 32 on a directed power-law graph: wide rows forward, hub rows in the adjoint orientation
-            large_graph_filter_case("pl49152_G64", N=49152, B=6, G=64, F=32, K=3, Nin=49152, seed=12, kind=1)
+        want = [a for a in sys.argv[sys.argv.index("--large-only") + 1:] if not a.startswith("--") and a != OUT]
+        for c in LARGE:
+            if not want or c["name"] in want:
+                large_graph_filter_case(**c)
     else:
         main()

@@ -245,7 +245,8 @@ def _large_files():
 def test_sweep_size_layer_against_the_literal_reference(path):
     """tests/golden/large/ (round 6): the reference's own GraphFilter run with the dense 49 152 x 49 152 GSO in float64 -- forward + autograd -- at the
     smallest size where the node-major hops are the MFMA source sweep: an undirected weighted graph, 32 -> 32, Nin < N (layout pass inside the fused
-    launch, both orientations); a directed power-law graph, 64 -> 32 (wide rows forward, hub rows in the adjoint orientation).  Default path; y and dx
+    launch, both orientations); a directed power-law graph, 64 -> 32 (wide rows forward, hub rows in the adjoint orientation); and the same literal run at config 2's size
+    and taps (N = 1e4, K = 5: the LDS panel pipeline).  Default path; y and dx
     at the fixture's 1024 nodes, their sums of squares over all nodes, dweight and dbias in full."""
     from _util import large_gfilter_inputs
     d = dict(np.load(path, allow_pickle=False))
@@ -259,7 +260,10 @@ def test_sweep_size_layer_against_the_literal_reference(path):
     layer.addGSO(A)
     layer.to(DEV)
     plans = layer._gso.plans(DEV)
-    assert _lib.lib().gf_spmm_hop_kernel(plans[0], 0, B, G) == 1 and _lib.lib().gf_spmm_hop_kernel(plans[0], 1, B, F) == 1
+    if N >= 49152:
+        assert _lib.lib().gf_spmm_hop_kernel(plans[0], 0, B, G) == 1 and _lib.lib().gf_spmm_hop_kernel(plans[0], 1, B, F) == 1
+    else:                                                  # config 2's size: the LDS panel pipeline (chain kernel, one-pass backward)
+        assert _lib.lib().gf_lsigf_pipeline(plans, 1, G, F, K) == 2
     xt = torch.tensor(x, dtype=torch.float32, device=DEV, requires_grad=True)
     y = layer(xt)
     assert tuple(y.shape) == (B, F, Nin)
